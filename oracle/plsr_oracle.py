@@ -1,0 +1,337 @@
+"""CPU oracle (numpy) for the plskern / plsnipals hot path of Jchemo.jl.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and only as the checker.  The product path
+(``jchemo.jl_amd/``) never imports this module and has no CPU fallback.
+
+PARITY UNPINNED.  The reference (`/root/reference`, Jchemo.jl v0.1.23) is pure
+Julia; there is no Julia toolchain in the build container and the reference
+ships no tests, golden vectors or fixtures for this path
+(`test/runtests.jl:1-2` only loads the package).  This restatement is pinned
+instead by (i) the algebraic invariants of a PLS fit, (ii) agreement between
+the two independent algorithms restated here (plskern vs plsnipals), (iii)
+scikit-learn's ``PLSRegression`` and LAPACK ``dgesdd`` through numpy (the same
+LAPACK routine Julia's ``svd`` calls), see ``tests/test_oracle.py``.
+
+Every function cites the reference lines it restates (paths relative to
+`/root/reference/`).  Arrays are float64; matrices are (n, p) numpy arrays in
+either memory order (the arithmetic is order-independent).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# Portable synthetic-input generator (shared with the HIP library and the C
+# oracle): element k of a stream is a pure function of (seed, k), so it can be
+# produced in parallel on the device and vectorised here.
+#   z_k = seed + (k + 1) * 0x9E3779B97F4A7C15        (splitmix64 state walk)
+#   z ^= z >> 30; z *= 0xBF58476D1CE4E5B9; z ^= z >> 27; z *= 0x94D049BB133111EB; z ^= z >> 31
+#   u_k = (z >> 11) * 2**-53  in [0, 1)
+# Matrices are filled in COLUMN-MAJOR order (Julia's `rand(n, p)` layout):
+# element (i, j) of an n_total x p matrix is u_{i + j * n_total}.
+# --------------------------------------------------------------------------
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64_uniform(seed: int, start: int, count: int) -> np.ndarray:
+    """u_k for k = start .. start+count-1 (float64 in [0,1))."""
+    with np.errstate(over="ignore"):
+        k = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + k * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def rand_matrix(seed: int, n: int, p: int, row0: int = 0, n_total: Optional[int] = None) -> np.ndarray:
+    """Rows [row0, row0+n) of the n_total x p column-major-filled matrix, as an
+    (n, p) Fortran-ordered float64 array."""
+    n_total = n if n_total is None else n_total
+    out = np.empty((n, p), dtype=np.float64, order="F")
+    for j in range(p):
+        out[:, j] = splitmix64_uniform(seed, row0 + j * n_total, n)
+    return out
+
+
+# --------------------------------------------------------------------------
+# Column utilities  (src/utility.jl)
+# --------------------------------------------------------------------------
+def ensure_mat(X) -> np.ndarray:
+    """src/utility.jl:544-548 — vector -> (n,1) matrix, number -> (1,1)."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 0:
+        return X.reshape(1, 1)
+    if X.ndim == 1:
+        return X.reshape(-1, 1)
+    return X
+
+
+def mweight(w) -> np.ndarray:
+    """src/utility.jl:715-723 — w / sum(w) (copy)."""
+    w = np.array(w, dtype=np.float64).reshape(-1)
+    return w / w.sum()
+
+
+def colmean(X, w) -> np.ndarray:
+    """src/utility.jl:195 — vec(mweight(w)' * X)."""
+    return mweight(w) @ ensure_mat(X)
+
+
+def colvar(X, w) -> np.ndarray:
+    """src/utility.jl:314-323 — two-pass weighted, uncorrected variance."""
+    X = ensure_mat(X)
+    w = mweight(w)
+    z = colmean(X, w)
+    return np.array([np.dot(w, (X[:, j] - z[j]) ** 2) for j in range(X.shape[1])])
+
+
+def colstd(X, w) -> np.ndarray:
+    """src/utility.jl:264."""
+    return np.sqrt(colvar(X, mweight(w)))
+
+
+def center_(X: np.ndarray, v: np.ndarray) -> None:
+    """src/utility.jl:76-81 — in place."""
+    X -= v[None, :]
+
+
+def cscale_(X: np.ndarray, u: np.ndarray, v: np.ndarray) -> None:
+    """src/utility.jl:482-487 — in place (X - u) / v."""
+    X -= u[None, :]
+    X /= v[None, :]
+
+
+# --------------------------------------------------------------------------
+# Result record  (src/plskern.jl:1-14)
+# --------------------------------------------------------------------------
+@dataclass
+class Plsr:
+    T: np.ndarray        # n x nlv
+    P: np.ndarray        # p x nlv
+    R: np.ndarray        # p x nlv
+    W: np.ndarray        # p x nlv
+    C: np.ndarray        # q x nlv
+    TT: np.ndarray       # nlv
+    xmeans: np.ndarray   # p
+    xscales: np.ndarray  # p
+    ymeans: np.ndarray   # q
+    yscales: np.ndarray  # q
+    weights: np.ndarray  # n (normalised)
+    niter: Optional[np.ndarray] = None
+
+
+def _preamble(X, Y, weights, nlv, scal):
+    """src/plskern.jl:114-130 (identical in src/plsnipals.jl:39-56).  Mutates X, Y."""
+    n, p = X.shape
+    q = Y.shape[1]
+    nlv = min(n, p, nlv)
+    weights = mweight(weights)
+    xmeans = colmean(X, weights)
+    ymeans = colmean(Y, weights)
+    xscales = np.ones(p)
+    yscales = np.ones(q)
+    if scal:
+        xscales = colstd(X, weights)
+        yscales = colstd(Y, weights)
+        cscale_(X, xmeans, xscales)
+        cscale_(Y, ymeans, yscales)
+    else:
+        center_(X, xmeans)
+        center_(Y, ymeans)
+    return n, p, q, nlv, weights, xmeans, ymeans, xscales, yscales
+
+
+def dominant_left_sv(K: np.ndarray) -> np.ndarray:
+    """src/plskern.jl:150-155 / src/plsnipals.jl:72-77 — q==1: normalised
+    column; else `svd(K).U[:, 1]` (LAPACK dgesdd via numpy; sign is LAPACK's)."""
+    if K.shape[1] == 1:
+        w = K[:, 0].copy()
+        return w / np.linalg.norm(w)
+    U, _, _ = np.linalg.svd(K, full_matrices=False)
+    return U[:, 0].copy()
+
+
+def plskern_(X: np.ndarray, Y: np.ndarray, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plskern!` — src/plskern.jl:112-178.  X and Y are overwritten with their
+    centred/scaled versions (F5)."""
+    assert X.dtype == np.float64 and Y.dtype == np.float64 and X.ndim == 2 and Y.ndim == 2
+    if weights is None:
+        weights = np.ones(X.shape[0])
+    n, p, q, nlv, weights, xmeans, ymeans, xscales, yscales = _preamble(X, Y, weights, nlv, scal)
+    XtY = X.T @ (weights[:, None] * Y)                      # :131-132
+    T = np.empty((n, nlv)); W = np.empty((p, nlv)); P = np.empty((p, nlv))
+    R = np.empty((p, nlv)); C = np.empty((q, nlv)); TT = np.empty(nlv)
+    for a in range(nlv):                                    # :149-175
+        w = dominant_left_sv(XtY)                           # :150-155
+        r = w.copy()
+        for j in range(a):                                  # :156-161
+            r -= np.dot(w, P[:, j]) * R[:, j]
+        t = X @ r                                           # :162
+        dt = weights * t                                    # :163
+        tt = np.dot(t, dt)                                  # :164
+        c = (XtY.T @ r) / tt                                # :165-166
+        zp = X.T @ dt                                       # :167
+        XtY -= np.outer(zp, c)                              # :168
+        P[:, a] = zp / tt; T[:, a] = t; W[:, a] = w         # :169-171
+        R[:, a] = r; C[:, a] = c; TT[a] = tt                # :172-174
+    return Plsr(T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights, None)
+
+
+def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plskern` — src/plskern.jl:106-110 (copies, then `plskern!`)."""
+    Xc = np.array(ensure_mat(X), dtype=np.float64, copy=True)
+    Yc = np.array(ensure_mat(Y), dtype=np.float64, copy=True)
+    return plskern_(Xc, Yc, weights, nlv=nlv, scal=scal)
+
+
+def plsnipals_(X: np.ndarray, Y: np.ndarray, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plsnipals!` — src/plsnipals.jl:37-97.  X and Y end up centred AND deflated."""
+    assert X.dtype == np.float64 and Y.dtype == np.float64 and X.ndim == 2 and Y.ndim == 2
+    if weights is None:
+        weights = np.ones(X.shape[0])
+    n, p, q, nlv, weights, xmeans, ymeans, xscales, yscales = _preamble(X, Y, weights, nlv, scal)
+    T = np.empty((n, nlv)); W = np.empty((p, nlv)); P = np.empty((p, nlv))
+    C = np.empty((q, nlv)); TT = np.empty(nlv)
+    for a in range(nlv):                                    # :70-94
+        XtY = X.T @ (weights[:, None] * Y)                  # :71
+        w = dominant_left_sv(XtY)                           # :72-77
+        t = X @ w                                           # :78
+        dt = weights * t                                    # :79
+        tt = np.dot(t, dt)                                  # :80
+        zp = (X.T @ dt) / tt                                # :81-82
+        c = (Y.T @ dt) / tt                                 # :83-84
+        X -= np.outer(t, zp)                                # :86
+        Y -= np.outer(t, c)                                 # :87
+        P[:, a] = zp; T[:, a] = t; W[:, a] = w; C[:, a] = c; TT[a] = tt
+    R = W @ np.linalg.inv(P.T @ W)                          # :95
+    return Plsr(T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights, None)
+
+
+def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plsnipals` — src/plsnipals.jl:31-35."""
+    Xc = np.array(ensure_mat(X), dtype=np.float64, copy=True)
+    Yc = np.array(ensure_mat(Y), dtype=np.float64, copy=True)
+    return plsnipals_(Xc, Yc, weights, nlv=nlv, scal=scal)
+
+
+# --------------------------------------------------------------------------
+# Accessors  (src/plskern.jl:187-260)
+# --------------------------------------------------------------------------
+def transform(fm: Plsr, X, *, nlv: Optional[int] = None) -> np.ndarray:
+    """src/plskern.jl:187-195."""
+    X = ensure_mat(X)
+    a = fm.T.shape[1]
+    nlv = a if nlv is None else min(nlv, a)
+    return ((X - fm.xmeans[None, :]) / fm.xscales[None, :]) @ fm.R[:, :nlv]
+
+
+def coef(fm: Plsr, *, nlv: Optional[int] = None):
+    """src/plskern.jl:207-217 — returns (B p x q, int 1 x q)."""
+    a = fm.T.shape[1]
+    nlv = a if nlv is None else min(nlv, a)
+    beta = fm.C[:, :nlv].T
+    B = (fm.R[:, :nlv] / fm.xscales[:, None]) @ beta * fm.yscales[None, :]
+    intercept = fm.ymeans[None, :] - fm.xmeans[None, :] @ B
+    return B, intercept
+
+
+def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None):
+    """src/plskern.jl:226-238 — a collection of nlv is replaced by the contiguous
+    range max(0,min):min(a,max); one value -> matrix, several -> list."""
+    X = ensure_mat(X)
+    a = fm.T.shape[1]
+    if nlv is None:
+        rng = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng = list(range(max(0, int(vals.min())), min(a, int(vals.max())) + 1))
+    preds = []
+    for k in rng:
+        B, intercept = coef(fm, nlv=k)
+        preds.append(intercept + X @ B)
+    return preds[0] if len(preds) == 1 else preds
+
+
+def summary(fm: Plsr, X):
+    """src/plskern.jl:246-260 — dict(nlv, var, pvar, cumpvar)."""
+    X = ensure_mat(X)
+    n, nlv = fm.T.shape
+    Xs = (X - fm.xmeans[None, :]) / fm.xscales[None, :]
+    sstot = float(np.sum(fm.weights @ (Xs ** 2)))
+    tt_adj = np.sum(fm.P ** 2, axis=0) * fm.TT
+    pvar = tt_adj / sstot
+    return dict(nlv=np.arange(1, nlv + 1), var=tt_adj / n, pvar=pvar, cumpvar=np.cumsum(pvar))
+
+
+# --------------------------------------------------------------------------
+# Host-simulated row sharding: the same plskern, with every
+# n-length reduction computed as G per-shard partials summed in rank order.
+# `allreduce` may be replaced by a real collective (the gloo tests do).
+# --------------------------------------------------------------------------
+def plskern_sharded(shards_X, shards_Y, shards_w, *, nlv: int, scal: bool = False, allreduce=None):
+    """shards_*: lists (one entry per rank held by THIS process) of row blocks.
+    allreduce(vec) -> vec summed over every rank of every process; default sums
+    the local list only.  Returns (Plsr with T = list of per-shard blocks)."""
+    def ar(parts):
+        s = np.sum(np.stack(parts, 0), axis=0)
+        return allreduce(s) if allreduce is not None else s
+
+    Xs = [np.array(x, dtype=np.float64, copy=True) for x in shards_X]
+    Ys = [np.array(ensure_mat(y), dtype=np.float64, copy=True) for y in shards_Y]
+    p = Xs[0].shape[1]; q = Ys[0].shape[1]
+    head = ar([np.array([float(w.sum()), float(len(w))]) for w in shards_w])
+    wsum, n_total = head[0], int(round(head[1]))
+    nlv = min(n_total, p, nlv)
+    ds = [np.asarray(w, dtype=np.float64) / wsum for w in shards_w]
+    mom = ar([np.concatenate([d @ x, d @ y]) for d, x, y in zip(ds, Xs, Ys)])
+    xmeans, ymeans = mom[:p], mom[p:]
+    xscales, yscales = np.ones(p), np.ones(q)
+    if scal:
+        var = ar([np.concatenate([d @ (x - xmeans) ** 2, d @ (y - ymeans) ** 2]) for d, x, y in zip(ds, Xs, Ys)])
+        xscales, yscales = np.sqrt(var[:p]), np.sqrt(var[p:])
+    for x, y in zip(Xs, Ys):
+        cscale_(x, xmeans, xscales); cscale_(y, ymeans, yscales)
+    K = ar([(x.T @ (d[:, None] * y)).ravel() for d, x, y in zip(ds, Xs, Ys)]).reshape(p, q)
+    W = np.empty((p, nlv)); P = np.empty((p, nlv)); R = np.empty((p, nlv))
+    C = np.empty((q, nlv)); TT = np.empty(nlv); Ts = [np.empty((x.shape[0], nlv)) for x in Xs]
+    for a in range(nlv):
+        w = dominant_left_sv(K)
+        r = w.copy()
+        for j in range(a):
+            r -= np.dot(w, P[:, j]) * R[:, j]
+        parts = []
+        for g, (d, x) in enumerate(zip(ds, Xs)):
+            t = x @ r
+            Ts[g][:, a] = t
+            dt = d * t
+            parts.append(np.concatenate([x.T @ dt, [np.dot(t, dt)]]))
+        red = ar(parts)                                     # ONE collective per LV: [zp (p), tt]
+        zp, tt = red[:p], red[p]
+        c = (K.T @ r) / tt
+        K -= np.outer(zp, c)
+        P[:, a] = zp / tt; W[:, a] = w; R[:, a] = r; C[:, a] = c; TT[a] = tt
+    wn = [d for d in ds]
+    return Plsr(Ts, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, wn, None)
+
+
+# --------------------------------------------------------------------------
+# Comparison helpers used by the parity tests
+# --------------------------------------------------------------------------
+def sign_align(ref_W: np.ndarray, new_W: np.ndarray) -> np.ndarray:
+    """Per-LV sign s_a = sign(<w_ref,a , w_new,a>) (F3)."""
+    s = np.sign(np.sum(ref_W * new_W, axis=0))
+    s[s == 0] = 1.0
+    return s
+
+
+def rel_fro(a: np.ndarray, b: np.ndarray) -> float:
+    den = np.linalg.norm(a)
+    return float(np.linalg.norm(a - b) / (den if den > 0 else 1.0))

@@ -1,0 +1,149 @@
+"""Pins the oracle (CPU, no GPU): the reference ships no fixtures (test/runtests.jl:1-2), so the
+numpy and C restatements are held to (i) PLS invariants, (ii) plskern == plsnipals, (iii) LAPACK /
+scikit-learn, (iv) the committed golden vectors.  SURVEY.md §4."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import c_oracle as CO
+from oracle import plsr_oracle as O
+
+FIELDS = ("T", "P", "R", "W", "C")
+
+
+def _aligned_err(a, b):
+    s = O.sign_align(a.W, b.W)
+    return max(O.rel_fro(getattr(a, f), getattr(b, f) * s) for f in FIELDS)
+
+
+def test_generator_known_answers():
+    # splitmix64 known-answer: first outputs for seed 0 (Vigna's reference sequence) mapped to [0,1)
+    z = [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    want = np.array([(v >> 11) / 2.0**53 for v in z])
+    assert np.array_equal(O.splitmix64_uniform(0, 0, 3), want)
+    a = O.rand_matrix(5, 17, 4, row0=3, n_total=40)
+    full = O.rand_matrix(5, 40, 4)
+    assert np.array_equal(a, full[3:20])
+    assert np.array_equal(CO.fill_uniform(5, 17, 4, row0=3, n_total=40), a)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg1_scal_w", "q1", "ragged", "wide_q"])
+def test_invariants_and_cross_agreement(name, golden_cases):
+    c = golden_cases.CASES[name]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    fk = O.plskern(X, Y, w, nlv=c["nlv"], scal=c["scal"])
+    fn = O.plsnipals(X, Y, w, nlv=c["nlv"], scal=c["scal"])
+    k = fk.T.shape[1]
+    assert k == min(c["n"], c["p"], c["nlv"])
+    D = np.diag(fk.weights)
+    Xs = (X - fk.xmeans) / fk.xscales
+    Ys = (Y - fk.ymeans) / fk.yscales
+    assert abs(fk.weights.sum() - 1) < 1e-14
+    assert np.abs(fk.T.T @ D @ fk.T - np.diag(fk.TT)).max() < 1e-12 * fk.TT.max()
+    assert np.abs(fk.R.T @ fk.P - np.eye(k)).max() < 1e-10
+    assert O.rel_fro(fk.T, Xs @ fk.R) < 1e-12
+    assert np.abs(np.linalg.norm(fk.W, axis=0) - 1).max() < 1e-13
+    assert O.rel_fro(fk.P, Xs.T @ D @ fk.T / fk.TT) < 1e-12
+    assert O.rel_fro(fk.C, Ys.T @ D @ fk.T / fk.TT) < 1e-10
+    B0, i0 = O.coef(fk, nlv=0)
+    assert np.all(B0 == 0) and np.allclose(i0, fk.ymeans[None, :])
+    cum = O.summary(fk, X)["cumpvar"]
+    assert np.all(np.diff(cum) >= -1e-14) and cum[-1] <= 1 + 1e-12
+    # weight rescaling invariance
+    if w is not None:
+        f2 = O.plskern(X, Y, 3.7 * w, nlv=c["nlv"], scal=c["scal"])
+        assert _aligned_err(fk, f2) < 1e-12
+    # two independent algorithms agree (src/plskern.jl:73-76 presents them as interchangeable)
+    assert _aligned_err(fk, fn) < 1e-9
+    assert O.rel_fro(fk.TT, fn.TT) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["cfg1", "wide_q"])
+def test_sklearn_and_lapack(name, golden_cases):
+    from sklearn.cross_decomposition import PLSRegression
+    c = golden_cases.CASES[name]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    fk = O.plskern(X, Y, nlv=c["nlv"])            # unweighted: sklearn has no row weights
+    sk = PLSRegression(n_components=c["nlv"], scale=False, tol=1e-14, max_iter=100000).fit(X, Y)
+    B, intercept = O.coef(fk)
+    coef = sk.coef_.T if sk.coef_.shape == (c["q"], c["p"]) else sk.coef_
+    assert O.rel_fro(B, coef) < 1e-5
+    assert O.rel_fro(O.predict(fk, Xt), sk.predict(Xt)) < 1e-6
+    # Gram-eigen route (what the HIP small-state kernel does) == LAPACK dgesdd U[:,0]
+    K = (X - X.mean(0)).T @ (Y - Y.mean(0)) / c["n"]
+    u = O.dominant_left_sv(K)
+    lam, V = np.linalg.eigh(K.T @ K)
+    w2 = K @ V[:, -1]
+    w2 /= np.linalg.norm(w2)
+    assert min(np.linalg.norm(u - w2), np.linalg.norm(u + w2)) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg1_scal_w", "q1", "ragged", "wide_q"])
+@pytest.mark.parametrize("alg", ["kern", "nipals"])
+def test_golden_vectors(name, alg, golden_cases):
+    g = load_golden(name)
+    c = golden_cases.CASES[name]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    assert np.array_equal(g["gen_probe"], np.concatenate([X[:3, 0], X[0, :3], Y[:2, 0]]))
+    for impl in (O, CO):
+        fn = getattr(impl, "plskern" if alg == "kern" else "plsnipals")
+        fm = fn(X, Y, w, nlv=c["nlv"], scal=c["scal"])
+        s = O.sign_align(g[f"{alg}_W"], fm.W)
+        for f in FIELDS:
+            assert O.rel_fro(g[f"{alg}_{f}"], getattr(fm, f) * s) < 1e-10, (impl.__name__, f)
+        for f in ("TT", "xmeans", "xscales", "ymeans", "yscales", "weights"):
+            assert O.rel_fro(g[f"{alg}_{f}"], getattr(fm, f)) < 1e-12, (impl.__name__, f)
+        k = fm.T.shape[1]
+        assert O.rel_fro(g[f"{alg}_transform"], O.transform(fm, Xt) * s) < 1e-10
+        assert O.rel_fro(g[f"{alg}_pred"], np.stack(O.predict(fm, Xt, nlv=range(0, k + 1)))) < 1e-10
+        sm = O.summary(fm, X)
+        assert O.rel_fro(g[f"{alg}_summary"], np.stack([sm["var"], sm["pvar"], sm["cumpvar"]])) < 1e-10
+
+
+def test_inplace_semantics(golden_cases):
+    """`plskern!` / `plsnipals!` overwrite X, Y (src/plskern.jl:122-130, src/plsnipals.jl:86-87)."""
+    g = load_golden("cfg1_scal_w")
+    c = golden_cases.CASES["cfg1_scal_w"]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    for impl in (O, CO):
+        Xk, Yk = np.asfortranarray(X.copy()), np.asfortranarray(Y.copy())
+        impl.plskern_(Xk, Yk, w, nlv=c["nlv"], scal=c["scal"])
+        assert np.allclose(Xk[:4, :4], g["kern_Xinplace_probe"], rtol=1e-12, atol=1e-14)
+        assert np.allclose(Yk, g["kern_Yinplace"], rtol=1e-12, atol=1e-14)
+        Xn, Yn = np.asfortranarray(X.copy()), np.asfortranarray(Y.copy())
+        impl.plsnipals_(Xn, Yn, w, nlv=c["nlv"], scal=c["scal"])
+        assert np.allclose(Xn[:4, :4], g["nipals_Xinplace_probe"], rtol=1e-9, atol=1e-12)
+        assert abs(np.linalg.norm(Xn) - g["nipals_Xinplace_fro"][0]) < 1e-9 * g["nipals_Xinplace_fro"][0]
+
+
+def test_predict_range_and_clamps():
+    """src/plskern.jl:226-238: collection -> contiguous clamped range; one value -> matrix."""
+    X = O.rand_matrix(1, 40, 9); Y = O.rand_matrix(2, 40, 2); Xt = O.rand_matrix(3, 5, 9)
+    fm = O.plskern(X, Y, nlv=4)
+    assert isinstance(O.predict(fm, Xt), np.ndarray)
+    assert len(O.predict(fm, Xt, nlv=[1, 3])) == 3                  # expanded to 1:3
+    assert len(O.predict(fm, Xt, nlv=range(-2, 99))) == 5           # clamped to 0:4
+    assert O.transform(fm, Xt, nlv=99).shape == (5, 4)
+    y1 = O.plskern(X, Y[:, 0], nlv=3)                               # vector y -> n x 1 (ensure_mat)
+    assert y1.C.shape == (1, 3)
+
+
+def test_degenerate_rank_propagates_nan():
+    """H9: no guard in the reference — when Y is exhausted, tt -> 0 and NaN/Inf propagate."""
+    X = O.rand_matrix(1, 30, 6)
+    Y = np.zeros((30, 1))
+    with np.errstate(all="ignore"):
+        fm = O.plskern(X, Y, nlv=2)
+    assert not np.all(np.isfinite(fm.C))
+
+
+def test_sharded_equals_unsharded():
+    X = O.rand_matrix(1, 101, 23); Y = O.rand_matrix(2, 101, 4); w = 0.5 + O.splitmix64_uniform(9, 0, 101)
+    ref = O.plskern(X, Y, w, nlv=7, scal=True)
+    cuts = [0, 25, 50, 76, 101]
+    sh = O.plskern_sharded([X[a:b] for a, b in zip(cuts, cuts[1:])], [Y[a:b] for a, b in zip(cuts, cuts[1:])],
+                           [w[a:b] for a, b in zip(cuts, cuts[1:])], nlv=7, scal=True)
+    s = O.sign_align(ref.W, sh.W)
+    assert O.rel_fro(ref.T, np.vstack(sh.T) * s) < 1e-11
+    for f in ("P", "R", "W", "C"):
+        assert O.rel_fro(getattr(ref, f), getattr(sh, f) * s) < 1e-11
