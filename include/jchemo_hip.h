@@ -1,0 +1,154 @@
+/*
+ * jchemo_hip.h — C ABI of libjchemo_hip.so: the MI355X (gfx950) PLS regression engine behind
+ * Jchemo.jl's plskern / plsnipals hot path.
+ *
+ * The reference (/root/reference, Jchemo.jl v0.1.23) has NO FFI boundary: its "operator API" is the
+ * Julia call shape  fun(X, Y[, weights]; nlv, scal=false) -> ::Plsr  plus the generics
+ * transform / coef / predict / summary.  Each entry point below names the reference lines it
+ * replaces; INTEGRATION.md shows the Julia `ccall` stubs (and the ctypes stubs used by the tests).
+ *
+ * Conventions
+ *   - every function returns an int32 status: 0 = OK, <0 = error (codes below); the message is
+ *     available from jch_last_error().  Nothing throws or aborts across the boundary.
+ *   - matrices are COLUMN-MAJOR float64 exactly as Julia stores them (element (i,j) at
+ *     base[i + j*ld]); `ld` is in elements.
+ *   - the caller owns every buffer it passes; the library keeps no host pointer after return and
+ *     owns only device workspace inside the ctx (re-used across calls).
+ *   - a ctx is bound to ONE GPU and one HIP stream and is not thread-safe.  All calls are blocking
+ *     (they return after the ctx stream has drained).
+ *   - multi-GPU = one process (one ctx) per GPU, rows of X/Y/weights/T sharded by rows; the ctx is
+ *     joined to an RCCL communicator with jch_ctx_comm_init and every rank makes the same call with
+ *     its own shard.  All p x q-and-smaller results are replicated (bit-identical) on every rank.
+ */
+#ifndef JCHEMO_HIP_H
+#define JCHEMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JCH_VERSION 100 /* 0.1.0 */
+
+#if defined(JCH_BUILD)
+#define JCH_API __attribute__((visibility("default")))
+#else
+#define JCH_API
+#endif
+
+/* status codes */
+#define JCH_OK 0
+#define JCH_EINVAL (-1) /* bad argument / unsupported shape */
+#define JCH_EHIP (-2)   /* HIP runtime error (message has the HIP string) */
+#define JCH_ERCCL (-3)  /* RCCL error or RCCL not loadable */
+#define JCH_ENOMEM (-4) /* device or host allocation failed */
+#define JCH_ENODEV (-5) /* no usable gfx950 device */
+
+/* where the n-sized arrays (X, Y, weights, T, weights_norm) of a call live */
+#define JCH_LOC_HOST 0   /* host pointers: the library stages them through the device */
+#define JCH_LOC_DEVICE 1 /* device pointers on the ctx's GPU (e.g. an AMDGPU.jl ROCArray / torch tensor) */
+
+/* storage type of X / Y handed to a fit */
+#define JCH_F64 0
+#define JCH_BF16 1 /* bf16 storage, fp32 row arithmetic, fp64 small state (BASELINE config 3); device-resident only */
+
+typedef struct jch_ctx jch_ctx; /* opaque: device, stream, RCCL communicator, workspace pool */
+
+JCH_API int32_t jch_version(void);
+
+/* Create a context on HIP device `device_id`.  `stream` is a hipStream_t to launch on (e.g.
+ * torch.cuda.current_stream().cuda_stream) or NULL to let the ctx create its own. */
+JCH_API int32_t jch_ctx_create(jch_ctx **out, int32_t device_id, void *stream, uint32_t flags);
+JCH_API int32_t jch_ctx_destroy(jch_ctx *ctx);
+/* Message of the last failing call on ctx (ctx == NULL: last jch_ctx_create failure).  Valid until
+ * the next call on the same ctx. */
+JCH_API const char *jch_last_error(const jch_ctx *ctx);
+
+/* ---- row-sharded multi-GPU (RCCL over xGMI) ------------------------------------
+ * Rank 0 fills a 128-byte id with jch_comm_unique_id, the host side broadcasts it (the Python mirror
+ * uses torch.distributed, the Julia wrapper MPI/Distributed), every rank calls jch_ctx_comm_init. */
+JCH_API int32_t jch_comm_unique_id(void *uid128);
+JCH_API int32_t jch_ctx_comm_init(jch_ctx *ctx, const void *uid128, int32_t rank, int32_t nranks);
+JCH_API int32_t jch_ctx_comm_info(const jch_ctx *ctx, int32_t *rank, int32_t *nranks);
+
+typedef struct jch_pls_desc {
+    int64_t n;       /* rows held by THIS rank (all rows when single-GPU) */
+    int64_t p;       /* columns of X */
+    int64_t q;       /* columns of Y (1..64) */
+    int32_t nlv;     /* requested LVs; clamped to min(n_total, p, nlv) like plskern.jl:116 */
+    int32_t scal;    /* 0/1: scale columns by their weighted uncorrected std (plskern.jl:123-126) */
+    int32_t dtype;   /* JCH_F64 | JCH_BF16 */
+    int32_t loc;     /* JCH_LOC_HOST | JCH_LOC_DEVICE for X, Y, weights, T, weights_norm */
+    int32_t inplace; /* 1 = `plskern!` / `plsnipals!` semantics: X and Y are overwritten with their
+                        centred/scaled (plsnipals: and deflated) versions; 0 = `plskern` (inputs untouched,
+                        the reference's copy at plskern.jl:108 never materialises) */
+    int32_t reserved;
+} jch_pls_desc;
+
+/*
+ * jch_plskern_fit — replaces `plskern!` / `plskern` (src/plskern.jl:106-178): weight normalisation
+ * (utility.jl:715-723), weighted column means / stds (utility.jl:195,264,314-323), centring/scaling
+ * (utility.jl:76-81,482-487), XtY = X'DY (plskern.jl:131-132) and the per-LV loop (plskern.jl:149-175).
+ *   X  n x p (ldx >= n), Y  n x q (ldy >= n), weights n or NULL (= ones)          [desc->loc]
+ *   T  n x nlv (ld n), weights_norm n                                              [desc->loc]
+ *   P, R, W  p x nlv (ld p); C  q x nlv (ld q); TT nlv; xmeans, xscales p; ymeans, yscales q   [HOST]
+ *   nlv_out: the clamped number of LVs actually computed (columns filled in T/P/R/W/C/TT).
+ * Any output pointer may be NULL to skip it.  Sign of each LV (w, r, t, P, C columns flip together,
+ * SURVEY F3) is fixed by: the largest-|.| component of the dominant right singular vector is positive.
+ */
+JCH_API int32_t jch_plskern_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                        const double *weights, double *T, double *P, double *R, double *W, double *C,
+                        double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
+                        double *weights_norm, int32_t *nlv_out);
+
+/* jch_plsnipals_fit — replaces `plsnipals!` / `plsnipals` (src/plsnipals.jl:31-97); same signature.
+ * With inplace = 1, X and Y return centred AND deflated (plsnipals.jl:86-87). */
+JCH_API int32_t jch_plsnipals_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                          const double *weights, double *T, double *P, double *R, double *W, double *C,
+                          double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
+                          double *weights_norm, int32_t *nlv_out);
+
+/*
+ * jch_affine_gemm — out (m x k, ld ldo) = ((X - 1*shift') * diag(1/scale)) * B + 1*bias'
+ * the single device primitive behind `transform` (src/plskern.jl:187-195: shift = xmeans, scale =
+ * xscales, B = R[:,1:k], bias = 0) and `predict` (src/plskern.jl:226-238 via coef :207-217:
+ * shift = 0, scale = 1, B = [B_k0 | B_k1 | ...], bias = [int_k0 | ...]; one pass over X for the whole
+ * nlv range instead of one GEMM per value).
+ *   X m x p (ldx) and out [loc]; shift, scale (p, may be NULL), B (p x k, ld p), bias (k, may be NULL) HOST.
+ */
+JCH_API int32_t jch_affine_gemm(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx,
+                        const double *shift, const double *scale, const double *B, int64_t k,
+                        const double *bias, double *out, int64_t ldo);
+
+/* jch_weighted_ss — sum_i d_i * || (x_i - shift) / scale ||^2 : the `sstot` of `summary`
+ * (src/plskern.jl:250-251).  X n x p and d (n) [loc]; shift/scale HOST; result HOST.  With a
+ * communicator the result is the sum over all ranks' shards. */
+JCH_API int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int64_t n, int64_t p, int64_t ldx,
+                        const double *d, const double *shift, const double *scale, double *sstot);
+
+/* ---- harness utilities (bench / tests) ---------------------------------------------------------- */
+/* Fill device matrix out (n x p, column-major ld) with rows [row0,row0+n) of the n_total x p matrix
+ * whose element (i,j) is splitmix64-uniform(seed, i + j*n_total) — the README's `rand(n,p)` stand-in
+ * (README.md:79-94), identical to oracle/plsr_oracle.py:splitmix64_uniform. */
+JCH_API int32_t jch_fill_uniform(jch_ctx *ctx, double *dev_out, int64_t n, int64_t p, int64_t ld, int64_t row0,
+                         int64_t n_total, uint64_t seed);
+
+typedef struct jch_profile {
+    double fit_ms;        /* device time of the last fit, first kernel -> last kernel (HIP events)   */
+    double prologue_ms;   /* weights + means (+ var) + centre/transpose/XtY                           */
+    double sweep_ms;      /* sum over LVs of the dominant kernel (fused sweep; plsnipals: sweep+deflate) */
+    double smallstate_ms; /* sum over LVs of partial reduce + lv_update (+ all-reduce)                */
+    int32_t sweep_launches;
+    int32_t nlv;
+    double sweep_bytes;   /* algorithmic bytes of ONE dominant-kernel launch          */
+} jch_profile;
+/* Enable (1) / disable (0) per-kernel HIP-event timing of subsequent fits (adds event records on the
+ * ctx stream, no host syncs inside the fit). */
+JCH_API int32_t jch_ctx_set_profiling(jch_ctx *ctx, int32_t enable);
+JCH_API int32_t jch_ctx_get_profile(const jch_ctx *ctx, jch_profile *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JCHEMO_HIP_H */

@@ -1,0 +1,204 @@
+// Context, error plumbing, workspace, RCCL binding, profiling events.  Public ABI: include/jchemo_hip.h.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "jch_internal.h"
+
+static thread_local std::string g_create_err;
+
+int32_t jch_fail(jch_ctx *ctx, int32_t code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_err = buf;
+    return code;
+}
+
+extern "C" int32_t jch_version(void) { return JCH_VERSION; }
+
+extern "C" const char *jch_last_error(const jch_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int32_t jch_ctx_create(jch_ctx **out, int32_t device_id, void *stream, uint32_t flags)
+{
+    (void)flags;
+    if (!out) return jch_fail(nullptr, JCH_EINVAL, "jch_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return jch_fail(nullptr, JCH_ENODEV, "jch_ctx_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        return jch_fail(nullptr, JCH_EINVAL, "jch_ctx_create: device_id %d out of range [0,%d)", device_id, ndev);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return jch_fail(nullptr, JCH_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return jch_fail(nullptr, JCH_ENODEV, "jch_ctx_create: device %d is %s; this library is built for gfx950 only",
+                        device_id, prop.gcnArchName);
+    jch_ctx *ctx = new (std::nothrow) jch_ctx();
+    if (!ctx) return jch_fail(nullptr, JCH_ENOMEM, "jch_ctx_create: host allocation failed");
+    ctx->device = device_id;
+    ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) {
+        if (stream) {
+            ctx->stream = (hipStream_t)stream;
+        } else {
+            e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+            ctx->own_stream = true;
+        }
+    }
+    if (e != hipSuccess) {
+        delete ctx;
+        return jch_fail(nullptr, JCH_EHIP, "jch_ctx_create: %s", hipGetErrorString(e));
+    }
+    if (const char *s = getenv("JCH_SWEEP_BLOCKS_PER_CU")) ctx->sweep_blocks_per_cu = atoi(s);
+    *out = ctx;
+    return JCH_OK;
+}
+
+static void free_buf(jch_buf &b)
+{
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.bytes = 0;
+}
+
+static jch_rccl g_rccl;
+
+extern "C" int32_t jch_ctx_destroy(jch_ctx *ctx)
+{
+    if (!ctx) return JCH_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    for (jch_buf *b : {&ctx->xr, &ctx->yr, &ctx->xstage, &ctx->ystage, &ctx->wstage, &ctx->tbuf, &ctx->dnorm, &ctx->part,
+                       &ctx->kpart, &ctx->small, &ctx->colpart, &ctx->gemm_b, &ctx->gemm_out, &ctx->xq})
+        free_buf(*b);
+    for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return JCH_OK;
+}
+
+int32_t jch_reserve(jch_ctx *ctx, jch_buf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 256;
+    if (b.bytes >= bytes) return JCH_OK;
+    if (b.ptr) {
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(b.ptr);
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    bytes = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.ptr, bytes);
+    if (e != hipSuccess) {
+        b.ptr = nullptr;
+        return jch_fail(ctx, JCH_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    b.bytes = bytes;
+    return JCH_OK;
+}
+
+// ---- RCCL (dlopen: no link-time dependency; inside a torch process this resolves to the RCCL torch loaded) ----
+static int32_t rccl_load(jch_ctx *ctx)
+{
+    if (g_rccl.handle) return JCH_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return jch_fail(ctx, JCH_ERCCL, "cannot dlopen librccl.so.1: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void **, int, jch_uid, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.GetErrorString)
+        return jch_fail(ctx, JCH_ERCCL, "librccl is missing an expected symbol");
+    g_rccl.handle = h;
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_comm_unique_id(void *uid128)
+{
+    if (!uid128) return jch_fail(nullptr, JCH_EINVAL, "jch_comm_unique_id: NULL");
+    JCH_TRY(rccl_load(nullptr));
+    int r = g_rccl.GetUniqueId(uid128);
+    if (r != 0) return jch_fail(nullptr, JCH_ERCCL, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_ctx_comm_init(jch_ctx *ctx, const void *uid128, int32_t rank, int32_t nranks)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!uid128 || nranks < 1 || rank < 0 || rank >= nranks)
+        return jch_fail(ctx, JCH_EINVAL, "jch_ctx_comm_init: bad rank %d / nranks %d", rank, nranks);
+    if (ctx->comm) return jch_fail(ctx, JCH_EINVAL, "jch_ctx_comm_init: ctx already has a communicator");
+    JCH_TRY(rccl_load(ctx));
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    jch_uid id;
+    memcpy(&id, uid128, sizeof id);
+    int r = g_rccl.CommInitRank(&ctx->comm, nranks, id, rank);
+    if (r != 0) {
+        ctx->comm = nullptr;
+        return jch_fail(ctx, JCH_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, g_rccl.GetErrorString(r));
+    }
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_ctx_comm_info(const jch_ctx *ctx, int32_t *rank, int32_t *nranks)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (rank) *rank = ctx->rank;
+    if (nranks) *nranks = ctx->nranks;
+    return JCH_OK;
+}
+
+int32_t jch_allreduce_f64(jch_ctx *ctx, double *dev_buf, size_t count)
+{
+    if (!ctx->comm || count == 0) return JCH_OK;  // single rank: the local sum is the global sum
+    int r = g_rccl.AllReduce(dev_buf, dev_buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    if (r != 0) return jch_fail(ctx, JCH_ERCCL, "ncclAllReduce(%zu f64): %s", count, g_rccl.GetErrorString(r));
+    return JCH_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------
+hipEvent_t jch_ev(jch_ctx *ctx)
+{
+    if (!ctx->profiling) return nullptr;
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(ev);
+    }
+    hipEvent_t ev = ctx->ev_pool[ctx->ev_used++];
+    if (hipEventRecord(ev, ctx->stream) != hipSuccess) return nullptr;
+    return ev;
+}
+
+extern "C" int32_t jch_ctx_set_profiling(jch_ctx *ctx, int32_t enable)
+{
+    if (!ctx) return JCH_EINVAL;
+    ctx->profiling = enable != 0;
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_ctx_get_profile(const jch_ctx *ctx, jch_profile *out)
+{
+    if (!ctx || !out) return JCH_EINVAL;
+    *out = ctx->prof;
+    return JCH_OK;
+}

@@ -1,0 +1,223 @@
+// Fit orchestration: jch_plskern_fit / jch_plsnipals_fit (include/jchemo_hip.h).
+// Everything between the first and the last kernel of a fit is enqueued on ctx->stream with no host sync
+// (single GPU); a multi-GPU fit syncs once in the prologue to learn the global row count.
+#include <algorithm>
+
+#include "jch_internal.h"
+
+__global__ __launch_bounds__(256) void k_fill_const(double *__restrict__ v, int m, double c)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < m) v[j] = c;
+}
+
+namespace {
+
+struct fit_io {
+    const jch_pls_desc *d;
+    void *X; int64_t ldx; void *Y; int64_t ldy; const double *weights;
+    double *T, *P, *R, *W, *C, *TT, *xmeans, *xscales, *ymeans, *yscales, *weights_norm;
+    int32_t *nlv_out;
+};
+
+int32_t validate(jch_ctx *ctx, const fit_io &io, const char *who)
+{
+    const jch_pls_desc *d = io.d;
+    if (!d) return jch_fail(ctx, JCH_EINVAL, "%s: desc is NULL", who);
+    if (d->n < 1 || d->p < 1 || d->q < 1) return jch_fail(ctx, JCH_EINVAL, "%s: empty input (n=%lld p=%lld q=%lld)", who,
+                                                         (long long)d->n, (long long)d->p, (long long)d->q);
+    if (d->q > JCH_MAXQ) return jch_fail(ctx, JCH_EINVAL, "%s: q=%lld > %d not supported", who, (long long)d->q, JCH_MAXQ);
+    if (d->p > JCH_SWEEP_MAXP)
+        return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld > %d not supported by the fused sweep yet", who, (long long)d->p,
+                        JCH_SWEEP_MAXP);
+    if (d->nlv < 1) return jch_fail(ctx, JCH_EINVAL, "%s: nlv=%d must be >= 1", who, d->nlv);
+    if (d->dtype != JCH_F64) return jch_fail(ctx, JCH_EINVAL, "%s: dtype %d not supported (f64 only in this build)", who, d->dtype);
+    if (d->loc != JCH_LOC_HOST && d->loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "%s: bad loc %d", who, d->loc);
+    if (!io.X || !io.Y) return jch_fail(ctx, JCH_EINVAL, "%s: X or Y is NULL", who);
+    if (io.ldx < d->n || io.ldy < d->n) return jch_fail(ctx, JCH_EINVAL, "%s: ldx/ldy smaller than n", who);
+    return JCH_OK;
+}
+
+struct carve {
+    char *base; size_t off;
+    double *take(size_t count) { double *p = (double *)(base + off); off += ((count * sizeof(double)) + 255) & ~(size_t)255; return p; }
+};
+
+int32_t h2d_matrix(jch_ctx *ctx, double *dst, const double *src, int64_t n, int64_t cols, int64_t ld)
+{
+    if (ld == n) JCH_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n * cols, hipMemcpyHostToDevice, ctx->stream));
+    else JCH_HIP(ctx, hipMemcpy2DAsync(dst, sizeof(double) * n, src, sizeof(double) * ld, sizeof(double) * n, cols,
+                                       hipMemcpyHostToDevice, ctx->stream));
+    return JCH_OK;
+}
+int32_t d2h_matrix(jch_ctx *ctx, double *dst, const double *src, int64_t n, int64_t cols, int64_t ld)
+{
+    if (ld == n) JCH_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n * cols, hipMemcpyDeviceToHost, ctx->stream));
+    else JCH_HIP(ctx, hipMemcpy2DAsync(dst, sizeof(double) * ld, src, sizeof(double) * n, sizeof(double) * n, cols,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+    return JCH_OK;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (a && b && hipEventElapsedTime(&ms, a, b) == hipSuccess) return ms;
+    return 0.f;
+}
+
+int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
+{
+    const char *who = algo == 0 ? "jch_plskern_fit" : "jch_plsnipals_fit";
+    if (!ctx) return JCH_EINVAL;
+    JCH_TRY(validate(ctx, io, who));
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const jch_pls_desc &d = *io.d;
+    const int64_t n = d.n;
+    const int p = (int)d.p, q = (int)d.q;
+    const int ldr = (p + 1) & ~1, qpad = ((q + 15) / 16) * 16;
+    const bool host = d.loc == JCH_LOC_HOST;
+    const bool inplace = d.inplace != 0;
+    ctx->ev_used = 0;
+    ctx->prof = jch_profile{};
+
+    // ---- inputs on the device (column-major as handed over)
+    double *Xc = (double *)io.X, *Yc = (double *)io.Y;
+    const double *wdev = io.weights;
+    int64_t ldxc = io.ldx, ldyc = io.ldy;
+    if (host) {
+        JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * (size_t)n * p));
+        JCH_TRY(jch_reserve(ctx, ctx->ystage, sizeof(double) * (size_t)n * q));
+        Xc = (double *)ctx->xstage.ptr; Yc = (double *)ctx->ystage.ptr; ldxc = n; ldyc = n;
+        JCH_TRY(h2d_matrix(ctx, Xc, (const double *)io.X, n, p, io.ldx));
+        JCH_TRY(h2d_matrix(ctx, Yc, (const double *)io.Y, n, q, io.ldy));
+        if (io.weights) {
+            JCH_TRY(jch_reserve(ctx, ctx->wstage, sizeof(double) * (size_t)n));
+            JCH_HIP(ctx, hipMemcpyAsync(ctx->wstage.ptr, io.weights, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            wdev = (const double *)ctx->wstage.ptr;
+        }
+    }
+    // ---- working copies and small state
+    const int nlv_cap = (int)std::min<int64_t>(d.nlv, p);  // upper bound before the global-n clamp
+    JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
+    JCH_TRY(jch_reserve(ctx, ctx->yr, sizeof(double) * (size_t)n * qpad));
+    double *Xr = (double *)ctx->xr.ptr, *Yr = (double *)ctx->yr.ptr;
+    double *dn = nullptr;
+    if (!host && io.weights_norm) dn = io.weights_norm;
+    else { JCH_TRY(jch_reserve(ctx, ctx->dnorm, sizeof(double) * (size_t)n)); dn = (double *)ctx->dnorm.ptr; }
+    double *Tdev = nullptr;
+    if (!host && io.T) Tdev = io.T;
+    else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
+
+    const size_t small_bytes = 256 * 16 + sizeof(double) * ((size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
+                                                         (size_t)nlv_cap * q + nlv_cap + 2 * ((size_t)ldr + 1 + qpad) + 2 * (size_t)(p + q) + 8);
+    JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
+    carve cv{(char *)ctx->small.ptr, 0};
+    jch_small s;
+    s.K = cv.take((size_t)p * qpad); s.w = cv.take(ldr); s.r = cv.take(ldr);
+    s.P = cv.take((size_t)nlv_cap * p); s.R = cv.take((size_t)nlv_cap * p); s.W = cv.take((size_t)nlv_cap * p);
+    s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap);
+    s.zt = cv.take((size_t)ldr + 1 + qpad); s.zpc = cv.take((size_t)ldr + qpad);
+    s.mom = cv.take(p + q); s.scl = cv.take(p + q); s.hdr = cv.take(8);
+
+    hipEvent_t ev_begin = jch_ev(ctx);
+    // ---- K0 weights; global row count for the nlv clamp (src/plskern.jl:116-117)
+    JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr));
+    int64_t n_total = n;
+    if (ctx->nranks > 1) {
+        double hdr_h[2];
+        JCH_HIP(ctx, hipMemcpyAsync(hdr_h, s.hdr, sizeof hdr_h, hipMemcpyDeviceToHost, ctx->stream));
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        n_total = (int64_t)(hdr_h[1] + 0.5);
+    }
+    const int nlv = (int)std::min<int64_t>(std::min<int64_t>(n_total, p), d.nlv);
+    // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
+    JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
+    if (d.scal) JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl));
+    else hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
+    JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && algo == 0, Xr, ldr, Yr, qpad, s.K));
+    hipEvent_t ev_prologue = jch_ev(ctx);
+
+    // ---- LV loop
+    const size_t sweep_ev0 = ctx->ev_used;
+    JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, algo));
+    for (int a = 0; a < nlv; ++a) {
+        double *tcol = Tdev + (size_t)a * (size_t)n;
+        if (algo == 0) {
+            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt));
+            JCH_TRY(jch_allreduce_f64(ctx, s.zt, (size_t)ldr + 1));  // ONE collective per LV: [zp (p), tt]
+            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0));
+        } else {
+            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt));
+            JCH_TRY(jch_allreduce_f64(ctx, s.zt, (size_t)ldr + 1 + qpad));  // [zp_raw, tt, c_raw]
+            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1));
+            const bool last = a + 1 == nlv;
+            if (!last || inplace) {
+                // X -= t zp', Y -= t c' fused with the next K = X'DY (src/plsnipals.jl:86-87,71)
+                JCH_TRY(jch_launch_deflate(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, tcol, s.zpc, last ? nullptr : s.K));
+            }
+            if (!last) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 1));
+        }
+    }
+    if (algo == 1) JCH_TRY(jch_launch_nipals_R(ctx, s, p, nlv));
+    hipEvent_t ev_end = jch_ev(ctx);
+    const size_t sweep_ev1 = ctx->ev_used;
+
+    // ---- results
+    if (algo == 1 && inplace) {  // hand back centred + deflated X, Y in the caller's column-major arrays
+        JCH_TRY(jch_launch_export_colmajor(ctx, Xr, ldr, Yr, qpad, n, p, q, Xc, ldxc, Yc, ldyc));
+    }
+    auto d2h = [&](double *dst, const double *src, size_t count) -> int32_t {
+        if (dst) JCH_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+        return JCH_OK;
+    };
+    JCH_TRY(d2h(io.P, s.P, (size_t)nlv * p)); JCH_TRY(d2h(io.R, s.R, (size_t)nlv * p)); JCH_TRY(d2h(io.W, s.W, (size_t)nlv * p));
+    JCH_TRY(d2h(io.C, s.C, (size_t)nlv * q)); JCH_TRY(d2h(io.TT, s.TT, nlv));
+    JCH_TRY(d2h(io.xmeans, s.mom, p)); JCH_TRY(d2h(io.ymeans, s.mom + p, q));
+    JCH_TRY(d2h(io.xscales, s.scl, p)); JCH_TRY(d2h(io.yscales, s.scl + p, q));
+    if (host) {
+        JCH_TRY(d2h(io.T, Tdev, (size_t)n * nlv));
+        JCH_TRY(d2h(io.weights_norm, dn, (size_t)n));
+        if (inplace) {
+            JCH_TRY(d2h_matrix(ctx, (double *)io.X, Xc, n, p, io.ldx));
+            JCH_TRY(d2h_matrix(ctx, (double *)io.Y, Yc, n, q, io.ldy));
+        }
+    }
+    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (io.nlv_out) *io.nlv_out = nlv;
+
+    if (ctx->profiling) {
+        jch_profile &pr = ctx->prof;
+        pr.fit_ms = ev_ms(ev_begin, ev_end);
+        pr.prologue_ms = ev_ms(ev_begin, ev_prologue);
+        pr.nlv = nlv;
+        // events between sweep_ev0 and sweep_ev1 come in (begin,end) pairs recorded by the sweep/deflate launchers
+        double sw = 0.0; int cnt = 0;
+        for (size_t i = sweep_ev0; i + 1 < sweep_ev1; i += 2) { sw += ev_ms(ctx->ev_pool[i], ctx->ev_pool[i + 1]); ++cnt; }
+        pr.sweep_ms = sw;
+        pr.sweep_launches = algo == 0 ? cnt : nlv;
+        pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
+        const double per_x = (double)n * ldr * 8.0;
+        pr.sweep_bytes = algo == 0 ? per_x + 16.0 * (double)n : 3.0 * per_x;
+    }
+    return JCH_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t jch_plskern_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                                   const double *weights, double *T, double *P, double *R, double *W, double *C, double *TT,
+                                   double *xmeans, double *xscales, double *ymeans, double *yscales, double *weights_norm,
+                                   int32_t *nlv_out)
+{
+    fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
+    return fit_impl(ctx, io, 0);
+}
+
+extern "C" int32_t jch_plsnipals_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                                     const double *weights, double *T, double *P, double *R, double *W, double *C, double *TT,
+                                     double *xmeans, double *xscales, double *ymeans, double *yscales, double *weights_norm,
+                                     int32_t *nlv_out)
+{
+    fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
+    return fit_impl(ctx, io, 1);
+}

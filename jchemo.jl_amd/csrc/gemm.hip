@@ -1,0 +1,156 @@
+// K7 — out = X * Bs + bias on v_mfma_f64_16x16x4_f64: the device primitive behind `transform`
+// (src/plskern.jl:187-195) and `predict` (src/plskern.jl:226-238).  Centring/scaling is folded into Bs and
+// bias on the host (p x k work), so X is read once, untouched, with no m x p temporary (the reference
+// allocates one in `cscale`, plskern.jl:191).  X and out are column-major (Julia).
+//   M = 16 rows of X per wave (4 waves = 64 rows per block), K = 4 columns of X per MFMA, N = 16 output columns
+//   per accumulator, up to 8 accumulators (128 output columns) per block; wider outputs use grid.y.
+// Bound: HBM on X (m*p*8 bytes) for k <= 128.
+#include <vector>
+
+#include "jch_internal.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#define KCH 32  // X columns per LDS-staged chunk of Bs
+
+__global__ __launch_bounds__(256) void k_affine_gemm(const double *__restrict__ Xc, int64_t m, int p, int64_t ldx,
+                                                      const double *__restrict__ Bs, int kpad,
+                                                      const double *__restrict__ bias, int k, double *__restrict__ out,
+                                                      int64_t ldo)
+{
+    __shared__ double bl[KCH * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n0 = blockIdx.y * 128;                       // first output column of this block
+    const int ncols = min(128, kpad - n0);                 // multiple of 16
+    const int ntiles = ncols / 16;
+    const int64_t i0 = (int64_t)blockIdx.x * 64 + 16 * wv;
+    const int64_t irow = i0 + (lane & 15);
+    const bool rlive = irow < m;
+    v4f64 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int j0 = 0; j0 < p; j0 += KCH) {
+        __syncthreads();
+        for (int e = tid; e < KCH * ncols; e += 256) {
+            const int jj = e / ncols, cc = e % ncols;
+            bl[jj * 128 + cc] = (j0 + jj < p) ? Bs[(size_t)(j0 + jj) * kpad + n0 + cc] : 0.0;
+        }
+        double a[KCH / 4];
+#pragma unroll
+        for (int kk = 0; kk < KCH / 4; ++kk) {
+            const int j = j0 + 4 * kk + (lane >> 4);
+            a[kk] = (rlive && j < p) ? Xc[(size_t)irow + (size_t)j * (size_t)ldx] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KCH / 4; ++kk) {
+            const double *brow = bl + (4 * kk + (lane >> 4)) * 128 + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], brow[16 * t], acc[t], 0, 0, 0);
+        }
+    }
+    // D[row = (lane>>4) + 4 reg][col = lane&15]
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t >= ntiles) break;
+        const int col = n0 + 16 * t + (lane & 15);
+        if (col >= k) continue;
+        const double bv = bias[col];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t i = i0 + (lane >> 4) + 4 * reg;
+            if (i < m) out[(size_t)i + (size_t)col * (size_t)ldo] = acc[t][reg] + bv;
+        }
+    }
+}
+
+int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p, int64_t ldx, const double *Bs, int k, int kpad,
+                               const double *bias, double *out, int64_t ldo)
+{
+    dim3 grid((unsigned)((m + 63) / 64), (unsigned)((kpad + 127) / 128));
+    hipLaunchKernelGGL(k_affine_gemm, grid, dim3(256), 0, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_affine_gemm(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx,
+                                   const double *shift, const double *scale, const double *B, int64_t k, const double *bias,
+                                   double *out, int64_t ldo)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!X || !B || !out || m < 0 || p < 1 || k < 1 || ldx < m || ldo < m)
+        return jch_fail(ctx, JCH_EINVAL, "jch_affine_gemm: bad arguments");
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_affine_gemm: bad loc");
+    if (m == 0) return JCH_OK;
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const int kpad = (int)((k + 15) / 16 * 16);
+    // fold centring/scaling: Bs = diag(1/scale) B ; bias' = bias - shift' Bs      (host, p x k)
+    std::vector<double> hb((size_t)p * kpad + kpad, 0.0);
+    double *Bs = hb.data(), *b2 = hb.data() + (size_t)p * kpad;
+    for (int64_t c = 0; c < k; ++c) {
+        double acc = bias ? bias[c] : 0.0;
+        for (int64_t j = 0; j < p; ++j) {
+            const double v = B[j + c * p] / (scale ? scale[j] : 1.0);
+            Bs[j * kpad + c] = v;
+            if (shift) acc -= shift[j] * v;
+        }
+        b2[c] = acc;
+    }
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, sizeof(double) * hb.size()));
+    double *dB = (double *)ctx->gemm_b.ptr;
+    JCH_HIP(ctx, hipMemcpyAsync(dB, hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice, ctx->stream));
+    const double *dX = X;
+    double *dO = out;
+    int64_t ldxd = ldx, ldod = ldo;
+    if (loc == JCH_LOC_HOST) {
+        JCH_TRY(jch_reserve(ctx, ctx->xq, sizeof(double) * (size_t)m * p));
+        JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * (size_t)m * k));
+        if (ldx == m) JCH_HIP(ctx, hipMemcpyAsync(ctx->xq.ptr, X, sizeof(double) * (size_t)m * p, hipMemcpyHostToDevice, ctx->stream));
+        else JCH_HIP(ctx, hipMemcpy2DAsync(ctx->xq.ptr, sizeof(double) * m, X, sizeof(double) * ldx, sizeof(double) * m, p,
+                                           hipMemcpyHostToDevice, ctx->stream));
+        dX = (const double *)ctx->xq.ptr; dO = (double *)ctx->gemm_out.ptr; ldxd = m; ldod = m;
+    }
+    JCH_TRY(jch_launch_affine_gemm(ctx, dX, m, (int)p, ldxd, dB, (int)k, kpad, dB + (size_t)p * kpad, dO, ldod));
+    if (loc == JCH_LOC_HOST) {
+        if (ldo == m) JCH_HIP(ctx, hipMemcpyAsync(out, dO, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+        else JCH_HIP(ctx, hipMemcpy2DAsync(out, sizeof(double) * ldo, dO, sizeof(double) * m, sizeof(double) * m, k,
+                                           hipMemcpyDeviceToHost, ctx->stream));
+    }
+    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `hb` alive until the H2D copy is done
+    return JCH_OK;
+}
+
+// sstot of `summary` (src/plskern.jl:250-251): sum_j (1/scale_j^2) * sum_i d_i (x_ij - shift_j)^2 — the K1
+// second-moment kernel on X alone, combined on the host (p values).
+extern "C" int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int64_t n, int64_t p, int64_t ldx,
+                                   const double *d, const double *shift, const double *scale, double *sstot)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!X || !d || !sstot || n < 1 || p < 1 || ldx < n) return jch_fail(ctx, JCH_EINVAL, "jch_weighted_ss: bad arguments");
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_weighted_ss: bad loc");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const double *dX = X, *dd = d;
+    int64_t ldxd = ldx;
+    if (loc == JCH_LOC_HOST) {
+        JCH_TRY(jch_reserve(ctx, ctx->xq, sizeof(double) * (size_t)n * p));
+        JCH_TRY(jch_reserve(ctx, ctx->wstage, sizeof(double) * (size_t)n));
+        if (ldx == n) JCH_HIP(ctx, hipMemcpyAsync(ctx->xq.ptr, X, sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice, ctx->stream));
+        else JCH_HIP(ctx, hipMemcpy2DAsync(ctx->xq.ptr, sizeof(double) * n, X, sizeof(double) * ldx, sizeof(double) * n, p,
+                                           hipMemcpyHostToDevice, ctx->stream));
+        JCH_HIP(ctx, hipMemcpyAsync(ctx->wstage.ptr, d, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        dX = (const double *)ctx->xq.ptr; dd = (const double *)ctx->wstage.ptr; ldxd = n;
+    }
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, sizeof(double) * 2 * (size_t)p));
+    double *dshift = (double *)ctx->gemm_b.ptr, *dvar = dshift + p;
+    std::vector<double> hs((size_t)p, 0.0);
+    if (shift) for (int64_t j = 0; j < p; ++j) hs[j] = shift[j];
+    JCH_HIP(ctx, hipMemcpyAsync(dshift, hs.data(), sizeof(double) * (size_t)p, hipMemcpyHostToDevice, ctx->stream));
+    JCH_TRY(jch_launch_moments(ctx, dX, ldxd, nullptr, 0, dd, n, (int)p, 0, dshift, dvar, false));
+    std::vector<double> hv((size_t)p);
+    JCH_HIP(ctx, hipMemcpyAsync(hv.data(), dvar, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, ctx->stream));
+    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double s = 0.0;
+    for (int64_t j = 0; j < p; ++j) { const double sc = scale ? scale[j] : 1.0; s += hv[j] / (sc * sc); }
+    *sstot = s;
+    return JCH_OK;
+}

@@ -1,0 +1,143 @@
+// Internal declarations of libjchemo_hip.so (gfx950 only).  Public ABI: include/jchemo_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "jchemo_hip.h"
+
+#define JCH_MAXQ 64       // Jacobi workspace bound (q x q in LDS)
+#define JCH_SWEEP_MAXP 2048  // widest row the register-resident fused sweep holds (16 column chunks of 128)
+
+struct jch_buf {  // grow-only device buffer
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct jch_uid {
+    char internal[128];
+};
+struct jch_rccl {  // RCCL entry points, dlopen'ed on first use (single-GPU users never need RCCL)
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, jch_uid, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+struct jch_ctx {
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // communicator
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
+    // workspace (grow-only)
+    jch_buf xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq;
+    // profiling
+    bool profiling = false;
+    jch_profile prof{};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    // tuning knobs (env JCH_SWEEP_BLOCKS_PER_CU etc.)
+    int sweep_blocks_per_cu = 0;
+};
+
+// ---- error plumbing --------------------------------------------------------------------------------
+int32_t jch_fail(jch_ctx *ctx, int32_t code, const char *fmt, ...);
+#define JCH_HIP(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return jch_fail(ctx, e__ == hipErrorOutOfMemory ? JCH_ENOMEM : JCH_EHIP, "%s: %s (%s:%d)", #expr, \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                           \
+    } while (0)
+#define JCH_TRY(expr)                 \
+    do {                              \
+        int32_t s__ = (expr);         \
+        if (s__ != JCH_OK) return s__; \
+    } while (0)
+
+int32_t jch_reserve(jch_ctx *ctx, jch_buf &b, size_t bytes);
+int32_t jch_allreduce_f64(jch_ctx *ctx, double *dev_buf, size_t count);  // no-op when nranks == 1
+
+// profiling helpers: record an event on the stream when profiling is on
+struct jch_span {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+hipEvent_t jch_ev(jch_ctx *ctx);  // nullptr when profiling is off
+
+// ---- kernel launchers (each enqueues on ctx->stream; no host sync) --------------------------------
+// prologue.hip
+int32_t jch_launch_weights(jch_ctx *ctx, const double *w_dev /*may be null*/, int64_t n, double *dnorm,
+                           double *hdr /*[4] device: sum w, n_total*/);
+int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const double *Yc, int64_t ldy,
+                           const double *d, int64_t n, int p, int q, const double *means /*null: first moment*/,
+                           double *out /*[p+q] device*/, bool do_sqrt = true);
+int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d,
+                              int64_t n, int p, int q, const double *mom, const double *scl, bool writeback,
+                              double *Xr, int ldr, double *Yr, int qpad, double *K /*[p][qpad] device*/);
+int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n,
+                                   int p, int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy);
+// sweep.hip
+int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
+                         const double *Yr, int qpad, int q_extra /*0: plskern; q: also c_raw (plsnipals)*/,
+                         double *tcol, double *zt /*[p+1+q_extra] device, reduced over blocks*/);
+int32_t jch_launch_deflate(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q,
+                           const double *d, const double *tcol, const double *zpc /*[ldr + qpad]: zp then c*/,
+                           double *Knext /*[p][qpad] or null*/);
+// smallstate.hip
+struct jch_small {  // device-resident replicated small state of one fit
+    double *K;      // [p][qpad]
+    double *w, *r;  // [ldr]
+    double *P, *R, *W;  // [nlv][p]   (== Julia's p x nlv column-major)
+    double *C;          // [nlv][q]
+    double *TT;         // [nlv]
+    double *zt;         // [ldr + 1 + qpad]  reduced sweep output: zp, tt, (c_raw)
+    double *zpc;        // [ldr + qpad]      plsnipals: zp/tt, c/tt
+    double *mom, *scl;  // [p+q]
+    double *hdr;        // [4]
+};
+int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a /*-1: init*/,
+                             int nlv, int algo /*0 plskern, 1 plsnipals*/);
+int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv);
+// gemm.hip
+int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p, int64_t ldx, const double *Bs /*[p][kpad] scaled*/,
+                               int k, int kpad, const double *bias /*[kpad]*/, double *out, int64_t ldo);
+int32_t jch_launch_weighted_ss(jch_ctx *ctx, const double *Xc, int64_t n, int p, int64_t ldx, const double *d,
+                               const double *shift, const double *iscale, double *out1);
+// util.hip
+int32_t jch_launch_fill(jch_ctx *ctx, double *out, int64_t n, int64_t p, int64_t ld, int64_t row0, int64_t n_total,
+                        uint64_t seed);
+
+// ---- device helpers ---------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ double jch_wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in every thread.
+// scratch: >= NT/64 doubles of LDS.  Deterministic (fixed tree).
+template <int NT>
+__device__ __forceinline__ double jch_block_sum(double v, double *scratch)
+{
+    v = jch_wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wv] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += scratch[i];
+    return s;
+}
+#endif

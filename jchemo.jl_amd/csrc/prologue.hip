@@ -1,0 +1,302 @@
+// Prologue kernels of a fit (src/plskern.jl:114-132 == src/plsnipals.jl:39-56):
+//   K0  weight normalisation            mweight            utility.jl:715-723
+//   K1  weighted column means / vars    colmean, colvar    utility.jl:195, 314-323 (two-pass variance)
+//   K2  centre/scale + re-layout + XtY  center!/cscale!    utility.jl:76-81, 482-487; plskern.jl:131-132
+// Input X, Y are column-major (Julia); the working copy Xr is ROW-major (ld = ldr, even, pad column zero)
+// so the per-LV sweep streams whole rows.  K2 is the one real tall-skinny GEMM of the fit and runs on
+// v_mfma_f64_16x16x4_f64 (A = X tile^T, B = d.*Y tile, N = q padded to 16).
+#include "jch_internal.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- K0: weights
+__global__ __launch_bounds__(256) void k_wsum_part(const double *__restrict__ w, int64_t n, double *__restrict__ part)
+{
+    __shared__ double sc[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += w[i];
+    s = jch_block_sum<256>(s, sc);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_wsum_final(const double *__restrict__ part, int nb, int64_t n, int have_w,
+                                                    double *__restrict__ hdr)
+{
+    __shared__ double sc[4];
+    double s = 0.0;
+    if (have_w)
+        for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    s = jch_block_sum<256>(s, sc);
+    if (threadIdx.x == 0) {
+        hdr[0] = have_w ? s : (double)n;  // sum of weights of this shard
+        hdr[1] = (double)n;               // rows of this shard
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wnorm(const double *__restrict__ w, int64_t n, const double *__restrict__ hdr,
+                                               double *__restrict__ d)
+{
+    const double sw = hdr[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        d[i] = (w ? w[i] : 1.0) / sw;
+}
+
+int32_t jch_launch_weights(jch_ctx *ctx, const double *w, int64_t n, double *dnorm, double *hdr)
+{
+    const int nb = (int)std::min<int64_t>(1024, (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
+    JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * 4096));
+    double *part = (double *)ctx->colpart.ptr;
+    if (w) hipLaunchKernelGGL(k_wsum_part, dim3(nb), dim3(256), 0, ctx->stream, w, n, part);
+    hipLaunchKernelGGL(k_wsum_final, dim3(1), dim3(256), 0, ctx->stream, part, nb, n, w ? 1 : 0, hdr);
+    JCH_TRY(jch_allreduce_f64(ctx, hdr, 2));  // global sum of weights, global row count
+    hipLaunchKernelGGL(k_wnorm, dim3(nb), dim3(256), 0, ctx->stream, w, n, hdr, dnorm);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+// ---------------------------------------------------------------- K1: weighted column moments
+// grid (p+q, S): block (j, s) reduces rows [s*chunk, (s+1)*chunk) of column j.
+template <bool VAR>
+__global__ __launch_bounds__(256) void k_moments(const double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
+                                                  int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
+                                                  int64_t chunk, const double *__restrict__ means,
+                                                  double *__restrict__ colpart)
+{
+    __shared__ double sc[4];
+    const int j = blockIdx.x;
+    const double *col = j < p ? Xc + (size_t)j * (size_t)ldx : Yc + (size_t)(j - p) * (size_t)ldy;
+    const int64_t i0 = (int64_t)blockIdx.y * chunk;
+    const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
+    const double m = VAR ? means[j] : 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = i0 + threadIdx.x;
+    for (; i + 768 < i1; i += 1024) {
+        double a0 = col[i], a1 = col[i + 256], a2 = col[i + 512], a3 = col[i + 768];
+        double d0 = d[i], d1 = d[i + 256], d2 = d[i + 512], d3 = d[i + 768];
+        if (VAR) { a0 -= m; a1 -= m; a2 -= m; a3 -= m; a0 *= a0; a1 *= a1; a2 *= a2; a3 *= a3; }
+        s0 += d0 * a0; s1 += d1 * a1; s2 += d2 * a2; s3 += d3 * a3;
+    }
+    for (; i < i1; i += 256) {
+        double a0 = col[i];
+        if (VAR) { a0 -= m; a0 *= a0; }
+        s0 += d[i] * a0;
+    }
+    double s = jch_block_sum<256>((s0 + s1) + (s2 + s3), sc);
+    if (threadIdx.x == 0) colpart[(size_t)blockIdx.y * (size_t)(p + q) + j] = s;
+}
+
+__global__ __launch_bounds__(256) void k_colreduce(const double *__restrict__ colpart, int S, int m, int sqrt_out,
+                                                   double *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    double s = 0.0;
+    for (int k = 0; k < S; ++k) s += colpart[(size_t)k * m + j];
+    out[j] = s;
+    (void)sqrt_out;
+}
+
+__global__ __launch_bounds__(256) void k_sqrt_inplace(double *__restrict__ v, int m)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < m) v[j] = sqrt(v[j]);
+}
+
+int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const double *Yc, int64_t ldy, const double *d,
+                           int64_t n, int p, int q, const double *means, double *out, bool do_sqrt)
+{
+    const int m = p + q;
+    int S = (ctx->cus * 8 + m - 1) / m;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    int64_t chunk = (n + S - 1) / S;
+    chunk = (chunk + 255) / 256 * 256;
+    if (chunk < 256) chunk = 256;
+    S = (int)((n + chunk - 1) / chunk);
+    if (S < 1) S = 1;
+    JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * (size_t)S * m + 4096 * sizeof(double)));
+    double *colpart = (double *)ctx->colpart.ptr;
+    if (means)
+        hipLaunchKernelGGL(k_moments<true>, dim3(m, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk,
+                           means, colpart);
+    else
+        hipLaunchKernelGGL(k_moments<false>, dim3(m, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk,
+                           means, colpart);
+    hipLaunchKernelGGL(k_colreduce, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, colpart, S, m, 0, out);
+    JCH_TRY(jch_allreduce_f64(ctx, out, (size_t)m));
+    if (means && do_sqrt) hipLaunchKernelGGL(k_sqrt_inplace, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, out, m);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+// ---------------------------------------------------------------- K2: centre/scale + row-major copy + XtY
+// Tile: 64 rows x 64 columns, 256 threads (4 waves).  grid = (row slots, column tiles, y groups of 16).
+#define XT_LD 65
+#define YT_LD 17
+// WRITEBACK (plskern!/plsnipals! semantics) stores the centred X back into the caller's column-major
+// array; it is only legal when each X element is read by exactly one block (one y group).  Y is never
+// written here (every column tile re-reads the raw Y rows): the launcher exports Yr afterwards.
+template <bool WRITEBACK>
+__global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
+                                                     int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
+                                                     const double *__restrict__ mom, const double *__restrict__ scl,
+                                                     double *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
+                                                     double *__restrict__ Kpart, int kp_rows)
+{
+    __shared__ double xt[64 * XT_LD];
+    __shared__ double yt[64 * YT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = blockIdx.y * 64;
+    const int yg = blockIdx.z;
+    const int64_t nchunks = (n + 63) / 64;
+    // per-thread column constants for the load phase: columns (tid>>6) + 4k, k = 0..15
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t i0 = c * 64;
+        // ---- Y tile: 64 rows x 16 cols, element e = tid + 256k -> (row e&63, col e>>6)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + 256 * k, row = e & 63, col = e >> 6;
+            const int yc = yg * 16 + col;
+            const int64_t i = i0 + row;
+            double v = 0.0, dv = 0.0;
+            if (i < n && yc < q) {
+                v = (Yc[(size_t)i + (size_t)yc * (size_t)ldy] - mom[p + yc]) / scl[p + yc];
+                dv = d[i];
+            }
+            if (blockIdx.y == 0 && i < n) Yr[(size_t)i * qpad + yc] = v;
+            yt[row * YT_LD + col] = dv * v;
+        }
+        // ---- X tile: 64 rows x 64 cols, coalesced down the columns
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int col = wv + 4 * k, j = j0 + col;
+            const int64_t i = i0 + lane;
+            double v = 0.0;
+            if (i < n && j < p) {
+                v = (Xc[(size_t)i + (size_t)j * (size_t)ldx] - mom[j]) / scl[j];
+                if (WRITEBACK && yg == 0) Xc[(size_t)i + (size_t)j * (size_t)ldx] = v;
+            }
+            xt[lane * XT_LD + col] = v;
+        }
+        __syncthreads();
+        // ---- row-major store (y group 0 only): element e -> (col e&63, row e>>6)
+        if (yg == 0) {
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                const int row = wv + 4 * k, j = j0 + lane;
+                const int64_t i = i0 + row;
+                if (i < n && j < ldr) Xr[(size_t)i * ldr + j] = xt[row * XT_LD + lane];
+            }
+        }
+        // ---- XtY on the matrix cores: wave wv owns columns j0+16wv .. +15
+        //      A[m = x column][k = row] , B[k = row][n = y column]; lane l: (k = l>>4, m|n = l&15)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int row = 4 * kk + (lane >> 4);
+            const double a = xt[row * XT_LD + 16 * wv + (lane & 15)];
+            const double b = yt[row * YT_LD + (lane & 15)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[m][n]: n = lane&15 (y column), m = (lane>>4) + 4*reg (x column within the wave's 16)
+    double *kp = Kpart + ((size_t)blockIdx.x * kp_rows) * qpad;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int j = j0 + 16 * wv + (lane >> 4) + 4 * reg;
+        if (j < kp_rows) kp[(size_t)j * qpad + yg * 16 + (lane & 15)] = acc[reg];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_kpart(const double *__restrict__ Kpart, int nbx, int kp_rows, int p, int qpad,
+                                                      double *__restrict__ K)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p * qpad) return;
+    const size_t stride = (size_t)kp_rows * qpad;
+    double s = 0.0;
+    for (int b = 0; b < nbx; ++b) s += Kpart[(size_t)b * stride + e];
+    K[e] = s;
+}
+
+int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d, int64_t n,
+                              int p, int q, const double *mom, const double *scl, bool writeback, double *Xr, int ldr,
+                              double *Yr, int qpad, double *K)
+{
+    const int ptiles = (ldr + 63) / 64;
+    const int kp_rows = ptiles * 64;
+    const int ygroups = qpad / 16;
+    const int64_t nchunks = (n + 63) / 64;
+    int nbx = (ctx->cus * 3 + ptiles * ygroups - 1) / (ptiles * ygroups);
+    if (nbx < 1) nbx = 1;
+    if (nbx > nchunks) nbx = (int)(nchunks > 0 ? nchunks : 1);
+    JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * qpad));
+    double *Kpart = (double *)ctx->kpart.ptr;
+    dim3 grid(nbx, ptiles, ygroups);
+    const bool wb_fused = writeback && ygroups == 1;
+    if (wb_fused)
+        hipLaunchKernelGGL(k_center_xty<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, mom, scl, Xr,
+                           ldr, Yr, qpad, Kpart, kp_rows);
+    else
+        hipLaunchKernelGGL(k_center_xty<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, mom, scl, Xr,
+                           ldr, Yr, qpad, Kpart, kp_rows);
+    hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad,
+                       K);
+    JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
+    JCH_HIP(ctx, hipGetLastError());
+    if (writeback)  // Y always, X only when it could not be fused above
+        JCH_TRY(jch_launch_export_colmajor(ctx, wb_fused ? nullptr : Xr, ldr, Yr, qpad, n, p, q, Xc, ldx, Yc, ldy));
+    return JCH_OK;
+}
+
+// ---------------------------------------------------------------- export: row-major working copy -> column-major
+// (plsnipals! hands back the deflated X, Y: src/plsnipals.jl:86-87)
+__global__ __launch_bounds__(256) void k_export_colmajor(const double *__restrict__ Xr, int ldr, const double *__restrict__ Yr,
+                                                          int qpad, int64_t n, int p, int q, double *__restrict__ Xc,
+                                                          int64_t ldx, double *__restrict__ Yc, int64_t ldy)
+{
+    __shared__ double xt[64 * XT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = blockIdx.y * 64;
+    const int64_t nchunks = (n + 63) / 64;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t i0 = c * 64;
+        if (Xr) {
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                const int row = wv + 4 * k, j = j0 + lane;
+                const int64_t i = i0 + row;
+                xt[row * XT_LD + lane] = (i < n && j < p) ? Xr[(size_t)i * ldr + j] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {
+                const int col = wv + 4 * k, j = j0 + col;
+                const int64_t i = i0 + lane;
+                if (i < n && j < p) Xc[(size_t)i + (size_t)j * (size_t)ldx] = xt[lane * XT_LD + col];
+            }
+        }
+        if (blockIdx.y == 0 && Yc) {
+            for (int e = tid; e < 64 * q; e += 256) {
+                const int row = e & 63, yc = e >> 6;
+                const int64_t i = i0 + row;
+                if (i < n) Yc[(size_t)i + (size_t)yc * (size_t)ldy] = Yr[(size_t)i * qpad + yc];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n, int p,
+                                   int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy)
+{
+    const int ptiles = Xr ? (p + 63) / 64 : 1;
+    const int64_t nchunks = (n + 63) / 64;
+    int nbx = (ctx->cus * 4 + ptiles - 1) / ptiles;
+    if (nbx > nchunks) nbx = (int)(nchunks > 0 ? nchunks : 1);
+    hipLaunchKernelGGL(k_export_colmajor, dim3(nbx, ptiles), dim3(256), 0, ctx->stream, Xr, ldr, Yr, qpad, n, p, q, Xc, ldx,
+                       Yc, ldy);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}

@@ -1,0 +1,346 @@
+// K3/K5 — the replicated small state of a fit, one workgroup, everything p x q or smaller, all fp64.
+//
+//   phase A (finish LV a)   src/plskern.jl:165-166,168-174: c = K'r/tt ; K -= zp c' ; P_a, W_a, R_a, C_a, TT_a
+//                           src/plsnipals.jl:82,84,89-93  : zp/tt, c/tt and the column stores
+//   phase B (prepare a+1)   src/plskern.jl:150-161 / src/plsnipals.jl:72-77: w = dominant left singular
+//                           vector of K (q == 1: K/||K||), r = w - sum_j (w.P_j) R_j
+// The reference calls LAPACK dgesdd on the p x q matrix; here: Gram G = K'K (q x q), parallel cyclic
+// Jacobi eigen-decomposition in LDS, v = dominant eigenvector, w = K v / ||K v||  (matches dgesdd's U[:,1]
+// to <= 3e-13).  Sign rule (the reference's sign is LAPACK's, F3): largest-|.| entry of v > 0.
+// Every rank of a multi-GPU fit runs this kernel on identical all-reduced inputs -> bit-identical state.
+#include "jch_internal.h"
+
+#define NT 256
+
+// out[k] (k < ncols) = sum_j A[j*lda + k] * x[j], j < rows.  ncols <= 64.  scratch >= 256 doubles.
+__device__ static void block_matTvec(const double *__restrict__ A, int lda, int rows, int ncols,
+                                     const double *__restrict__ x, double *out_lds, double *scratch)
+{
+    const int cw = ncols <= 16 ? 16 : (ncols <= 32 ? 32 : 64);
+    const int groups = NT / cw;
+    const int k = threadIdx.x % cw, g = threadIdx.x / cw;
+    double s = 0.0;
+    if (k < ncols)
+        for (int j = g; j < rows; j += groups) s += A[(size_t)j * lda + k] * x[j];
+    __syncthreads();
+    scratch[g * cw + k] = s;
+    __syncthreads();
+    if (threadIdx.x < ncols) {
+        double t = 0.0;
+        for (int gg = 0; gg < groups; ++gg) t += scratch[gg * cw + threadIdx.x];
+        out_lds[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// Parallel cyclic Jacobi on the symmetric q x q matrix in A0 (LDS, ld = lda).  On return the eigenvalues are
+// on the diagonal of the returned buffer and V holds the eigenvectors (columns).  Two syncs per round.
+__device__ static void jacobi_eig(int q, int lda, double *&A0, double *&A1, double *&V0, double *&V1, double *cs,
+                                  int *partner, int *flag)
+{
+    const int m = (q + 1) & ~1;  // even number of players; index q (if odd) is a bye
+    const int tid = threadIdx.x;
+    for (int e = tid; e < q * q; e += NT) {
+        const int i = e / q, j = e % q;
+        V0[i * lda + j] = (i == j) ? 1.0 : 0.0;
+    }
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        for (int round = 0; round < m - 1; ++round) {
+            // ---- step 1: one thread per pair computes its rotation
+            if (tid < m / 2) {
+                int a, b;
+                if (tid == 0) { a = m - 1; b = round; }
+                else { a = (round + tid) % (m - 1); b = (round - tid + (m - 1)) % (m - 1); }
+                if (a > b) { const int t = a; a = b; b = t; }
+                double c = 1.0, s = 0.0;
+                if (b < q) {
+                    const double app = A0[a * lda + a], aqq = A0[b * lda + b], apq = A0[a * lda + b];
+                    if (fabs(apq) > 1e-290 && fabs(apq) > 1e-17 * sqrt(fabs(app * aqq))) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0);
+                        s = t * c;
+                        *flag = 1;  // benign race: any rotation this sweep sets it
+                    }
+                    partner[a] = b; partner[b] = a;
+                    // role: +1 for the lower index (p), -1 for the higher (q)
+                    cs[2 * a] = c; cs[2 * a + 1] = s;
+                    cs[2 * b] = c; cs[2 * b + 1] = -s;
+                } else if (a < q) {  // bye
+                    partner[a] = a;
+                    cs[2 * a] = 1.0; cs[2 * a + 1] = 0.0;
+                }
+            }
+            __syncthreads();
+            // ---- step 2: A1 = J' A0 J, V1 = V0 J   (for index i with partner i': Jcol_i = c e_i + s_i e_i',
+            //      with s_i = +s for the lower index (new_p = c*x_p - s*x_q) -> encoded so that
+            //      new_i = c * x_i - sgn * s * x_partner, sgn carried in cs[2i+1])
+            for (int e = tid; e < q * q; e += NT) {
+                const int i = e / q, j = e % q;
+                const int ip = partner[i], jp = partner[j];
+                const double ci = cs[2 * i], si = cs[2 * i + 1], cj = cs[2 * j], sj = cs[2 * j + 1];
+                // row op on rows (i, ip) evaluated at columns j and jp
+                const double rij = ci * A0[i * lda + j] - si * A0[ip * lda + j];
+                const double rijp = ci * A0[i * lda + jp] - si * A0[ip * lda + jp];
+                A1[i * lda + j] = cj * rij - sj * rijp;
+                V1[i * lda + j] = cj * V0[i * lda + j] - sj * V0[i * lda + jp];
+            }
+            __syncthreads();
+            double *t = A0; A0 = A1; A1 = t;
+            t = V0; V0 = V1; V1 = t;
+        }
+        const int any = *flag;
+        __syncthreads();
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
+struct lv_args {
+    jch_small s;
+    int p, q, qpad, ldr, a, nlv, algo, do_a, do_b;
+};
+
+__global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int p = g.p, q = g.q, qpad = g.qpad, ldr = g.ldr, a = g.a, tid = threadIdx.x;
+    const int lda = q + 1;
+    double *scratch = lds;                 // [256]
+    double *vec = scratch + 256;           // [64]   c / v / dots
+    double *dots = vec + 64;               // [nlv]  (<= 256 reserved)
+    double *A0 = dots + 256, *A1 = A0 + q * lda, *V0 = A1 + q * lda, *V1 = V0 + q * lda;
+    double *cs = V1 + q * lda;             // [2*(q+1)]
+    int *partner = reinterpret_cast<int *>(cs + 2 * (q + 2));  // [q+1]
+    int *flag = partner + (q + 2);
+    double *K = g.s.K;
+    const double *zt = g.s.zt;
+
+    // ------------------------------------------------------------------ phase A
+    if (g.do_a) {
+        const double tt = zt[ldr];
+        if (g.algo == 0) {
+            block_matTvec(K, qpad, p, q, g.s.r, vec, scratch);  // vec[k] = (K' r)_k
+            if (tid < q) {
+                vec[tid] = vec[tid] / tt;
+                g.s.C[(size_t)a * q + tid] = vec[tid];
+            }
+            __syncthreads();
+            for (int e = tid; e < p * q; e += NT) {
+                const int j = e / q, k = e % q;
+                K[(size_t)j * qpad + k] -= zt[j] * vec[k];
+            }
+            for (int j = tid; j < p; j += NT) {
+                g.s.P[(size_t)a * p + j] = zt[j] / tt;
+                g.s.W[(size_t)a * p + j] = g.s.w[j];
+                g.s.R[(size_t)a * p + j] = g.s.r[j];
+            }
+        } else {
+            for (int j = tid; j < ldr; j += NT) {
+                const double z = j < p ? zt[j] / tt : 0.0;
+                g.s.zpc[j] = z;
+                if (j < p) {
+                    g.s.P[(size_t)a * p + j] = z;
+                    g.s.W[(size_t)a * p + j] = g.s.w[j];
+                }
+            }
+            for (int k = tid; k < qpad; k += NT) {
+                const double c = k < q ? zt[ldr + 1 + k] / tt : 0.0;
+                g.s.zpc[ldr + k] = c;
+                if (k < q) g.s.C[(size_t)a * q + k] = c;
+            }
+        }
+        if (tid == 0) g.s.TT[a] = tt;
+        __syncthreads();
+        __threadfence_block();
+    }
+    if (!g.do_b) return;
+
+    // ------------------------------------------------------------------ phase B: next w, r
+    const int anext = g.do_a ? a + 1 : a;  // number of finished LVs (columns of P/R valid)
+    double ssq = 0.0;
+    if (q == 1) {
+        for (int j = tid; j < p; j += NT) {
+            const double v = K[(size_t)j * qpad];
+            g.s.w[j] = v;
+            ssq += v * v;
+        }
+    } else {
+        // Gram G = K'K (q x q): the nent = q(q+1)/2 upper entries, rows of K split over NT/EW groups
+        const int nent = q * (q + 1) / 2;
+        const int EW = nent <= 64 ? 64 : (nent <= 128 ? 128 : 256);
+        const int G = NT / EW, el = tid % EW, gr = tid / EW;
+        for (int e0 = 0; e0 < nent; e0 += EW) {
+            int e = e0 + el, k1 = 0;
+            double s = 0.0;
+            const bool act = e < nent;
+            if (act) {
+                while (e >= q - k1) { e -= q - k1; ++k1; }
+                const int k2 = k1 + e;
+                for (int j = gr; j < p; j += G) s += K[(size_t)j * qpad + k1] * K[(size_t)j * qpad + k2];
+            }
+            __syncthreads();
+            scratch[gr * EW + el] = s;
+            __syncthreads();
+            if (act && gr == 0) {
+                double t = 0.0;
+                for (int gg = 0; gg < G; ++gg) t += scratch[gg * EW + el];
+                const int k2 = k1 + e;
+                A0[k1 * lda + k2] = t;
+                A0[k2 * lda + k1] = t;
+            }
+        }
+        __syncthreads();
+        jacobi_eig(q, lda, A0, A1, V0, V1, cs, partner, flag);
+        if (tid == 0) {
+            int best = 0;
+            for (int k = 1; k < q; ++k)
+                if (A0[k * lda + k] > A0[best * lda + best]) best = k;
+            double big = 0.0;
+            for (int k = 0; k < q; ++k)
+                if (fabs(V0[k * lda + best]) > fabs(big)) big = V0[k * lda + best];
+            const double sg = big < 0.0 ? -1.0 : 1.0;
+            for (int k = 0; k < q; ++k) vec[k] = sg * V0[k * lda + best];
+        }
+        __syncthreads();
+        for (int j = tid; j < p; j += NT) {
+            double wv = 0.0;
+            for (int k = 0; k < q; ++k) wv += K[(size_t)j * qpad + k] * vec[k];
+            g.s.w[j] = wv;
+            ssq += wv * wv;
+        }
+    }
+    const double nrm = sqrt(jch_block_sum<NT>(ssq, scratch));
+    const bool plain = (g.algo == 1 || anext == 0);
+    for (int j = tid; j < ldr; j += NT) {  // each thread re-reads only its own stores
+        const double wv = j < p ? g.s.w[j] / nrm : 0.0;
+        g.s.w[j] = wv;
+        if (plain) g.s.r[j] = wv;
+    }
+    if (plain) return;
+    // dots[i] = w . P_i   (one wave per finished LV, lanes stride the vector)
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int i = wv; i < anext; i += NT / 64) {
+            const double *Pi = g.s.P + (size_t)i * p;
+            double s = 0.0;
+            for (int j = lane; j < p; j += 64) s += g.s.w[j] * Pi[j];
+            s = jch_wave_sum(s);
+            if (lane == 0) dots[i] = s;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < ldr; j += NT) {
+        double rj = 0.0;
+        if (j < p) {
+            rj = g.s.w[j];
+            for (int l = 0; l < anext; ++l) rj -= dots[l] * g.s.R[(size_t)l * p + j];
+        }
+        g.s.r[j] = rj;
+    }
+}
+
+int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo)
+{
+    // a encodes the phase:  a == -1           -> phase B only (first w, r)
+    //                       a >= 0, a < nlv   -> phase A for LV a, then phase B unless it was the last LV
+    // plsnipals splits A and B around the deflation pass: a |= 0x40000000 -> phase A only,
+    //                                                      a |= 0x20000000 -> phase B only with `a` LVs finished.
+    lv_args g;
+    g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.nlv = nlv; g.algo = algo;
+    const int flags = a < 0 ? 0 : (a & 0x60000000);
+    const int aa = a < 0 ? -1 : (a & 0x1fffffff);
+    if (aa < 0) { g.a = 0; g.do_a = 0; g.do_b = 1; }
+    else if (flags & 0x40000000) { g.a = aa; g.do_a = 1; g.do_b = 0; }
+    else if (flags & 0x20000000) { g.a = aa; g.do_a = 0; g.do_b = 1; }
+    else { g.a = aa; g.do_a = 1; g.do_b = (aa + 1 < nlv) ? 1 : 0; }
+    if (nlv > 256) return jch_fail(ctx, JCH_EINVAL, "nlv > 256 not supported");
+    const int lda = q + 1;
+    const size_t lds = sizeof(double) * (256 + 64 + 256 + 4 * (size_t)q * lda + 2 * (q + 2)) + sizeof(int) * (q + 2 + 2);
+    hipLaunchKernelGGL(k_lv_update, dim3(1), dim3(NT), lds, ctx->stream, g);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+// R = W inv(P'W)   (src/plsnipals.jl:95) — once per plsnipals fit; single workgroup, Gauss-Jordan with
+// partial pivoting on the nlv x nlv matrix held in global scratch (s.zt region is too small: uses s.K? no —
+// caller provides scratch via s.hdr + 4; see fit.hip).
+struct nipR_args {
+    const double *P, *W;
+    double *R, *M, *Mi;
+    int p, nlv;
+};
+__global__ __launch_bounds__(NT) void k_nipals_R(nipR_args g)
+{
+    __shared__ int piv_s;
+    const int m = g.nlv, p = g.p, tid = threadIdx.x;
+    // M = P' W   (m x m, row-major [i][j]);  P, W stored [lv][p]
+    for (int e = tid >> 6; e < m * m; e += NT / 64) {
+        const int i = e / m, j = e % m, lane = tid & 63;
+        double s = 0.0;
+        for (int k = lane; k < p; k += 64) s += g.P[(size_t)i * p + k] * g.W[(size_t)j * p + k];
+        s = jch_wave_sum(s);
+        if (lane == 0) { g.M[e] = s; g.Mi[e] = (i == j) ? 1.0 : 0.0; }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int c = 0; c < m; ++c) {
+        if (tid == 0) {
+            int piv = c; double best = fabs(g.M[c * m + c]);
+            for (int i = c + 1; i < m; ++i)
+                if (fabs(g.M[i * m + c]) > best) { best = fabs(g.M[i * m + c]); piv = i; }
+            piv_s = piv;
+        }
+        __syncthreads();
+        const int piv = piv_s;
+        if (piv != c)
+            for (int j = tid; j < m; j += NT) {
+                double t = g.M[c * m + j]; g.M[c * m + j] = g.M[piv * m + j]; g.M[piv * m + j] = t;
+                t = g.Mi[c * m + j]; g.Mi[c * m + j] = g.Mi[piv * m + j]; g.Mi[piv * m + j] = t;
+            }
+        __threadfence();
+        __syncthreads();
+        const double dd = g.M[c * m + c];
+        __syncthreads();
+        for (int j = tid; j < m; j += NT) { g.M[c * m + j] /= dd; g.Mi[c * m + j] /= dd; }
+        __threadfence();
+        __syncthreads();
+        for (int e = tid; e < m * m; e += NT) {
+            const int i = e / m, j = e % m;
+            if (i == c) continue;
+            const double f = g.M[i * m + c];
+            // column c of M (the multipliers f) is left untouched in this step and zeroed in the next
+            if (f != 0.0 && j != c) g.M[i * m + j] -= f * g.M[c * m + j];
+            if (f != 0.0) g.Mi[i * m + j] -= f * g.Mi[c * m + j];
+        }
+        __threadfence();
+        __syncthreads();
+        for (int i = tid; i < m; i += NT)
+            if (i != c) g.M[i * m + c] = 0.0;
+        __threadfence();
+        __syncthreads();
+    }
+    // R[j][k] = sum_i W[i][k] * Mi[i][j]      (R = W * inv(P'W), stored [lv][p])
+    for (int e = tid; e < m * p; e += NT) {
+        const int j = e / p, k = e % p;
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += g.W[(size_t)i * p + k] * g.Mi[i * m + j];
+        g.R[(size_t)j * p + k] = s;
+    }
+}
+
+int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv)
+{
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, sizeof(double) * 2 * (size_t)nlv * nlv));
+    nipR_args g;
+    g.P = s.P; g.W = s.W; g.R = s.R; g.p = p; g.nlv = nlv;
+    g.M = (double *)ctx->gemm_b.ptr;
+    g.Mi = g.M + (size_t)nlv * nlv;
+    hipLaunchKernelGGL(k_nipals_R, dim3(1), dim3(NT), 0, ctx->stream, g);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}

@@ -1,0 +1,145 @@
+"""ctypes binding of libjchemo_hip.so (C ABI: include/jchemo_hip.h).
+
+No CPU fallback: if the HIP library is missing or no gfx950 device is present, every compute entry
+point raises — the product path never routes through oracle/ or numpy arithmetic for n-sized work.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+try:  # torch (if present) must load its bundled HIP runtime BEFORE our library resolves libamdhip64.so.7,
+    import torch  # noqa: F401  so that torch tensors and this library share one runtime instance.
+except Exception:  # pragma: no cover
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libjchemo_hip.so")
+
+JCH_OK, JCH_EINVAL, JCH_EHIP, JCH_ERCCL, JCH_ENOMEM, JCH_ENODEV = 0, -1, -2, -3, -4, -5
+LOC_HOST, LOC_DEVICE = 0, 1
+F64, BF16 = 0, 1
+
+SYMBOLS = (
+    "jch_version", "jch_ctx_create", "jch_ctx_destroy", "jch_last_error", "jch_comm_unique_id",
+    "jch_ctx_comm_init", "jch_ctx_comm_info", "jch_plskern_fit", "jch_plsnipals_fit", "jch_affine_gemm",
+    "jch_weighted_ss", "jch_fill_uniform", "jch_ctx_set_profiling", "jch_ctx_get_profile",
+)
+
+
+class JchError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libjchemo_hip error {code}: {msg}")
+        self.code = code
+
+
+class PlsDesc(C.Structure):
+    _fields_ = [("n", C.c_int64), ("p", C.c_int64), ("q", C.c_int64), ("nlv", C.c_int32), ("scal", C.c_int32),
+                ("dtype", C.c_int32), ("loc", C.c_int32), ("inplace", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("fit_ms", C.c_double), ("prologue_ms", C.c_double), ("sweep_ms", C.c_double),
+                ("smallstate_ms", C.c_double), ("sweep_launches", C.c_int32), ("nlv", C.c_int32),
+                ("sweep_bytes", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built: `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JchError(JCH_ENODEV, f"{LIB_PATH} not built; run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p  # double* passed as raw addresses
+    L.jch_version.restype = i32
+    L.jch_ctx_create.argtypes = [C.POINTER(vp), i32, vp, C.c_uint32]
+    L.jch_ctx_destroy.argtypes = [vp]
+    L.jch_last_error.argtypes = [vp]
+    L.jch_last_error.restype = C.c_char_p
+    L.jch_comm_unique_id.argtypes = [vp]
+    L.jch_ctx_comm_init.argtypes = [vp, vp, i32, i32]
+    L.jch_ctx_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    fit = [vp, C.POINTER(PlsDesc), dp, i64, dp, i64, dp] + [dp] * 11 + [C.POINTER(i32)]
+    L.jch_plskern_fit.argtypes = fit
+    L.jch_plsnipals_fit.argtypes = fit
+    L.jch_affine_gemm.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, i64, dp, dp, i64]
+    L.jch_weighted_ss.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, C.POINTER(C.c_double)]
+    L.jch_fill_uniform.argtypes = [vp, dp, i64, i64, i64, i64, i64, C.c_uint64]
+    L.jch_ctx_set_profiling.argtypes = [vp, i32]
+    L.jch_ctx_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    for name in SYMBOLS:
+        if name != "jch_last_error":
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+class Context:
+    """One GPU, one stream (jch_ctx).  `stream` = a hipStream_t handle (int) or None for a private stream;
+    'torch' = torch's current stream on that device."""
+
+    def __init__(self, device: int = 0, stream=None):
+        L = load()
+        h = C.c_void_p()
+        if stream == "torch":
+            if torch is None:
+                raise JchError(JCH_EINVAL, "stream='torch' needs torch")
+            stream = torch.cuda.current_stream(device).cuda_stream
+        st = L.jch_ctx_create(C.byref(h), device, C.c_void_p(stream or 0), 0)
+        if st != JCH_OK:
+            raise JchError(st, L.jch_last_error(None).decode())
+        self._h = h
+        self.device = device
+        self.rank, self.nranks = 0, 1
+
+    def check(self, status: int):
+        if status != JCH_OK:
+            raise JchError(status, load().jch_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().jch_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- multi-GPU: one process per GPU, ids exchanged by the host side (torch.distributed here)
+    def comm_init(self, uid: bytes, rank: int, nranks: int):
+        buf = C.create_string_buffer(uid, 128)
+        self.check(load().jch_ctx_comm_init(self._h, buf, rank, nranks))
+        self.rank, self.nranks = rank, nranks
+
+    def set_profiling(self, on: bool):
+        self.check(load().jch_ctx_set_profiling(self._h, int(on)))
+
+    def profile(self) -> Profile:
+        pr = Profile()
+        self.check(load().jch_ctx_get_profile(self._h, C.byref(pr)))
+        return pr
+
+
+def unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    st = load().jch_comm_unique_id(buf)
+    if st != JCH_OK:
+        raise JchError(st, load().jch_last_error(None).decode())
+    return buf.raw
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        use_torch = torch is not None and torch.cuda.is_available()
+        _default_ctx[device] = Context(device, stream="torch" if use_torch else None)
+    return _default_ctx[device]

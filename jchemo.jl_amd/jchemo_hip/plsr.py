@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's operator interface for the PLS hot path.
+
+Same names, argument meaning and error behaviour as Jchemo.jl (paths relative to /root/reference):
+    plskern / plskern_ (= `plskern!`)      src/plskern.jl:106-178
+    plsnipals / plsnipals_ (= `plsnipals!`) src/plsnipals.jl:31-97
+    transform / coef / predict / summary    src/plskern.jl:187-260
+    Plsr                                    src/plskern.jl:1-14
+All n-sized arithmetic runs in libjchemo_hip.so (HIP, gfx950); numpy is used only for p x q glue
+(`coef`) exactly as the Julia wrapper does it on the host.  X / Y may be numpy arrays (host) or torch
+CUDA tensors (device-resident; column-major is Julia's layout, so a (n, p) torch tensor must satisfy
+stride(0) == 1 — use `colmajor_empty`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, JchError, PlsDesc, default_context
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+@dataclass
+class Plsr:
+    """Field names and shapes equal the reference's `Plsr` (src/plskern.jl:1-14).  `T` and `weights` are
+    numpy arrays for host fits and torch CUDA tensors for device-resident fits."""
+    T: object
+    P: np.ndarray
+    R: np.ndarray
+    W: np.ndarray
+    C: np.ndarray
+    TT: np.ndarray
+    xmeans: np.ndarray
+    xscales: np.ndarray
+    ymeans: np.ndarray
+    yscales: np.ndarray
+    weights: object
+    niter: Optional[np.ndarray] = None
+
+
+# ---------------------------------------------------------------------------------- array plumbing
+def _is_torch(a) -> bool:
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def colmajor_empty(n: int, p: int, device="cuda:0"):
+    """(n, p) float64 torch tensor with Julia's column-major strides (1, n)."""
+    return torch.empty((p, n), dtype=torch.float64, device=device).t()
+
+
+def ensure_mat(X):
+    """src/utility.jl:544-548: vector -> n x 1, number -> 1 x 1 (no copy when already a matrix)."""
+    if _is_torch(X):
+        if X.dim() == 1:
+            return X.reshape(-1, 1)
+        if X.dim() == 0:
+            return X.reshape(1, 1)
+        return X
+    X = np.asarray(X)
+    if X.ndim == 0:
+        return X.reshape(1, 1)
+    if X.ndim == 1:
+        return X.reshape(-1, 1)
+    return X
+
+
+def _addr_ld(a):
+    """(address, leading dimension) of a column-major float64 matrix view; raises if not column-major."""
+    if _is_torch(a):
+        if a.dtype != torch.float64:
+            raise TypeError("expected a float64 tensor")
+        n = a.shape[0]
+        if a.dim() == 1:
+            if a.stride(0) != 1 and n > 1:
+                raise ValueError("vector must be contiguous")
+            return a.data_ptr(), max(n, 1)
+        if n > 1 and a.stride(0) != 1:
+            raise ValueError("device matrix must be column-major (stride(0) == 1); see colmajor_empty()")
+        ld = a.stride(1) if a.shape[1] > 1 else max(n, 1)
+        if ld < n:
+            raise ValueError("bad leading dimension")
+        return a.data_ptr(), ld
+    if a.dtype != np.float64:
+        raise TypeError("expected a float64 array")
+    n = a.shape[0]
+    if a.ndim == 1:
+        if not a.flags.c_contiguous:
+            raise ValueError("vector must be contiguous")
+        return a.ctypes.data, max(n, 1)
+    if not a.flags.f_contiguous:
+        raise ValueError("host matrix must be Fortran-ordered (column-major)")
+    return a.ctypes.data, max(n, 1)
+
+
+def _as_colmajor_copy(a):
+    a = ensure_mat(a)
+    if _is_torch(a):
+        out = colmajor_empty(a.shape[0], a.shape[1], a.device)
+        out.copy_(a.to(torch.float64))
+        return out
+    return np.array(a, dtype=np.float64, order="F", copy=True)
+
+
+def _as_colmajor_view(a):
+    """For the `!` variants: the caller's own storage must be usable in place."""
+    a = ensure_mat(a)
+    _addr_ld(a)  # raises if not column-major float64
+    return a
+
+
+def _np(a):
+    return a.ctypes.data if a is not None else None
+
+
+# ---------------------------------------------------------------------------------- fits
+def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Optional[Context]):
+    dev = _is_torch(X)
+    if dev != _is_torch(Y):
+        raise TypeError("X and Y must both be host arrays or both device tensors")
+    if dev and not X.is_cuda:
+        raise TypeError("torch inputs must live on the GPU (host data: pass numpy arrays)")
+    n, p = X.shape
+    q = Y.shape[1]
+    if Y.shape[0] != n:
+        raise ValueError(f"DimensionMismatch: X has {n} rows, Y has {Y.shape[0]}")
+    device = X.device.index if dev else 0
+    ctx = ctx or default_context(device or 0)
+    if weights is None:
+        w_arr, w_addr = None, None
+    elif dev:
+        w_arr = weights if _is_torch(weights) else torch.as_tensor(np.asarray(weights, dtype=np.float64), device=X.device)
+        w_arr = w_arr.to(torch.float64).contiguous()
+        w_addr = w_arr.data_ptr()
+    else:
+        w_arr = np.ascontiguousarray(np.asarray(weights, dtype=np.float64).reshape(-1))
+        w_addr = w_arr.ctypes.data
+    if w_arr is not None and w_arr.shape[0] != n:
+        raise ValueError(f"DimensionMismatch: weights has {w_arr.shape[0]} entries, X has {n} rows")
+    kmax = max(1, min(p, int(nlv)))  # global-n clamp happens in the library (nlv_out)
+    if dev:
+        T = colmajor_empty(n, kmax, X.device)
+        wn = torch.empty(n, dtype=torch.float64, device=X.device)
+        t_addr, wn_addr = T.data_ptr(), wn.data_ptr()
+    else:
+        T = np.empty((n, kmax), dtype=np.float64, order="F")
+        wn = np.empty(n, dtype=np.float64)
+        t_addr, wn_addr = T.ctypes.data, wn.ctypes.data
+    P = np.zeros((p, kmax), order="F"); R = np.zeros((p, kmax), order="F"); W = np.zeros((p, kmax), order="F")
+    Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
+    xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
+    xa, ldx = _addr_ld(X)
+    ya, ldy = _addr_ld(Y)
+    desc = PlsDesc(n=n, p=p, q=q, nlv=int(nlv), scal=int(bool(scal)), dtype=_lib.F64,
+                   loc=_lib.LOC_DEVICE if dev else _lib.LOC_HOST, inplace=int(inplace), reserved=0)
+    got = C.c_int32(0)
+    if dev:
+        torch.cuda.current_stream(X.device).synchronize()  # inputs produced on other streams are complete
+    st = getattr(_lib.load(), entry)(ctx._h, C.byref(desc), xa, ldx, ya, ldy, w_addr, t_addr, _np(P), _np(R), _np(W),
+                                      _np(Cm), _np(TT), _np(xm), _np(xs), _np(ym), _np(ys), wn_addr, C.byref(got))
+    ctx.check(st)
+    k = got.value
+    return Plsr(T[:, :k], P[:, :k], R[:, :k], W[:, :k], Cm[:, :k], TT[:k], xm, xs, ym, ys, wn, None)
+
+
+def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plskern(X, Y, weights = ones(n); nlv, scal = false)` — src/plskern.jl:106-110.  X, Y untouched
+    (the reference copies them first; here the library simply never writes them)."""
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    try:
+        _addr_ld(X); _addr_ld(Y)
+    except (ValueError, TypeError):
+        X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)   # layout/dtype conversion only
+    return _fit("jch_plskern_fit", X, Y, weights, nlv, scal, False, ctx)
+
+
+def plskern_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plskern!(X::Matrix, Y::Matrix, ...)` — src/plskern.jl:112-178: X and Y are overwritten with their
+    centred/scaled versions, so they must be column-major float64 matrices owned by the caller."""
+    return _fit("jch_plskern_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
+
+
+def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plsnipals` — src/plsnipals.jl:31-35."""
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    try:
+        _addr_ld(X); _addr_ld(Y)
+    except (ValueError, TypeError):
+        X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
+    return _fit("jch_plsnipals_fit", X, Y, weights, nlv, scal, False, ctx)
+
+
+def plsnipals_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plsnipals!` — src/plsnipals.jl:37-97: X, Y end up centred/scaled AND deflated."""
+    return _fit("jch_plsnipals_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
+
+
+# ---------------------------------------------------------------------------------- accessors
+def _nlv_arg(fm: Plsr, nlv) -> int:
+    a = fm.P.shape[1]
+    return a if nlv is None else min(int(nlv), a)
+
+
+def _affine(X, shift, scale, B, bias, ctx):
+    X = ensure_mat(X)
+    try:
+        _addr_ld(X)
+    except (ValueError, TypeError):
+        X = _as_colmajor_copy(X)
+    dev = _is_torch(X)
+    m, p = X.shape
+    k = B.shape[1]
+    B = np.asfortranarray(B, dtype=np.float64)
+    if B.shape[0] != p:
+        raise ValueError(f"DimensionMismatch: X has {p} columns, the model has {B.shape[0]}")
+    ctx = ctx or default_context((X.device.index or 0) if dev else 0)
+    if dev:
+        out = colmajor_empty(m, k, X.device)
+        torch.cuda.current_stream(X.device).synchronize()
+        oa = out.data_ptr()
+    else:
+        out = np.empty((m, k), dtype=np.float64, order="F")
+        oa = out.ctypes.data
+    xa, ldx = _addr_ld(X)
+    sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+    bi = None if bias is None else np.ascontiguousarray(bias, dtype=np.float64).reshape(-1)
+    ctx.check(_lib.load().jch_affine_gemm(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, m, p, ldx, _np(sh), _np(sc),
+                                          B.ctypes.data, k, _np(bi), oa, max(m, 1)))
+    return out
+
+
+def transform(fm: Plsr, X, *, nlv: Optional[int] = None, ctx: Optional[Context] = None):
+    """src/plskern.jl:187-195: `cscale(X, xmeans, xscales) * R[:, 1:nlv]` (nlv clamped to the model's)."""
+    k = _nlv_arg(fm, nlv)
+    return _affine(X, fm.xmeans, fm.xscales, fm.R[:, :k], None, ctx)
+
+
+def coef(fm: Plsr, *, nlv: Optional[int] = None):
+    """src/plskern.jl:207-217 — (B p x q, int 1 x q); nlv = 0 gives B = 0.  p x q host glue."""
+    k = _nlv_arg(fm, nlv)
+    beta = fm.C[:, :k].T
+    B = (fm.R[:, :k] / fm.xscales[:, None]) @ beta * fm.yscales[None, :]
+    intercept = fm.ymeans[None, :] - fm.xmeans[None, :] @ B
+    return B, intercept
+
+
+def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Optional[Context] = None):
+    """src/plskern.jl:226-238: a collection of nlv becomes the contiguous range max(0,min):min(a,max); one
+    value -> matrix, several -> list of matrices.  All values are computed in ONE pass over X."""
+    a = fm.P.shape[1]
+    if nlv is None:
+        rng = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng = list(range(max(0, int(vals.min())), min(a, int(vals.max())) + 1))
+    q = fm.C.shape[0]
+    Bs, ints = zip(*(coef(fm, nlv=k) for k in rng))
+    out = _affine(X, None, None, np.concatenate(Bs, axis=1), np.concatenate([i.reshape(-1) for i in ints]), ctx)
+    preds = [out[:, i * q:(i + 1) * q] for i in range(len(rng))]
+    return preds[0] if len(preds) == 1 else preds
+
+
+def summary(fm: Plsr, X, *, ctx: Optional[Context] = None):
+    """src/plskern.jl:246-260 — explained X-variance table as a dict of columns (nlv, var, pvar, cumpvar)."""
+    X = ensure_mat(X)
+    try:
+        _addr_ld(X)
+    except (ValueError, TypeError):
+        X = _as_colmajor_copy(X)
+    dev = _is_torch(X)
+    n = X.shape[0]
+    nlv = fm.P.shape[1]
+    ctx = ctx or default_context((X.device.index or 0) if dev else 0)
+    w = fm.weights
+    if dev and not _is_torch(w):
+        w = torch.as_tensor(np.asarray(w), device=X.device)
+    if not dev and _is_torch(w):
+        w = w.cpu().numpy()
+    ss = C.c_double(0.0)
+    xa, ldx = _addr_ld(X)
+    wa = w.data_ptr() if dev else np.ascontiguousarray(w).ctypes.data
+    if dev:
+        torch.cuda.current_stream(X.device).synchronize()
+    ctx.check(_lib.load().jch_weighted_ss(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, X.shape[1], ldx, wa,
+                                          _np(np.ascontiguousarray(fm.xmeans)), _np(np.ascontiguousarray(fm.xscales)),
+                                          C.byref(ss)))
+    tt_adj = np.sum(fm.P ** 2, axis=0) * fm.TT
+    pvar = tt_adj / ss.value
+    return dict(nlv=np.arange(1, nlv + 1), var=tt_adj / n, pvar=pvar, cumpvar=np.cumsum(pvar))
