@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — latent-variables/sec of the plskern hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete `plskern(X, Y; nlv = 25)` fit (prologue + 25 latent variables) through the C ABI,
+with X (n x p) and Y (n x q) already resident in HBM in Julia's column-major layout (README.md:79-94:
+X = rand(n, p), Y = rand(n, q); here the portable splitmix64 generator, filled on the device).  For N > 1
+the n = 1e6 rows are sharded over the ranks (STRONG scaling, as the metric is quoted at fixed n) and every
+latent variable costs one RCCL all-reduce of [zp (p), tt].  value = nlv * steps / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline     : the fused sweep kernel's algorithmic bytes per launch (n_local*ld*8 + 16 n_local)
+                 / its average duration measured with HIP events on the ctx stream inside the timed region,
+                 against the 8 TB/s HBM3E peak;
+  cpu_baseline : the C oracle (a port of the reference's 2-dgemv schedule, oracle/plsr_oracle.c) timed on this
+                 host's cores on a bounded row sample (rank 0, N == 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "jchemo.jl_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+README_PLSKERN_LVS = 25 / 8.100469   # README.md:90-91: plskern n=1e6 p=500 q=10 nlv=25 in 8.10 s (i9-10885H)
+
+
+def cpu_baseline(n_total, p, q, nlv, sample_rows):
+    """C oracle (kind 'port': reference schedule, 2 X-sweeps per LV) on `sample_rows` rows; LV/s scaled to n_total."""
+    from oracle import c_oracle as CO
+    CO.build()
+    ns = int(min(sample_rows, n_total))
+    X = CO.fill_uniform(20250112, ns, p, 0, n_total)
+    Y = CO.fill_uniform(20250113, ns, q, 0, n_total)
+    t0 = time.perf_counter()
+    CO.plskern_(X, Y, None, nlv=nlv, scal=False)        # `plskern!` on the sample (in place, like README.md:93)
+    dt = time.perf_counter() - t0
+    scale = n_total / ns
+    return {"value": nlv / (dt * scale), "unit": "LV/s", "cores": int(CO.lib().orc_num_threads()), "kind": "port",
+            "sample": f"plskern! on the first {ns} of {n_total} rows (same p={p}, q={q}, nlv={nlv}); {dt:.2f} s measured, "
+                      f"time scaled x{scale:.2f} (memory-bound, linear in n)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--p", type=int, default=500)
+    ap.add_argument("--q", type=int, default=10)
+    ap.add_argument("--nlv", type=int, default=25)
+    ap.add_argument("--algo", choices=["plskern", "plsnipals"], default="plskern")
+    ap.add_argument("--cpu-sample-rows", type=int, default=250_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import jchemo_hip as J
+    from jchemo_hip import _lib
+    lib = J.load()
+    ctx = J.Context(local_rank, stream="torch")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        box = [J.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], rank, world)
+
+    n_total, p, q, nlv = args.n, args.p, args.q, args.nlv
+    row0 = (n_total * rank) // world
+    n = (n_total * (rank + 1)) // world - row0
+    # ---- synthetic inputs, generated in place on the device (column-major, Julia layout)
+    X = J.colmajor_empty(n, p, dev)
+    Y = J.colmajor_empty(n, q, dev)
+    ctx.check(lib.jch_fill_uniform(ctx._h, X.data_ptr(), n, p, n, row0, n_total, 20250112))
+    ctx.check(lib.jch_fill_uniform(ctx._h, Y.data_ptr(), n, q, n, row0, n_total, 20250113))
+    kmax = min(nlv, p, n_total)
+    T = J.colmajor_empty(n, kmax, dev)
+    wn = torch.empty(n, dtype=torch.float64, device=dev)
+    P = np.zeros((p, kmax), order="F"); R = np.zeros((p, kmax), order="F"); W = np.zeros((p, kmax), order="F")
+    Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
+    xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
+    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.F64, loc=_lib.LOC_DEVICE, inplace=0, reserved=0)
+    got = C.c_int32(0)
+    entry = lib.jch_plskern_fit if args.algo == "plskern" else lib.jch_plsnipals_fit
+
+    def step():
+        ctx.check(entry(ctx._h, C.byref(desc), X.data_ptr(), n, Y.data_ptr(), n, None, T.data_ptr(), P.ctypes.data,
+                        R.ctypes.data, W.ctypes.data, Cm.ctypes.data, TT.ctypes.data, xm.ctypes.data, xs.ctypes.data,
+                        ym.ctypes.data, ys.ctypes.data, wn.data_ptr(), C.byref(got)))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ctx.set_profiling(True)        # HIP events on the ctx stream around every sweep launch
+    for _ in range(args.warmup):
+        step()
+    sweep_ms = 0.0; sweep_launches = 0; fit_ms = 0.0; prologue_ms = 0.0; small_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        pr = ctx.profile()     # host-side read of already-recorded events (the fit call is blocking)
+        sweep_ms += pr.sweep_ms; sweep_launches += pr.sweep_launches; fit_ms += pr.fit_ms
+        prologue_ms += pr.prologue_ms; small_ms += pr.smallstate_ms
+        sweep_bytes = pr.sweep_bytes
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        k = got.value
+        value = k * args.steps / dt
+        avg_sweep_s = (sweep_ms / max(sweep_launches, 1)) * 1e-3
+        achieved = sweep_bytes / avg_sweep_s / 1e9 if avg_sweep_s > 0 else 0.0
+        kernel = "k_sweep (fused t = X r, tt, zp = X'Dt, T column store)" if args.algo == "plskern" else \
+            "k_sweep + k_deflate_xty (per LV)"
+        out = {
+            "metric": f"latent-variables/sec ({args.algo} n={n_total:.0e} p={p} q={q} nlv={nlv})".replace("e+0", "e"),
+            "value": value, "unit": "LV/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": value / README_PLSKERN_LVS if (args.algo == "plskern" and (n_total, p, q, nlv) == (1_000_000, 500, 10, 25)) else None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg2 (BASELINE.json configs[1]): {args.algo} n={n_total} p={p} q={q} nlv={nlv} Float64, "
+                                   f"X/Y device-resident column-major, rows sharded over {world} GPU(s)",
+                       "n": n_total, "p": p, "q": q, "nlv": k, "rows_per_gpu": n, "timed": "prologue + LV loop, device-resident"},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches},
+            "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
+                                   "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n_total, p, q, nlv, args.cpu_sample_rows)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "LV/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
