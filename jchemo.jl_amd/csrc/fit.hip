@@ -1,6 +1,8 @@
 // Fit orchestration: jch_plskern_fit / jch_plsnipals_fit (include/jchemo_hip.h).
 // Everything between the first and the last kernel of a fit is enqueued on ctx->stream with no host sync
 // (single GPU); a multi-GPU fit syncs once in the prologue to learn the global row count.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "jch_internal.h"
@@ -109,15 +111,17 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
     const size_t small_bytes = 256 * 16 + sizeof(double) * ((size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
-                                                         (size_t)nlv_cap * q + nlv_cap + 2 * ((size_t)ldr + 1 + qpad) + 2 * (size_t)(p + q) + 8);
+                                                         2 * (size_t)nlv_cap * q + 2 * nlv_cap + 128 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
     s.K = cv.take((size_t)p * qpad); s.w = cv.take(ldr); s.r = cv.take(ldr);
     s.P = cv.take((size_t)nlv_cap * p); s.R = cv.take((size_t)nlv_cap * p); s.W = cv.take((size_t)nlv_cap * p);
-    s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap);
-    s.zt = cv.take((size_t)ldr + 1 + qpad); s.zpc = cv.take((size_t)ldr + qpad);
+    s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap); s.Z = cv.take((size_t)nlv_cap * q);
+    const int ldz = (ldr + 1 + qpad + 7) & ~7;
+    s.zt = cv.take((size_t)JCH_ZT_SLICES * ldz); s.zpc = cv.take((size_t)ldr + qpad);
     s.mom = cv.take(p + q); s.scl = cv.take(p + q); s.hdr = cv.take(8);
+    s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(nlv_cap + 1) : nullptr;
 
     hipEvent_t ev_begin = jch_ev(ctx);
     // ---- K0 weights; global row count for the nlv clamp (src/plskern.jl:116-117)
@@ -130,32 +134,36 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         n_total = (int64_t)(hdr_h[1] + 0.5);
     }
     const int nlv = (int)std::min<int64_t>(std::min<int64_t>(n_total, p), d.nlv);
+    // small-state fast path (smallstate_fast.hip): everything in LDS, q <= 16
+    const bool fast = q <= 16 && nlv <= 1024 && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
+    const int max_slices = (fast && ctx->nranks == 1) ? JCH_ZT_SLICES : 1;
+    int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
     JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
     if (d.scal) JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl));
     else hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
-    JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && algo == 0, Xr, ldr, Yr, qpad, s.K));
+    JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && algo == 0, Xr, ldr, Yr, qpad, s.K, d.scal != 0));
     hipEvent_t ev_prologue = jch_ev(ctx);
 
     // ---- LV loop
     const size_t sweep_ev0 = ctx->ev_used;
-    JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, algo));
+    JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, algo, 1, ldz, fast));
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (algo == 0) {
-            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt));
+            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
             JCH_TRY(jch_allreduce_f64(ctx, s.zt, (size_t)ldr + 1));  // ONE collective per LV: [zp (p), tt]
-            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0));
+            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
         } else {
-            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt));
+            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
             JCH_TRY(jch_allreduce_f64(ctx, s.zt, (size_t)ldr + 1 + qpad));  // [zp_raw, tt, c_raw]
-            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1));
+            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast));
             const bool last = a + 1 == nlv;
             if (!last || inplace) {
                 // X -= t zp', Y -= t c' fused with the next K = X'DY (src/plsnipals.jl:86-87,71)
                 JCH_TRY(jch_launch_deflate(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, tcol, s.zpc, last ? nullptr : s.K));
             }
-            if (!last) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 1));
+            if (!last) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 1, 1, ldz, fast));
         }
     }
     if (algo == 1) JCH_TRY(jch_launch_nipals_R(ctx, s, p, nlv));
@@ -184,6 +192,13 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     }
     JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (io.nlv_out) *io.nlv_out = nlv;
+    if (s.dbg) {
+        std::vector<double> h(nlv + 1);
+        (void)hipMemcpy(h.data(), s.dbg, sizeof(double) * (nlv + 1), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[jch] jacobi sweeps per LV:");
+        for (int i = 0; i < nlv; ++i) fprintf(stderr, " %d", (int)h[i]);
+        fprintf(stderr, "\n");
+    }
 
     if (ctx->profiling) {
         jch_profile &pr = ctx->prof;

@@ -11,6 +11,7 @@
 #include "jchemo_hip.h"
 
 #define JCH_MAXQ 64       // Jacobi workspace bound (q x q in LDS)
+#define JCH_ZT_SLICES 8      // max second-stage partial slices of the sweep reduction
 #define JCH_SWEEP_MAXP 2048  // widest row the register-resident fused sweep holds (16 column chunks of 128)
 
 struct jch_buf {  // grow-only device buffer
@@ -83,13 +84,14 @@ int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const do
                            double *out /*[p+q] device*/, bool do_sqrt = true);
 int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d,
                               int64_t n, int p, int q, const double *mom, const double *scl, bool writeback,
-                              double *Xr, int ldr, double *Yr, int qpad, double *K /*[p][qpad] device*/);
+                              double *Xr, int ldr, double *Yr, int qpad, double *K /*[p][qpad] device*/, bool scal);
 int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n,
                                    int p, int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy);
 // sweep.hip
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra /*0: plskern; q: also c_raw (plsnipals)*/,
-                         double *tcol, double *zt /*[p+1+q_extra] device, reduced over blocks*/);
+                         double *tcol, double *zt /*[nslice][ldz] device, reduced over blocks*/, int ldz, int max_slices,
+                         int *nslice_out);
 int32_t jch_launch_deflate(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q,
                            const double *d, const double *tcol, const double *zpc /*[ldr + qpad]: zp then c*/,
                            double *Knext /*[p][qpad] or null*/);
@@ -100,13 +102,18 @@ struct jch_small {  // device-resident replicated small state of one fit
     double *P, *R, *W;  // [nlv][p]   (== Julia's p x nlv column-major)
     double *C;          // [nlv][q]
     double *TT;         // [nlv]
-    double *zt;         // [ldr + 1 + qpad]  reduced sweep output: zp, tt, (c_raw)
+    double *Z;          // [nlv][q]   Z = P'K of the finished LVs (fast small-state path)
+    double *zt;         // [JCH_ZT_SLICES][ldz]  reduced sweep output slices: zp, tt, (c_raw); ldz = ldr + 1 + qpad (+pad)
     double *zpc;        // [ldr + qpad]      plsnipals: zp/tt, c/tt
     double *mom, *scl;  // [p+q]
     double *hdr;        // [4]
+    double *dbg;        // [nlv + 1] diagnostics (JCH_LV_DEBUG): Jacobi sweeps per LV; may be null
 };
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a /*-1: init*/,
-                             int nlv, int algo /*0 plskern, 1 plsnipals*/);
+                             int nlv, int algo /*0 plskern, 1 plsnipals*/, int nslice, int ldz, bool fast);
+size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv);
+int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
+                                  int do_a, int do_b, int nslice, int ldz);
 int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv);
 // gemm.hip
 int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p, int64_t ldx, const double *Bs /*[p][kpad] scaled*/,

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void k_moments(const double *__restrict__ Xc, 
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int64_t i = i0 + threadIdx.x;
     for (; i + 768 < i1; i += 1024) {
-        double a0 = col[i], a1 = col[i + 256], a2 = col[i + 512], a3 = col[i + 768];
+        double a0 = __builtin_nontemporal_load(col + i), a1 = __builtin_nontemporal_load(col + i + 256),
+               a2 = __builtin_nontemporal_load(col + i + 512), a3 = __builtin_nontemporal_load(col + i + 768);
         double d0 = d[i], d1 = d[i + 256], d2 = d[i + 512], d3 = d[i + 768];
         if (VAR) { a0 -= m; a1 -= m; a2 -= m; a3 -= m; a0 *= a0; a1 *= a1; a2 *= a2; a3 *= a3; }
         s0 += d0 * a0; s1 += d1 * a1; s2 += d2 * a2; s3 += d3 * a3;
@@ -136,7 +137,7 @@ int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const do
 // WRITEBACK (plskern!/plsnipals! semantics) stores the centred X back into the caller's column-major
 // array; it is only legal when each X element is read by exactly one block (one y group).  Y is never
 // written here (every column tile re-reads the raw Y rows): the launcher exports Yr afterwards.
-template <bool WRITEBACK>
+template <bool WRITEBACK, bool SCAL>
 __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
                                                      int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                      const double *__restrict__ mom, const double *__restrict__ scl,
@@ -149,9 +150,27 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
     const int j0 = blockIdx.y * 64;
     const int yg = blockIdx.z;
     const int64_t nchunks = (n + 63) / 64;
-    // per-thread column constants for the load phase: columns (tid>>6) + 4k, k = 0..15
+    // per-thread column constants: this thread always handles columns j0 + wv + 4k of the X tile
+    double cm[16], cs[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = j0 + wv + 4 * k;
+        cm[k] = j < p ? mom[j] : 0.0;
+        cs[k] = (SCAL && j < p) ? scl[j] : 1.0;  // divisor, used only when scaling (cscale!: (x - u) / v)
+    }
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    // software pipeline: the global loads of chunk c+1 are in flight while chunk c is stored / multiplied
+    double xr[16];
+    int64_t c = blockIdx.x;
+    if (c < nchunks) {
+        const int64_t i = c * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = j0 + wv + 4 * k;
+            xr[k] = (i < n && j < p) ? __builtin_nontemporal_load(Xc + (size_t)i + (size_t)j * (size_t)ldx) : 0.0;
+        }
+    }
+    for (; c < nchunks; c += gridDim.x) {
         const int64_t i0 = c * 64;
         // ---- Y tile: 64 rows x 16 cols, element e = tid + 256k -> (row e&63, col e>>6)
 #pragma unroll
@@ -161,32 +180,47 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
             const int64_t i = i0 + row;
             double v = 0.0, dv = 0.0;
             if (i < n && yc < q) {
-                v = (Yc[(size_t)i + (size_t)yc * (size_t)ldy] - mom[p + yc]) / scl[p + yc];
+                v = Yc[(size_t)i + (size_t)yc * (size_t)ldy] - mom[p + yc];
+                if (SCAL) v /= scl[p + yc];
                 dv = d[i];
             }
             if (blockIdx.y == 0 && i < n) Yr[(size_t)i * qpad + yc] = v;
             yt[row * YT_LD + col] = dv * v;
         }
-        // ---- X tile: 64 rows x 64 cols, coalesced down the columns
-#pragma unroll 4
-        for (int k = 0; k < 16; ++k) {
-            const int col = wv + 4 * k, j = j0 + col;
+        // ---- X tile: centre/scale the prefetched registers into LDS (and back into the caller's array)
+        {
             const int64_t i = i0 + lane;
-            double v = 0.0;
-            if (i < n && j < p) {
-                v = (Xc[(size_t)i + (size_t)j * (size_t)ldx] - mom[j]) / scl[j];
-                if (WRITEBACK && yg == 0) Xc[(size_t)i + (size_t)j * (size_t)ldx] = v;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int j = j0 + wv + 4 * k;
+                double v = 0.0;
+                if (i < n && j < p) {
+                    v = SCAL ? (xr[k] - cm[k]) / cs[k] : xr[k] - cm[k];
+                    if (WRITEBACK && yg == 0) Xc[(size_t)i + (size_t)j * (size_t)ldx] = v;
+                }
+                xt[lane * XT_LD + wv + 4 * k] = v;
             }
-            xt[lane * XT_LD + col] = v;
         }
         __syncthreads();
-        // ---- row-major store (y group 0 only): element e -> (col e&63, row e>>6)
+        // ---- prefetch the next chunk
+        {
+            const int64_t cn = c + gridDim.x;
+            if (cn < nchunks) {
+                const int64_t i = cn * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int j = j0 + wv + 4 * k;
+                    xr[k] = (i < n && j < p) ? __builtin_nontemporal_load(Xc + (size_t)i + (size_t)j * (size_t)ldx) : 0.0;
+                }
+            }
+        }
+        // ---- row-major store (y group 0 only): (row wv+4k, col lane)
         if (yg == 0) {
 #pragma unroll 4
             for (int k = 0; k < 16; ++k) {
                 const int row = wv + 4 * k, j = j0 + lane;
                 const int64_t i = i0 + row;
-                if (i < n && j < ldr) Xr[(size_t)i * ldr + j] = xt[row * XT_LD + lane];
+                if (i < n && j < ldr) __builtin_nontemporal_store(xt[row * XT_LD + lane], Xr + (size_t)i * ldr + j);
             }
         }
         // ---- XtY on the matrix cores: wave wv owns columns j0+16wv .. +15
@@ -222,7 +256,7 @@ __global__ __launch_bounds__(256) void k_reduce_kpart(const double *__restrict__
 
 int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d, int64_t n,
                               int p, int q, const double *mom, const double *scl, bool writeback, double *Xr, int ldr,
-                              double *Yr, int qpad, double *K)
+                              double *Yr, int qpad, double *K, bool scal)
 {
     const int ptiles = (ldr + 63) / 64;
     const int kp_rows = ptiles * 64;
@@ -235,12 +269,13 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
     double *Kpart = (double *)ctx->kpart.ptr;
     dim3 grid(nbx, ptiles, ygroups);
     const bool wb_fused = writeback && ygroups == 1;
-    if (wb_fused)
-        hipLaunchKernelGGL(k_center_xty<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, mom, scl, Xr,
-                           ldr, Yr, qpad, Kpart, kp_rows);
-    else
-        hipLaunchKernelGGL(k_center_xty<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, mom, scl, Xr,
-                           ldr, Yr, qpad, Kpart, kp_rows);
+#define JCH_K2(WB, SC) hipLaunchKernelGGL((k_center_xty<WB, SC>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
+                                          mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows)
+    if (wb_fused && scal) JCH_K2(true, true);
+    else if (wb_fused) JCH_K2(true, false);
+    else if (scal) JCH_K2(false, true);
+    else JCH_K2(false, false);
+#undef JCH_K2
     hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad,
                        K);
     JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));

@@ -1,0 +1,473 @@
+// K3/K5 fast path — same math as smallstate.hip (phase A: src/plskern.jl:165-174 / src/plsnipals.jl:82-93;
+// phase B: src/plskern.jl:150-161 / src/plsnipals.jl:72-77), restructured for latency: this kernel sits on the
+// critical path between two sweeps, once per latent variable, so every dependent memory round trip counts.
+//   * every global load of the kernel is issued up front (K, zt slices, r, w, Z, and register prefetches of the
+//     P rows / R column this thread will need); K (p x q) then lives in LDS.
+//   * dominant eigenvector of the Gram matrix G = K'K by repeated squaring in one wave
+//     (A <- A^2 / tr(A)^2, ~10-14 wave-synchronous rounds of q FMAs; monitor 1 - tr(A^2)/tr(A)^2 -> 0), with the
+//     cyclic Jacobi solver as the fallback when the singular-value gap is below ~3e-5 (no convergence in 24
+//     squarings).  Eigenvector error is O(eps / gap) for both, the same as LAPACK's.
+//   * the r-recursion r = w - sum_i (w . P_i) R_i is evaluated as r = (K v - R (Z v)) / ||K v|| with
+//     Z = P'K (a x q) kept in the small state and updated incrementally per LV:
+//     Z_i <- Z_i - (P_i . zp) c' (i < a), Z_a = P_a' K_new — a dot products instead of a x q.
+//   * the sweep's second-stage partial slices zt[s][.] are summed here (saves a launch on one GPU).
+//   * no integer division in any loop (a runtime div/mod costs ~40 instructions on this ISA).
+// Used when q <= 16 and everything fits in LDS; otherwise jch_launch_lv_update falls back to k_lv_update.
+#include <stdlib.h>
+
+#include "jch_internal.h"
+
+#define FT 512
+
+struct lvf_args {
+    jch_small s;
+    int p, q, qpad, ldr, a, nlv, algo, do_a, do_b, nslice, ldz, skip;
+};
+
+__device__ __forceinline__ void wavesync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Rotation (c, s) annihilating apq.  The ANGLE only needs ~1e-8 accuracy (the off-diagonal then drops
+// quadratically), but c^2 + s^2 must equal 1 to rounding or V loses orthogonality: t from the hardware
+// reciprocal / rsqrt estimates (v_rcp_f64, v_rsq_f64: ~1e-8), c = rsqrt(1 + t^2) refined by one Newton step,
+// s = t c.  ~15 dependent f64 ops instead of ~70 for correctly rounded sqrt + 2 divisions + rsqrt.
+__device__ __forceinline__ void jacobi_rot(double app, double aqq, double apq, double &c, double &s)
+{
+    const double al = 0.5 * (aqq - app);
+    const double x = al * al + apq * apq;
+    const double h = x * __builtin_amdgcn_rsq(x);                       // sqrt(x), ~1e-8
+    const double t = apq * __builtin_amdgcn_rcp(al + (al >= 0.0 ? h : -h));
+    const double u = 1.0 + t * t;
+    double y = __builtin_amdgcn_rsq(u);
+    y = y * (1.5 - 0.5 * u * y * y);                                    // Newton: full double
+    y = y * (1.5 - 0.5 * u * y * y);
+    c = y;
+    s = t * y;
+}
+
+// One-wave parallel cyclic Jacobi on the symmetric q x q matrix A0 (q <= 16).  Writes the dominant eigenvector
+// (largest-|.| component positive) to vout[0..q).  Round-robin pairing: in round r, index x meets
+// m-1 <-> r, and otherwise (2r - x) mod (m-1); every lane derives its partners arithmetically.
+__device__ static void jacobi_wave(int q, int lda, double *A0, double *A1, double *V0, double *V1, double *csl,
+                                   double *vout, double *dbg)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = (q + 1) & ~1, qq = q * q, mm1 = m - 1;
+    int ie[4], je[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int e = lane + 64 * s;
+        ie[s] = e / q;
+        je[s] = e - ie[s] * q;
+        if (e < qq) V0[ie[s] * lda + je[s]] = (ie[s] == je[s]) ? 1.0 : 0.0;
+    }
+    wavesync();
+    // No integer division inside the rounds (a runtime modulo costs ~40 instructions on this ISA): every
+    // round-dependent index is advanced incrementally.  pa/pb: the pair owned by this lane in step 1;
+    // bi[s]/bj[s]: (2 round - i) mod (m-1), the generic partner of this lane's element row/column.
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool any_rot = false, any_big = false;
+        int pa = lane < mm1 ? lane : 0, pb = lane == 0 ? 0 : (lane < mm1 ? mm1 - lane : 0);   // round 0
+        int bi[4], bj[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bi[s] = (ie[s] == 0 || ie[s] >= mm1) ? 0 : mm1 - ie[s];
+            bj[s] = (je[s] == 0 || je[s] >= mm1) ? 0 : mm1 - je[s];
+        }
+        for (int round = 0; round < mm1; ++round) {
+            bool rot = false, big = false;
+            if (lane < m / 2) {
+                int a = lane == 0 ? mm1 : pa, b = lane == 0 ? round : pb;
+                if (a > b) { const int t = a; a = b; b = t; }
+                double c = 1.0, s = 0.0;
+                if (b < q) {
+                    const double app = A0[a * lda + a], aqq = A0[b * lda + b], apq = A0[a * lda + b];
+                    const double lim = fabs(app * aqq), b2 = apq * apq;
+                    if (b2 > 1e-300 && b2 > 1e-34 * lim) {
+                        jacobi_rot(app, aqq, apq, c, s);
+                        rot = true;
+                        big = b2 > 1e-16 * lim;
+                    }
+                    csl[2 * a] = c; csl[2 * a + 1] = s;
+                    csl[2 * b] = c; csl[2 * b + 1] = -s;
+                } else if (a < q) {
+                    csl[2 * a] = 1.0; csl[2 * a + 1] = 0.0;
+                }
+            }
+            any_rot |= __ballot(rot) != 0ull;
+            any_big |= __ballot(big) != 0ull;
+            wavesync();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (lane + 64 * s < qq) {
+                    const int i = ie[s], j = je[s];
+                    int ip = i == mm1 ? round : (i == round ? mm1 : bi[s]);
+                    int jp = j == mm1 ? round : (j == round ? mm1 : bj[s]);
+                    if (ip >= q) ip = i;   // bye (odd q): identity rotation recorded for i
+                    if (jp >= q) jp = j;
+                    const double ci = csl[2 * i], si = csl[2 * i + 1], cj = csl[2 * j], sj = csl[2 * j + 1];
+                    const double rij = ci * A0[i * lda + j] - si * A0[ip * lda + j];
+                    const double rijp = ci * A0[i * lda + jp] - si * A0[ip * lda + jp];
+                    A1[i * lda + j] = cj * rij - sj * rijp;
+                    V1[i * lda + j] = cj * V0[i * lda + j] - sj * V0[i * lda + jp];
+                }
+            }
+            wavesync();
+            double *t = A0; A0 = A1; A1 = t;
+            t = V0; V0 = V1; V1 = t;
+            // advance to round + 1:  (round + lane) mod (m-1), (round - lane) mod (m-1), (2 round - i) mod (m-1)
+            pa = pa + 1 >= mm1 ? pa + 1 - mm1 : pa + 1;
+            pb = pb + 1 >= mm1 ? pb + 1 - mm1 : pb + 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bi[s] = bi[s] + 2 >= mm1 ? bi[s] + 2 - mm1 : bi[s] + 2;
+                bj[s] = bj[s] + 2 >= mm1 ? bj[s] + 2 - mm1 : bj[s] + 2;
+            }
+        }
+        // quadratic convergence: once every rotation of a sweep is below 1e-8 (relative), the off-diagonal left
+        // behind is below 1e-16: done, no confirmation sweep needed.
+        if (lane == 0 && dbg) *dbg = sweep + 1;
+        if (!any_rot || !any_big) break;
+    }
+    if (lane == 0) {
+        int best = 0;
+        for (int k = 1; k < q; ++k)
+            if (A0[k * lda + k] > A0[best * lda + best]) best = k;
+        double bigv = 0.0;
+        for (int k = 0; k < q; ++k)
+            if (fabs(V0[k * lda + best]) > fabs(bigv)) bigv = V0[k * lda + best];
+        const double sg = bigv < 0.0 ? -1.0 : 1.0;
+        for (int k = 0; k < q; ++k) vout[k] = sg * V0[k * lda + best];
+    }
+}
+
+// Dominant eigenvector of the symmetric positive semi-definite q x q matrix G (LDS, preserved) by repeated
+// squaring, one wave.  Returns false (wave-uniform) if the monitor did not converge: the caller falls back to
+// Jacobi.  B0/B1: work buffers.
+__device__ static bool dominant_by_squaring(int q, int lda, const double *G, double *B0, double *B1, double *vout,
+                                            double *dbg)
+{
+    const int lane = threadIdx.x & 63;
+    const int nent = q * (q + 1) / 2;
+    int k1s[3], k2s[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        int e = lane + 64 * s, k1 = 0;
+        if (e < nent) {
+            while (e >= q - k1) { e -= q - k1; ++k1; }
+            k1s[s] = k1; k2s[s] = k1 + e;
+            const double v = G[k1 * lda + k1 + e];
+            B0[k1 * lda + k1 + e] = v;
+            B0[(k1 + e) * lda + k1] = v;
+        } else { k1s[s] = -1; k2s[s] = 0; }
+    }
+    wavesync();
+    double *A = B0, *Bn = B1;
+    int extra = -1, it = 0;
+    bool ok = false;
+    for (; it < 24; ++it) {
+        double t = 0.0;
+        for (int k = 0; k < q; ++k) t += A[k * lda + k];
+        // A = (previous A)^2 / tr(previous A)^2, so t = sum(lambda^2)/(sum lambda)^2 -> 1 as A -> rank one
+        if (it > 0 && extra < 0 && (1.0 - t) < 1e-12) extra = 1;   // then ONE more squaring: rho ~5e-13 -> ~1e-25
+        if (extra == 0) { ok = true; break; }
+        if (extra > 0) --extra;
+        const double isc = 1.0 / t, isc2 = isc * isc;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (k1s[s] >= 0) {
+                const double *ra = A + k1s[s] * lda, *rb = A + k2s[s] * lda;
+                double acc = 0.0;
+                for (int k = 0; k < q; ++k) acc += ra[k] * rb[k];
+                acc *= isc2;
+                Bn[k1s[s] * lda + k2s[s]] = acc;
+                Bn[k2s[s] * lda + k1s[s]] = acc;
+            }
+        }
+        wavesync();
+        double *tmp = A; A = Bn; Bn = tmp;
+    }
+    if (lane == 0 && dbg) *dbg = ok ? 100 + it : -1;
+    if (!ok) return false;
+    if (lane == 0) {
+        int best = 0;
+        for (int k = 1; k < q; ++k)
+            if (A[k * lda + k] > A[best * lda + best]) best = k;
+        double ss = 0.0, bigv = 0.0;
+        for (int k = 0; k < q; ++k) {
+            const double v = A[k * lda + best];
+            ss += v * v;
+            if (fabs(v) > fabs(bigv)) bigv = v;
+        }
+        const double sc = (bigv < 0.0 ? -1.0 : 1.0) / sqrt(ss);
+        for (int k = 0; k < q; ++k) vout[k] = sc * A[k * lda + best];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int p = g.p, q = g.q, qpad = g.qpad, ldr = g.ldr, a = g.a, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int ldk = q | 1, lda = q + 1;
+    double *Kl = lds;                              // [p][ldk]
+    double *ztl = Kl + (size_t)p * ldk;            // [ldr + 1 + qpad]
+    double *rl = ztl + (ldr + 1 + qpad + 1);       // [ldr]
+    double *wl = rl + ldr;                         // [ldr]
+    double *scratch = wl + ldr;                    // [2 FT]
+    double *cl = scratch + 2 * FT;                 // [64]
+    double *vl = cl + 64;                          // [64]
+    double *ul = vl + 64;                          // [nlv]   u = Z v ; phase A: s_i = P_i . zp
+    double *Zl = ul + g.nlv;                       // [nlv][q]
+    double *G0 = Zl + (size_t)g.nlv * q, *A0 = G0 + q * lda, *A1 = A0 + q * lda, *V0 = A1 + q * lda, *V1 = V0 + q * lda;
+    double *csl = V1 + q * lda;                    // [2 (q + 2)]
+    double *K = g.s.K;
+    const bool needK = g.do_b || g.algo == 0;
+    const int a_old = a;                                  // LVs whose P/R/Z rows are in global memory at entry
+    const int anext = g.do_a ? a + 1 : a;                 // LVs finished once phase A is done
+    const bool rec = g.algo == 0 && anext > 0;            // r-recursion state in use (src/plskern.jl:156-161)
+    const bool recA = rec && g.do_a && a_old > 0;         // phase A has old Z rows to update
+
+    // ---- issue EVERY global load of this kernel up front: one memory latency instead of one per phase
+    double rreg[32];   // R[i][tid], i < min(a_old, 32)                         (phase B tail)
+    double preg[4][8]; // P[wv + 8 v][lane + 64 c]                              (phase A: s_i = P_i . zp)
+    if (rec && g.do_b) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) rreg[i] = (i < a_old && tid < p) ? g.s.R[(size_t)i * p + tid] : 0.0;
+    }
+    if (recA) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = wv + (FT / 64) * v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int j = lane + 64 * c;
+                preg[v][c] = (i < a_old && j < p) ? g.s.P[(size_t)i * p + j] : 0.0;
+            }
+        }
+    }
+    if (needK) {   // 16 lanes per row segment; no integer division
+        const int k = tid & 15;
+        for (int kg = 0; kg < qpad; kg += 16)
+            if (kg + k < q)
+                for (int j = tid >> 4; j < p; j += FT / 16) Kl[j * ldk + kg + k] = K[(size_t)j * qpad + kg + k];
+    }
+    if (rec)
+        for (int e = tid; e < a_old * q; e += FT) Zl[e] = g.s.Z[e];
+    if (g.do_a) {
+        const int mz = ldr + 1 + (g.algo == 1 ? qpad : 0);
+        for (int c = tid; c < mz; c += FT) {
+            double s = 0.0;
+            for (int sl = 0; sl < g.nslice; ++sl) s += g.s.zt[(size_t)sl * g.ldz + c];
+            ztl[c] = s;
+        }
+        for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ phase A
+    if (g.do_a) {
+        const double tt = ztl[ldr];
+        if (g.algo == 0) {
+            {   // c = K' r / tt : partials over 32 row groups
+                const int k = tid & 15, gr = tid >> 4;
+                double s = 0.0;
+                if (k < q)
+                    for (int j = gr; j < p; j += FT / 16) s += Kl[j * ldk + k] * rl[j];
+                scratch[gr * 16 + k] = s;
+            }
+            if (recA) {   // s_i = P_i . zp for the finished LVs (wave per vector)
+                for (int v = 0; wv + (FT / 64) * v < a_old; ++v) {
+                    const int i = wv + (FT / 64) * v;
+                    double s = 0.0;
+                    if (v < 4) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const int j = lane + 64 * c;
+                            double pij = 0.0;
+#pragma unroll
+                            for (int vv = 0; vv < 4; ++vv)
+                                if (vv == v) pij = preg[vv][c];
+                            if (j < p) s += pij * ztl[j];
+                        }
+                    }
+                    for (int j = lane + (v < 4 ? 512 : 0); j < p; j += 64) s += g.s.P[(size_t)i * p + j] * ztl[j];
+                    s = jch_wave_sum(s);
+                    if (lane == 0) ul[i] = s;
+                }
+            }
+            __syncthreads();
+            if (tid < q) {
+                double t = 0.0;
+                for (int gg = 0; gg < FT / 16; ++gg) t += scratch[gg * 16 + tid];
+                t /= tt;
+                cl[tid] = t;
+                g.s.C[(size_t)a * q + tid] = t;
+            }
+            __syncthreads();
+            for (int j = tid; j < p; j += FT) {   // K <- K - zp c'  (LDS + global copy); P_a, W_a, R_a
+                const double zp = ztl[j];
+                for (int k = 0; k < q; ++k) {
+                    const double v = Kl[j * ldk + k] - zp * cl[k];
+                    Kl[j * ldk + k] = v;
+                    K[(size_t)j * qpad + k] = v;
+                }
+                g.s.P[(size_t)a * p + j] = zp / tt;
+                g.s.W[(size_t)a * p + j] = wl[j];
+                g.s.R[(size_t)a * p + j] = rl[j];
+            }
+            if (recA)     // Z_i <- Z_i - (P_i . zp) c'
+                for (int i = wv; i < a_old; i += FT / 64)
+                    if (lane < q) Zl[i * q + lane] -= ul[i] * cl[lane];
+            __syncthreads();
+            if (g.do_b) {   // new row Z_a = P_a' K_new = (zp' K_new) / tt
+                const int k = tid & 15, gr = tid >> 4;
+                double s = 0.0;
+                if (k < q)
+                    for (int j = gr; j < p; j += FT / 16) s += Kl[j * ldk + k] * ztl[j];
+                scratch[FT + gr * 16 + k] = s;    // second half of scratch: the Gram pass below uses the first
+            }
+        } else {
+            for (int j = tid; j < ldr; j += FT) {
+                const double z = j < p ? ztl[j] / tt : 0.0;
+                g.s.zpc[j] = z;
+                if (j < p) {
+                    g.s.P[(size_t)a * p + j] = z;
+                    g.s.W[(size_t)a * p + j] = wl[j];
+                }
+            }
+            for (int k = tid; k < qpad; k += FT) {
+                const double c = k < q ? ztl[ldr + 1 + k] / tt : 0.0;
+                g.s.zpc[ldr + k] = c;
+                if (k < q) g.s.C[(size_t)a * q + k] = c;
+            }
+        }
+        if (tid == 0) g.s.TT[a] = tt;
+    }
+    if (!g.do_b) return;
+
+    // ------------------------------------------------------------------ phase B
+    if (q > 1) {
+        // Gram G = K'K: upper entries e -> (k1, k2), rows split over FT/64 groups
+        const int nent = q * (q + 1) / 2;
+        const int el = tid & 63, gr = tid >> 6;
+        for (int e0 = 0; e0 < nent; e0 += 64) {
+            int e = e0 + el, k1 = 0;
+            double s = 0.0;
+            const bool act = e < nent;
+            if (act) {
+                while (e >= q - k1) { e -= q - k1; ++k1; }
+                const int k2 = k1 + e;
+                for (int j = gr; j < p; j += FT / 64) s += Kl[j * ldk + k1] * Kl[j * ldk + k2];
+            }
+            scratch[gr * 64 + el] = s;
+            __syncthreads();
+            if (act && gr == 0) {
+                double t = 0.0;
+                for (int gg = 0; gg < FT / 64; ++gg) t += scratch[gg * 64 + el];
+                const int k2 = k1 + e;
+                G0[k1 * lda + k2] = t;
+                G0[k2 * lda + k1] = t;
+            }
+            __syncthreads();
+        }
+    } else {
+        if (tid == 0) vl[0] = 1.0;
+        __syncthreads();
+    }
+    if (rec && g.do_a && tid < q) {   // finish Z_a (its partials were written before the Gram barriers)
+        double t = 0.0;
+        for (int gg = 0; gg < FT / 16; ++gg) t += scratch[FT + gg * 16 + tid];
+        Zl[a * q + tid] = t / ztl[ldr];
+    }
+    if (q > 1 && wv == 0) {
+        if (!dominant_by_squaring(q, lda, G0, A0, A1, vl, g.s.dbg ? g.s.dbg + anext : nullptr)) {
+            for (int e = lane; e < q * lda; e += 64) A0[e] = G0[e];
+            wavesync();
+            jacobi_wave(q, lda, A0, A1, V0, V1, csl, vl, g.s.dbg ? g.s.dbg + anext : nullptr);
+        }
+    }
+    __syncthreads();
+    if (rec) {
+        if (tid < anext) {   // u = Z v
+            double u = 0.0;
+            for (int k = 0; k < q; ++k) u += Zl[tid * q + k] * vl[k];
+            ul[tid] = u;
+        }
+        for (int e = tid; e < anext * q; e += FT) g.s.Z[e] = Zl[e];
+    }
+    // w_raw = K v ; ||w_raw||
+    double wr[JCH_SWEEP_MAXP / FT];
+    double ssq = 0.0;
+#pragma unroll
+    for (int it = 0; it < JCH_SWEEP_MAXP / FT; ++it) {
+        const int j = tid + it * FT;
+        double wv_ = 0.0;
+        if (j < p)
+            for (int k = 0; k < q; ++k) wv_ += Kl[j * ldk + k] * vl[k];
+        wr[it] = wv_;
+        ssq += wv_ * wv_;
+    }
+    const double inv = 1.0 / sqrt(jch_block_sum<FT>(ssq, scratch));   // (its barriers also publish ul)
+    // w = w_raw / ||.|| ;  r = (w_raw - R (Z v)) / ||.||   ==  w - sum_i (w . P_i) R_i
+#pragma unroll
+    for (int it = 0; it < JCH_SWEEP_MAXP / FT; ++it) {
+        const int j = tid + it * FT;
+        if (j < ldr) {
+            double wn = 0.0, rn = 0.0;
+            if (j < p) {
+                wn = wr[it] * inv;
+                rn = wr[it];
+                if (rec) {
+                    double r0 = 0.0, r1 = 0.0;
+                    int i0 = 0;
+                    if (it == 0) {
+#pragma unroll
+                        for (int i = 0; i < 32; i += 2) {
+                            if (i < a_old) r0 += rreg[i] * ul[i];
+                            if (i + 1 < a_old) r1 += rreg[i + 1] * ul[i + 1];
+                        }
+                        i0 = a_old < 32 ? a_old : 32;
+                    }
+                    for (int i = i0; i < a_old; ++i) r0 += g.s.R[(size_t)i * p + j] * ul[i];
+                    if (g.do_a) r1 += rl[j] * ul[a];     // R_a = r of the LV just finished (still in LDS)
+                    rn -= r0 + r1;
+                }
+                rn *= inv;
+            }
+            g.s.w[j] = wn;
+            g.s.r[j] = rn;
+        }
+    }
+}
+
+size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv)
+{
+    const int ldk = q | 1, lda = q + 1;
+    return sizeof(double) * ((size_t)p * ldk + (ldr + 2 + qpad) + 2 * (size_t)ldr + 2 * FT + 64 + 64 + nlv + (size_t)nlv * q +
+                             5 * (size_t)q * lda + 2 * (q + 2) + 8);
+}
+
+int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
+                                  int do_a, int do_b, int nslice, int ldz)
+{
+    lvf_args g;
+    g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.a = a; g.nlv = nlv; g.algo = algo;
+    g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz;
+    static int skip = -1;
+    if (skip < 0) { const char *e = getenv("JCH_LV_SKIP"); skip = e ? atoi(e) : 0; }
+    g.skip = skip;
+    const size_t lds = jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv);
+    static bool attr_set = false;
+    if (!attr_set) {
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_lv_update_fast, dim3(1), dim3(FT), lds, ctx->stream, g);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}

@@ -13,18 +13,22 @@
 // a fixed order by k_reduce_part: bit-reproducible run to run (no float atomics).
 //
 // Bound: HBM.  Algorithmic bytes per launch = n*ldr*8 (X) + 16 n (weights read + T column write).
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "jch_internal.h"
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
-template <int KC, int R, bool NIPALS>
+template <int KC, int R, bool NIPALS, bool NT>
 __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, int64_t n, int ldr,
                                                const double *__restrict__ dw, const double *__restrict__ rvec,
                                                const double *__restrict__ Yr, int qpad, double *__restrict__ tcol,
                                                double *__restrict__ part, int ldpart)
 {
-    extern __shared__ __attribute__((aligned(16))) double red[];  // [4][KC*128] + [4] tt + [4][64] c
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [nw][KC*128] + [16] tt + [nw][64] c
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     v2f64 rf[KC], zp[KC];
     bool in[KC];
 #pragma unroll
@@ -36,8 +40,8 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
     }
     double tt = 0.0, cacc = 0.0;
     const int64_t ngroups = (n + R - 1) / R;
-    const int64_t gstride = (int64_t)gridDim.x * 4;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wv; g < ngroups; g += gstride) {
+    const int64_t gstride = (int64_t)gridDim.x * nw;
+    for (int64_t g = (int64_t)blockIdx.x * nw + wv; g < ngroups; g += gstride) {
         const int64_t row0 = g * R;
         v2f64 x[R][KC];
 #pragma unroll
@@ -45,7 +49,8 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
             const bool live = row0 + rr < n;  // wave-uniform
             const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xr + (size_t)(row0 + rr) * (size_t)ldr) + lane;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) x[rr][k] = (live && in[k]) ? rp[64 * k] : v2f64{0.0, 0.0};
+            for (int k = 0; k < KC; ++k)
+                x[rr][k] = (live && in[k]) ? (NT ? __builtin_nontemporal_load(rp + 64 * k) : rp[64 * k]) : v2f64{0.0, 0.0};
         }
         double tsel = 0.0;
 #pragma unroll
@@ -70,10 +75,10 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
         }
         if (lane < R && row0 + lane < n) tcol[row0 + lane] = tsel;
     }
-    // ---- combine the 4 waves of the block in wave order, then one partial row per block
-    double *zred = red;                    // [4][KC*128]
-    double *tred = red + 4 * KC * 128;     // [4]
-    double *cred = tred + 4;               // [4][64]
+    // ---- combine the waves of the block in wave order, then one partial row per block
+    double *zred = red;                     // [nw][KC*128]
+    double *tred = red + nw * KC * 128;     // [16]
+    double *cred = tred + 16;               // [nw][64]
 #pragma unroll
     for (int k = 0; k < KC; ++k)
         *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * k) = zp[k];
@@ -81,45 +86,76 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
     if (NIPALS) cred[wv * 64 + lane] = cacc;
     __syncthreads();
     double *prow = part + (size_t)blockIdx.x * ldpart;
-    for (int c = threadIdx.x; c < ldr; c += 256)
-        prow[c] = ((zred[c] + zred[KC * 128 + c]) + zred[2 * KC * 128 + c]) + zred[3 * KC * 128 + c];
-    if (threadIdx.x == 0) prow[ldr] = ((tred[0] + tred[1]) + tred[2]) + tred[3];
-    if (NIPALS && threadIdx.x < qpad)
-        prow[ldr + 1 + threadIdx.x] =
-            ((cred[threadIdx.x] + cred[64 + threadIdx.x]) + cred[128 + threadIdx.x]) + cred[192 + threadIdx.x];
+    for (int c = threadIdx.x; c < ldr; c += blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += zred[w * (KC * 128) + c];
+        prow[c] = s;
+    }
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += tred[w];
+        prow[ldr] = s;
+    }
+    if (NIPALS && threadIdx.x < qpad) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += cred[w * 64 + threadIdx.x];
+        prow[ldr + 1 + threadIdx.x] = s;
+    }
 }
 
-// zt[c] = sum over blocks of part[b][c], fixed order: 4 interleaved streams per column, then combined.
-__global__ __launch_bounds__(256) void k_reduce_part(const double *__restrict__ part, int nb, int ldpart, int m,
-                                                     double *__restrict__ zt)
+// Stage 1: slice s (blockIdx.y) sums its contiguous range of per-block partial rows -> zt[s][c].  Fixed order:
+// 16 interleaved row streams per column (threadIdx.x >> 6), combined in stream order.
+__global__ __launch_bounds__(1024) void k_reduce_part(const double *__restrict__ part, int nb, int ldpart, int m, int nslice,
+                                                      double *__restrict__ zt, int ldz)
 {
-    __shared__ double sc[4][64];
+    __shared__ double sc[16][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    const int per = (nb + nslice - 1) / nslice;
+    const int b0 = blockIdx.y * per, b1 = min(nb, b0 + per);
     double s = 0.0;
     if (c < m)
-        for (int b = g; b < nb; b += 4) s += part[(size_t)b * ldpart + c];
+        for (int b = b0 + g; b < b1; b += 16) s += part[(size_t)b * ldpart + c];
     sc[g][cl] = s;
     __syncthreads();
-    if (g == 0 && c < m) zt[c] = ((sc[0][cl] + sc[1][cl]) + sc[2][cl]) + sc[3][cl];
+    if (g == 0 && c < m) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sc[k][cl];
+        zt[(size_t)blockIdx.y * ldz + c] = t;
+    }
 }
 
-template <int KC, int R>
+// Stage 2 (only when the consumer wants a single vector: multi-GPU all-reduce, generic small-state kernel).
+__global__ __launch_bounds__(256) void k_reduce_slices(double *__restrict__ zt, int ldz, int m, int nslice)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= m) return;
+    double s = 0.0;
+    for (int sl = 0; sl < nslice; ++sl) s += zt[(size_t)sl * ldz + c];
+    zt[c] = s;
+}
+
+template <int KC, int R, bool NT = true>
 static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
-                              const double *Yr, int qpad, bool nipals, double *tcol, double *zt, int m)
+                              const double *Yr, int qpad, bool nipals, double *tcol, double *zt, int ldz, int max_slices,
+                              int *nslice_out, int m)
 {
     const int64_t ngroups = (n + R - 1) / R;
-    const size_t lds = sizeof(double) * (4 * KC * 128 + 4 + 256);
-    // persistent-style grid: exactly the blocks the CUs can hold (register/LDS-limited), rows interleaved
-    static int occ[2] = {0, 0};
-    if (occ[nipals] == 0) {
+    // persistent-style grid: exactly the 256-thread blocks the CUs can hold (register-limited: 146 VGPRs -> 3
+    // per CU at KC = 4); rows are interleaved over all waves of the grid.  (One 768-thread block per CU was tried:
+    // __launch_bounds__(1024) caps the kernel at 128 VGPRs and the sweep ran 1.55x slower.)
+    static int bpc_cache[2] = {0, 0};
+    const size_t lds = sizeof(double) * (4 * KC * 128 + 16 + 256);
+    if (bpc_cache[nipals] == 0) {
         int nblk = 0;
-        hipError_t e = nipals ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, true>, 256, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, false>, 256, lds);
-        occ[nipals] = (e == hipSuccess && nblk > 0) ? nblk : 2;
+        hipError_t e = nipals ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, true, NT>, 256, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, false, NT>, 256, lds);
+        bpc_cache[nipals] = (e == hipSuccess && nblk > 0) ? nblk : 2;
     }
-    int bpc = ctx->sweep_blocks_per_cu > 0 ? ctx->sweep_blocks_per_cu : occ[nipals];
-    int64_t nb64 = (ngroups + 3) / 4;
+    const int bpc = ctx->sweep_blocks_per_cu > 0 ? ctx->sweep_blocks_per_cu : bpc_cache[nipals];
+    const int wpb = 4;
+    int64_t nb64 = (ngroups + wpb - 1) / wpb;
     if (nb64 > (int64_t)ctx->cus * bpc) nb64 = (int64_t)ctx->cus * bpc;
     if (nb64 < 1) nb64 = 1;
     const int nb = (int)nb64;
@@ -128,27 +164,48 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     double *part = (double *)ctx->part.ptr;
     (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
     if (nipals)
-        hipLaunchKernelGGL((k_sweep<KC, R, true>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
+        hipLaunchKernelGGL((k_sweep<KC, R, true, NT>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
                            tcol, part, ldpart);
     else
-        hipLaunchKernelGGL((k_sweep<KC, R, false>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
+        hipLaunchKernelGGL((k_sweep<KC, R, false, NT>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
                            tcol, part, ldpart);
     (void)jch_ev(ctx);  // (end)
-    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64), dim3(256), 0, ctx->stream, part, nb, ldpart, m, zt);
+    int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
+    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, nslice), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
+    if (max_slices == 1 && nslice > 1) {  // consumer wants one vector (all-reduce / generic small-state kernel)
+        hipLaunchKernelGGL(k_reduce_slices, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, zt, ldz, m, nslice);
+        nslice = 1;
+    }
+    *nslice_out = nslice;
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }
 
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
-                         const double *Yr, int qpad, int q_extra, double *tcol, double *zt)
+                         const double *Yr, int qpad, int q_extra, double *tcol, double *zt, int ldz, int max_slices,
+                         int *nslice_out)
 {
     (void)p;
     const bool nip = q_extra > 0;
     const int m = ldr + 1 + (nip ? qpad : 0);
-    if (ldr <= 128) return launch_sweep_t<1, 4>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, m);
-    if (ldr <= 256) return launch_sweep_t<2, 4>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, m);
-    if (ldr <= 512) return launch_sweep_t<4, 4>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, m);
-    if (ldr <= 1024) return launch_sweep_t<8, 2>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, m);
-    if (ldr <= 2048) return launch_sweep_t<16, 1>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, m);
+#define JCH_SWEEP_CASE(KC, R) return launch_sweep_t<KC, R>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m)
+    if (ldr <= 128) JCH_SWEEP_CASE(1, 4);
+    if (ldr <= 256) JCH_SWEEP_CASE(2, 4);
+    if (ldr <= 512) {   // tuning knobs for the headline shape (defaults chosen from measurements)
+        static int rsel = -1, ntsel = -1;
+        if (rsel < 0) { const char *e = getenv("JCH_SWEEP_R"); rsel = e ? atoi(e) : 4; }
+        if (ntsel < 0) { const char *e = getenv("JCH_SWEEP_NT"); ntsel = e ? atoi(e) : 1; }
+#define JCH_SWEEP_CASE_NT(KC, R, NT) return launch_sweep_t<KC, R, NT>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m)
+        if (rsel == 2 && !ntsel) JCH_SWEEP_CASE_NT(4, 2, false);
+        if (rsel == 2 && ntsel) JCH_SWEEP_CASE_NT(4, 2, true);
+        if (rsel == 8 && !ntsel) JCH_SWEEP_CASE_NT(4, 8, false);
+        if (rsel == 8 && ntsel) JCH_SWEEP_CASE_NT(4, 8, true);
+        if (!ntsel) JCH_SWEEP_CASE_NT(4, 4, false);
+        JCH_SWEEP_CASE(4, 4);
+#undef JCH_SWEEP_CASE_NT
+    }
+    if (ldr <= 1024) JCH_SWEEP_CASE(8, 2);
+    if (ldr <= 2048) JCH_SWEEP_CASE(16, 1);
+#undef JCH_SWEEP_CASE
     return jch_fail(ctx, JCH_EINVAL, "fused sweep supports p <= %d (got ld %d)", JCH_SWEEP_MAXP, ldr);
 }
