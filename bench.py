@@ -37,6 +37,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 T
 README_PLSKERN_LVS = 25 / 8.100469   # README.md:90-91: plskern n=1e6 p=500 q=10 nlv=25 in 8.10 s (i9-10885H)
 
 
+def pmc_traffic(algo, n_local, p):
+    """HBM bytes per sweep launch from the committed PMC pass (profiles/r01_pmc_sweep.json: FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, separate passes), scaled by rows when this rank holds a different share."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_sweep.json")) as f:
+            pm = json.load(f)
+        w = pm["workload"]
+        if algo == w["algo"] and p == w["p"]:
+            return pm["hbm_bytes_per_launch"] * (n_local / w["n"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(n_total, p, q, nlv, sample_rows):
     """C oracle (kind 'port': reference schedule, 2 X-sweeps per LV) on `sample_rows` rows; LV/s scaled to n_total."""
     from oracle import c_oracle as CO
@@ -153,7 +167,7 @@ def main():
                                    f"X/Y device-resident column-major, rows sharded over {world} GPU(s)",
                        "n": n_total, "p": p, "q": q, "nlv": k, "rows_per_gpu": n, "timed": "prologue + LV loop, device-resident"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.algo, n, p),
                          "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches},
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
                                    "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps},

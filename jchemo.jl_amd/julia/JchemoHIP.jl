@@ -1,0 +1,182 @@
+"""
+    JchemoHIP
+
+Julia host side of the MI355X-native PLS engine: the same call shapes as Jchemo.jl
+(`plskern`, `plskern!`, `plsnipals`, `plsnipals!`, `transform`, `coef`, `predict`, `summary` and a
+result with the fields of `Jchemo.Plsr`, src/plskern.jl:1-14 of the reference), implemented as thin
+`ccall`s into `libjchemo_hip.so` (C ABI: include/jchemo_hip.h).  AMDGPU.jl is used only as a handle
+for device buffers (`ROCArray`); there is no CUDA path and no CPU fallback.
+
+NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia toolchain (see DESIGN.md).  Every
+behaviour below is exercised through the identical C entry points by the ctypes mirror in
+`jchemo.jl_amd/jchemo_hip/` (tests/test_gpu_parity.py).
+"""
+module JchemoHIP
+
+using LinearAlgebra
+
+export Plsr, plskern, plskern!, plsnipals, plsnipals!, transform, coef, predict, summary_plsr, JchCtx
+
+const LIB = get(ENV, "JCHEMO_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libjchemo_hip.so"))
+
+# ---- status / context ---------------------------------------------------------------------------
+mutable struct JchCtx
+    h::Ptr{Cvoid}
+    function JchCtx(device::Integer = 0; stream::Ptr{Cvoid} = C_NULL)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:jch_ctx_create, LIB), Int32, (Ref{Ptr{Cvoid}}, Int32, Ptr{Cvoid}, UInt32), r, device, stream, 0)
+        st == 0 || error("jch_ctx_create: ", unsafe_string(ccall((:jch_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+        ctx = new(r[])
+        finalizer(c -> ccall((:jch_ctx_destroy, LIB), Int32, (Ptr{Cvoid},), c.h), ctx)
+        ctx
+    end
+end
+
+check(ctx::JchCtx, st::Integer) =
+    st == 0 || error("libjchemo_hip error $st: ", unsafe_string(ccall((:jch_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx.h)))
+
+const _default = Ref{Union{Nothing, JchCtx}}(nothing)
+default_ctx() = (_default[] === nothing && (_default[] = JchCtx(0)); _default[])
+
+"Join this process' context to a row-sharded multi-GPU fit (one Julia process per GPU; `uid` from rank 0's
+`unique_id()`, exchanged with MPI.jl / Distributed)."
+unique_id() = (b = zeros(UInt8, 128); ccall((:jch_comm_unique_id, LIB), Int32, (Ptr{UInt8},), b) == 0 || error("rccl"); b)
+comm_init!(ctx::JchCtx, uid::Vector{UInt8}, rank::Integer, nranks::Integer) =
+    check(ctx, ccall((:jch_ctx_comm_init, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), ctx.h, uid, rank, nranks))
+
+# ---- result record: same field names / shapes as Jchemo.Plsr (src/plskern.jl:1-14) -----------------
+struct Plsr{TT_, WT}
+    T::TT_                      # n x nlv   (Matrix{Float64}, or ROCArray for device-resident fits)
+    P::Matrix{Float64}
+    R::Matrix{Float64}
+    W::Matrix{Float64}
+    C::Matrix{Float64}
+    TT::Vector{Float64}
+    xmeans::Vector{Float64}
+    xscales::Vector{Float64}
+    ymeans::Vector{Float64}
+    yscales::Vector{Float64}
+    weights::WT
+    niter::Union{Array{Float64}, Nothing}
+end
+
+struct PlsDesc
+    n::Int64; p::Int64; q::Int64
+    nlv::Int32; scal::Int32; dtype::Int32; loc::Int32; inplace::Int32; reserved::Int32
+end
+
+ensure_mat(X::AbstractMatrix) = X                       # src/utility.jl:544-548
+ensure_mat(X::AbstractVector) = reshape(X, :, 1)
+ensure_mat(X::Number) = reshape([X], 1, 1)
+
+# Host arrays: loc = 0.  Device arrays (AMDGPU.ROCArray{Float64,2}): loc = 1; `pointer(A)` is the device address.
+_loc(::Array) = Int32(0)
+_loc(A) = Int32(1)                                      # any other strided column-major device array type
+_similar(A::Array, dims...) = Array{Float64}(undef, dims...)
+_similar(A, dims...) = similar(A, Float64, dims...)
+
+function _fit(sym::Symbol, X, Y, weights, nlv, scal, inplace, ctx::JchCtx)
+    n, p = size(X); q = size(Y, 2)
+    size(Y, 1) == n || throw(DimensionMismatch("X has $n rows, Y has $(size(Y, 1))"))
+    kmax = max(1, min(p, nlv))
+    T = _similar(X, n, kmax); wn = _similar(X, n)
+    P = zeros(p, kmax); R = zeros(p, kmax); W = zeros(p, kmax); C = zeros(q, kmax); TT = zeros(kmax)
+    xm = zeros(p); xs = zeros(p); ym = zeros(q); ys = zeros(q)
+    desc = Ref(PlsDesc(n, p, q, nlv, scal ? 1 : 0, 0, _loc(X), inplace ? 1 : 0, 0))
+    got = Ref{Int32}(0)
+    w = weights === nothing ? C_NULL : pointer(weights)
+    GC.@preserve X Y weights T wn begin
+        st = if sym === :plskern
+            ccall((:jch_plskern_fit, LIB), Int32,
+                  (Ptr{Cvoid}, Ref{PlsDesc}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64},
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+                  ctx.h, desc, pointer(X), stride(X, 2), pointer(Y), max(stride(Y, 2), n), w, pointer(T),
+                  P, R, W, C, TT, xm, xs, ym, ys, pointer(wn), got)
+        else
+            ccall((:jch_plsnipals_fit, LIB), Int32,
+                  (Ptr{Cvoid}, Ref{PlsDesc}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64},
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+                  ctx.h, desc, pointer(X), stride(X, 2), pointer(Y), max(stride(Y, 2), n), w, pointer(T),
+                  P, R, W, C, TT, xm, xs, ym, ys, pointer(wn), got)
+        end
+        check(ctx, st)
+    end
+    k = Int(got[])
+    Plsr(T[:, 1:k], P[:, 1:k], R[:, 1:k], W[:, 1:k], C[:, 1:k], TT[1:k], xm, xs, ym, ys, wn, nothing)
+end
+
+_w(weights, X) = weights === nothing ? nothing : convert(typeof(_similar(X, 0)), vec(Float64.(weights)))
+
+"`plskern(X, Y, weights = ones(n); nlv, scal = false)` — src/plskern.jl:106-110 (inputs untouched)."
+plskern(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plskern, ensure_mat(X), ensure_mat(Y), _w(weights, ensure_mat(X)), nlv, scal, false, ctx)
+"`plskern!(X::Matrix, Y::Matrix, ...)` — src/plskern.jl:112-178: X, Y are overwritten (centred/scaled)."
+plskern!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plskern, X, Y, _w(weights, X), nlv, scal, true, ctx)
+"`plsnipals` — src/plsnipals.jl:31-35."
+plsnipals(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plsnipals, ensure_mat(X), ensure_mat(Y), _w(weights, ensure_mat(X)), nlv, scal, false, ctx)
+"`plsnipals!` — src/plsnipals.jl:37-97: X, Y end up centred/scaled and deflated."
+plsnipals!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plsnipals, X, Y, _w(weights, X), nlv, scal, true, ctx)
+
+function _affine(X, shift, scale, B::Matrix{Float64}, bias, ctx)
+    X = ensure_mat(X); m, p = size(X); k = size(B, 2)
+    size(B, 1) == p || throw(DimensionMismatch("X has $p columns, the model has $(size(B, 1))"))
+    out = _similar(X, m, k)
+    GC.@preserve X out begin
+        check(ctx, ccall((:jch_affine_gemm, LIB), Int32,
+                         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                          Int64, Ptr{Float64}, Ptr{Float64}, Int64),
+                         ctx.h, _loc(X), pointer(X), m, p, stride(X, 2), shift === nothing ? C_NULL : pointer(shift),
+                         scale === nothing ? C_NULL : pointer(scale), B, k, bias === nothing ? C_NULL : pointer(bias),
+                         pointer(out), m))
+    end
+    out
+end
+
+"src/plskern.jl:187-195"
+function transform(object::Plsr, X; nlv = nothing, ctx = default_ctx())
+    a = size(object.P, 2)
+    nlv = nlv === nothing ? a : min(nlv, a)
+    _affine(X, object.xmeans, object.xscales, object.R[:, 1:nlv], nothing, ctx)
+end
+
+"src/plskern.jl:207-217 (p x q host glue, as in the reference)"
+function coef(object::Plsr; nlv = nothing)
+    a = size(object.P, 2)
+    nlv = nlv === nothing ? a : min(nlv, a)
+    beta = object.C[:, 1:nlv]'
+    B = Diagonal(1 ./ object.xscales) * object.R[:, 1:nlv] * beta * Diagonal(object.yscales)
+    int = object.ymeans' .- object.xmeans' * B
+    (B = B, int = int)
+end
+
+"src/plskern.jl:226-238 — the whole nlv range in ONE pass over X (B blocks concatenated)."
+function predict(object::Plsr, X; nlv = nothing, ctx = default_ctx())
+    a = size(object.P, 2); q = size(object.C, 1)
+    rng = nlv === nothing ? (a:a) : (max(0, minimum(nlv)):min(a, maximum(nlv)))
+    zs = [coef(object; nlv = k) for k in rng]
+    out = _affine(X, nothing, nothing, reduce(hcat, [z.B for z in zs]), reduce(vcat, [vec(z.int) for z in zs]), ctx)
+    pred = [out[:, (i - 1) * q + 1:i * q] for i in 1:length(rng)]
+    (pred = length(rng) == 1 ? pred[1] : pred,)
+end
+
+"`summary(object::Plsr, X)` — src/plskern.jl:246-260 (named summary_plsr to avoid piracy on Base.summary)."
+function summary_plsr(object::Plsr, X; ctx = default_ctx())
+    X = ensure_mat(X); n, nlv = size(X, 1), size(object.P, 2)
+    ss = Ref{Float64}(0.0)
+    GC.@preserve X begin
+        check(ctx, ccall((:jch_weighted_ss, LIB), Int32,
+                         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+                         ctx.h, _loc(X), pointer(X), n, size(X, 2), stride(X, 2), pointer(object.weights),
+                         object.xmeans, object.xscales, ss))
+    end
+    tt_adj = vec(sum(object.P .^ 2, dims = 1)) .* object.TT
+    pvar = tt_adj / ss[]
+    (explvarx = (nlv = 1:nlv, var = tt_adj / n, pvar = pvar, cumpvar = cumsum(pvar)),)
+end
+
+end # module
