@@ -111,18 +111,19 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
     const size_t small_bytes = 256 * 16 + sizeof(double) * ((size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
-                                                         2 * (size_t)nlv_cap * q + 2 * nlv_cap + 128 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8);
+                                                         (size_t)nlv_cap * q + 34 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
     s.K = cv.take((size_t)p * qpad); s.w = cv.take(ldr); s.r = cv.take(ldr);
     s.P = cv.take((size_t)nlv_cap * p); s.R = cv.take((size_t)nlv_cap * p); s.W = cv.take((size_t)nlv_cap * p);
-    s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap); s.Z = cv.take((size_t)nlv_cap * q);
+    s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap); s.Z = cv.take((size_t)nlv_cap * 16);
     const int ldz = (ldr + 1 + qpad + 7) & ~7;
     s.zt = cv.take((size_t)JCH_ZT_SLICES * ldz); s.zpc = cv.take((size_t)ldr + qpad);
     s.mom = cv.take(p + q); s.scl = cv.take(p + q); s.hdr = cv.take(8);
-    s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(nlv_cap + 1) : nullptr;
+    s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
 
+    if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
     hipEvent_t ev_begin = jch_ev(ctx);
     // ---- K0 weights; global row count for the nlv clamp (src/plskern.jl:116-117)
     JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr));
@@ -198,6 +199,13 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         fprintf(stderr, "[jch] jacobi sweeps per LV:");
         for (int i = 0; i < nlv; ++i) fprintf(stderr, " %d", (int)h[i]);
         fprintf(stderr, "\n");
+        std::vector<double> st(16 * (nlv + 1));
+        (void)hipMemcpy(st.data(), s.dbg + 512, sizeof(double) * st.size(), hipMemcpyDeviceToHost);
+        for (int c : {0, 1, nlv / 2, nlv - 1}) {
+            fprintf(stderr, "[jch] lv_update call %d stamps (cycles since kernel start):", c);
+            for (int k = 1; k < 16; ++k) if (st[16 * c + k] > 0) fprintf(stderr, " %d:%.0f", k, st[16 * c + k] - st[16 * c]);
+            fprintf(stderr, "\n");
+        }
     }
 
     if (ctx->profiling) {

@@ -18,6 +18,8 @@
 #include "jch_internal.h"
 
 #define FT 512
+// diagnostic stamps (JCH_LV_DEBUG only): thread 0 records the shader clock at phase boundaries
+#define JCH_STAMP(k) do { if (g.s.dbg && tid == 0) g.s.dbg[512 + 16 * (g.do_a ? a + 1 : 0) + (k)] = (double)__builtin_readcyclecounter(); } while (0)
 
 struct lvf_args {
     jch_small s;
@@ -145,16 +147,20 @@ __device__ static void jacobi_wave(int q, int lda, double *A0, double *A1, doubl
 }
 
 // Dominant eigenvector of the symmetric positive semi-definite q x q matrix G (LDS, preserved) by repeated
-// squaring, one wave.  Returns false (wave-uniform) if the monitor did not converge: the caller falls back to
-// Jacobi.  B0/B1: work buffers.
+// squaring, one wave.  Matrices are zero-padded to QP x QP (lda even), so every loop has a compile-time trip
+// count and its LDS loads issue back to back (a predicated `k < q` loop compiles to one branch + one exposed LDS
+// latency per k and made this routine 4x slower).  Returns false (wave-uniform) if the monitor did not
+// converge: the caller falls back to Jacobi.  B0/B1: zero-initialised work buffers.
+template <int QP>
 __device__ static bool dominant_by_squaring(int q, int lda, const double *G, double *B0, double *B1, double *vout,
                                             double *dbg)
 {
     const int lane = threadIdx.x & 63;
     const int nent = q * (q + 1) / 2;
-    int k1s[3], k2s[3];
+    constexpr int NS = (QP * (QP + 1) / 2 + 63) / 64;
+    int k1s[NS], k2s[NS];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < NS; ++s) {
         int e = lane + 64 * s, k1 = 0;
         if (e < nent) {
             while (e >= q - k1) { e -= q - k1; ++k1; }
@@ -170,21 +176,26 @@ __device__ static bool dominant_by_squaring(int q, int lda, const double *G, dou
     bool ok = false;
     for (; it < 24; ++it) {
         double t = 0.0;
-        for (int k = 0; k < q; ++k) t += A[k * lda + k];
+#pragma unroll
+        for (int k = 0; k < QP; ++k) t += A[k * lda + k];
         // A = (previous A)^2 / tr(previous A)^2, so t = sum(lambda^2)/(sum lambda)^2 -> 1 as A -> rank one
         if (it > 0 && extra < 0 && (1.0 - t) < 1e-12) extra = 1;   // then ONE more squaring: rho ~5e-13 -> ~1e-25
         if (extra == 0) { ok = true; break; }
         if (extra > 0) --extra;
-        const double isc = 1.0 / t, isc2 = isc * isc;
+        double isc = __builtin_amdgcn_rcp(t);      // any common scale factor will do: estimate + one Newton step
+        isc = isc * (2.0 - t * isc);
+        const double isc2 = isc * isc;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < NS; ++s) {
+            const int k1 = k1s[s] < 0 ? 0 : k1s[s], k2 = k2s[s];
+            const double *ra = A + k1 * lda, *rb = A + k2 * lda;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < QP; ++k) acc += ra[k] * rb[k];
+            acc *= isc2;
             if (k1s[s] >= 0) {
-                const double *ra = A + k1s[s] * lda, *rb = A + k2s[s] * lda;
-                double acc = 0.0;
-                for (int k = 0; k < q; ++k) acc += ra[k] * rb[k];
-                acc *= isc2;
-                Bn[k1s[s] * lda + k2s[s]] = acc;
-                Bn[k2s[s] * lda + k1s[s]] = acc;
+                Bn[k1 * lda + k2] = acc;
+                Bn[k2 * lda + k1] = acc;
             }
         }
         wavesync();
@@ -193,45 +204,74 @@ __device__ static bool dominant_by_squaring(int q, int lda, const double *G, dou
     if (lane == 0 && dbg) *dbg = ok ? 100 + it : -1;
     if (!ok) return false;
     if (lane == 0) {
+        double dg[QP];
+#pragma unroll
+        for (int k = 0; k < QP; ++k) dg[k] = A[k * lda + k];
         int best = 0;
-        for (int k = 1; k < q; ++k)
-            if (A[k * lda + k] > A[best * lda + best]) best = k;
+        double bd = dg[0];
+#pragma unroll
+        for (int k = 1; k < QP; ++k)
+            if (dg[k] > bd) { bd = dg[k]; best = k; }
+        double col[QP];
+#pragma unroll
+        for (int k = 0; k < QP; ++k) col[k] = A[k * lda + best];
         double ss = 0.0, bigv = 0.0;
-        for (int k = 0; k < q; ++k) {
-            const double v = A[k * lda + best];
-            ss += v * v;
-            if (fabs(v) > fabs(bigv)) bigv = v;
+#pragma unroll
+        for (int k = 0; k < QP; ++k) {
+            ss += col[k] * col[k];
+            if (fabs(col[k]) > fabs(bigv)) bigv = col[k];
         }
         const double sc = (bigv < 0.0 ? -1.0 : 1.0) / sqrt(ss);
-        for (int k = 0; k < q; ++k) vout[k] = sc * A[k * lda + best];
+#pragma unroll
+        for (int k = 0; k < QP; ++k) vout[k] = sc * col[k];
     }
     return true;
 }
 
+// dot of column k of the LDS-resident K (ld ldk) with an LDS vector over rows j = j0, j0+stride, ... :
+// 8 rows per batch with clamped addresses so the loads are unconditional and issue together.
+__device__ __forceinline__ double kcol_dot(const double *Kl, int ldk, int k, const double *x, int j0, int stride, int p)
+{
+    double s = 0.0;
+    for (int j = j0; j < p; j += 8 * stride) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = min(j + u * stride, p - 1);
+            a[u] = Kl[jj * ldk + k];
+            b[u] = x[jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (j + u * stride < p) ? a[u] * b[u] : 0.0;
+    }
+    return s;
+}
+
+template <int QP>
 __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int p = g.p, q = g.q, qpad = g.qpad, ldr = g.ldr, a = g.a, tid = threadIdx.x;
+    const int p = g.p, q = g.q, ldr = g.ldr, a = g.a, tid = threadIdx.x;   // qpad == 16 on this path
     const int lane = tid & 63, wv = tid >> 6;
-    const int ldk = q | 1, lda = q + 1;
-    double *Kl = lds;                              // [p][ldk]
-    double *ztl = Kl + (size_t)p * ldk;            // [ldr + 1 + qpad]
-    double *rl = ztl + (ldr + 1 + qpad + 1);       // [ldr]
+    constexpr int ldk = QP | 1, lda = QP + 2;
+    double *Kl = lds;                              // [p][ldk]   columns q..QP-1 are zero
+    double *ztl = Kl + (size_t)p * ldk;            // [ldr + 1 + 16]
+    double *rl = ztl + (ldr + 18);                 // [ldr]
     double *wl = rl + ldr;                         // [ldr]
     double *scratch = wl + ldr;                    // [2 FT]
-    double *cl = scratch + 2 * FT;                 // [64]
-    double *vl = cl + 64;                          // [64]
-    double *ul = vl + 64;                          // [nlv]   u = Z v ; phase A: s_i = P_i . zp
-    double *Zl = ul + g.nlv;                       // [nlv][q]
-    double *G0 = Zl + (size_t)g.nlv * q, *A0 = G0 + q * lda, *A1 = A0 + q * lda, *V0 = A1 + q * lda, *V1 = V0 + q * lda;
-    double *csl = V1 + q * lda;                    // [2 (q + 2)]
+    double *cl = scratch + 2 * FT;                 // [16]  (zero beyond q)
+    double *vl = cl + 16;                          // [16]
+    double *ul = vl + 16;                          // [nlv]   u = Z v ; phase A: s_i = P_i . zp
+    double *Zl = ul + ((g.nlv + 1) & ~1);          // [nlv][QP]
+    double *G0 = Zl + (size_t)g.nlv * QP, *A0 = G0 + QP * lda, *A1 = A0 + QP * lda, *V0 = A1 + QP * lda, *V1 = V0 + QP * lda;
+    double *csl = V1 + QP * lda;                   // [2 (QP + 2)]
     double *K = g.s.K;
     const bool needK = g.do_b || g.algo == 0;
     const int a_old = a;                                  // LVs whose P/R/Z rows are in global memory at entry
     const int anext = g.do_a ? a + 1 : a;                 // LVs finished once phase A is done
     const bool rec = g.algo == 0 && anext > 0;            // r-recursion state in use (src/plskern.jl:156-161)
     const bool recA = rec && g.do_a && a_old > 0;         // phase A has old Z rows to update
-
+    JCH_STAMP(0);
     // ---- issue EVERY global load of this kernel up front: one memory latency instead of one per phase
     double rreg[32];   // R[i][tid], i < min(a_old, 32)                         (phase B tail)
     double preg[4][8]; // P[wv + 8 v][lane + 64 c]                              (phase A: s_i = P_i . zp)
@@ -250,24 +290,44 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             }
         }
     }
-    if (needK) {   // 16 lanes per row segment; no integer division
-        const int k = tid & 15;
-        for (int kg = 0; kg < qpad; kg += 16)
-            if (kg + k < q)
-                for (int j = tid >> 4; j < p; j += FT / 16) Kl[j * ldk + kg + k] = K[(size_t)j * qpad + kg + k];
+    if (needK) {   // K is [p][16] contiguous: flat coalesced loads, 16 in flight per thread, addresses clamped
+        const int tot = p * 16;
+        for (int base = 0; base < tot; base += FT * 16) {
+            double kr[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kr[i] = K[min(base + tid + FT * i, tot - 1)];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = base + tid + FT * i;
+                if (e < tot && (e & 15) < QP) Kl[(e >> 4) * ldk + (e & 15)] = kr[i];
+            }
+        }
     }
+    for (int e = tid; e < 5 * QP * lda; e += FT) G0[e] = 0.0;   // G0, A0, A1, V0, V1: zero padding
+    if (tid < 32) cl[tid] = 0.0;                                 // cl, vl
+    for (int e = tid; e < g.nlv; e += FT) ul[e] = 0.0;           // (prefetched R rows beyond a_old multiply zeros)
     if (rec)
-        for (int e = tid; e < a_old * q; e += FT) Zl[e] = g.s.Z[e];
+        for (int e = tid; e < a_old * QP; e += FT) Zl[e] = g.s.Z[e];
     if (g.do_a) {
-        const int mz = ldr + 1 + (g.algo == 1 ? qpad : 0);
+        const int mz = ldr + 1 + (g.algo == 1 ? 16 : 0);
         for (int c = tid; c < mz; c += FT) {
-            double s = 0.0;
-            for (int sl = 0; sl < g.nslice; ++sl) s += g.s.zt[(size_t)sl * g.ldz + c];
+            double s;
+            if (g.nslice == 1) {
+                s = g.s.zt[c];
+            } else {   // all JCH_ZT_SLICES slices are written by k_reduce_part (unused ones hold zeros)
+                double z[JCH_ZT_SLICES];
+#pragma unroll
+                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) z[sl] = g.s.zt[(size_t)sl * g.ldz + c];
+                s = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) s += z[sl];
+            }
             ztl[c] = s;
         }
         for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
     }
     __syncthreads();
+    JCH_STAMP(1);
 
     // ------------------------------------------------------------------ phase A
     if (g.do_a) {
@@ -275,10 +335,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         if (g.algo == 0) {
             {   // c = K' r / tt : partials over 32 row groups
                 const int k = tid & 15, gr = tid >> 4;
-                double s = 0.0;
-                if (k < q)
-                    for (int j = gr; j < p; j += FT / 16) s += Kl[j * ldk + k] * rl[j];
-                scratch[gr * 16 + k] = s;
+                scratch[gr * 16 + k] = k < QP ? kcol_dot(Kl, ldk, k, rl, gr, FT / 16, p) : 0.0;
             }
             if (recA) {   // s_i = P_i . zp for the finished LVs (wave per vector)
                 for (int v = 0; wv + (FT / 64) * v < a_old; ++v) {
@@ -292,7 +349,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
 #pragma unroll
                             for (int vv = 0; vv < 4; ++vv)
                                 if (vv == v) pij = preg[vv][c];
-                            if (j < p) s += pij * ztl[j];
+                            s += pij * ztl[min(j, p - 1)];   // pij is 0 beyond p
                         }
                     }
                     for (int j = lane + (v < 4 ? 512 : 0); j < p; j += 64) s += g.s.P[(size_t)i * p + j] * ztl[j];
@@ -301,20 +358,27 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
                 }
             }
             __syncthreads();
-            if (tid < q) {
+            JCH_STAMP(2);
+            if (tid < 16) {
                 double t = 0.0;
+#pragma unroll
                 for (int gg = 0; gg < FT / 16; ++gg) t += scratch[gg * 16 + tid];
                 t /= tt;
+                if (tid >= q) t = 0.0;
                 cl[tid] = t;
-                g.s.C[(size_t)a * q + tid] = t;
+                if (tid < q) g.s.C[(size_t)a * q + tid] = t;
             }
             __syncthreads();
+            JCH_STAMP(3);
             for (int j = tid; j < p; j += FT) {   // K <- K - zp c'  (LDS + global copy); P_a, W_a, R_a
                 const double zp = ztl[j];
-                for (int k = 0; k < q; ++k) {
-                    const double v = Kl[j * ldk + k] - zp * cl[k];
-                    Kl[j * ldk + k] = v;
-                    K[(size_t)j * qpad + k] = v;
+                double kv[QP];
+#pragma unroll
+                for (int k = 0; k < QP; ++k) kv[k] = Kl[j * ldk + k] - zp * cl[k];
+#pragma unroll
+                for (int k = 0; k < QP; ++k) {
+                    Kl[j * ldk + k] = kv[k];
+                    K[(size_t)j * 16 + k] = kv[k];      // pad columns stay exactly zero (c_k = 0 there)
                 }
                 g.s.P[(size_t)a * p + j] = zp / tt;
                 g.s.W[(size_t)a * p + j] = wl[j];
@@ -322,14 +386,12 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             }
             if (recA)     // Z_i <- Z_i - (P_i . zp) c'
                 for (int i = wv; i < a_old; i += FT / 64)
-                    if (lane < q) Zl[i * q + lane] -= ul[i] * cl[lane];
+                    if (lane < QP) Zl[i * QP + lane] -= ul[i] * cl[lane];
             __syncthreads();
+            JCH_STAMP(4);
             if (g.do_b) {   // new row Z_a = P_a' K_new = (zp' K_new) / tt
                 const int k = tid & 15, gr = tid >> 4;
-                double s = 0.0;
-                if (k < q)
-                    for (int j = gr; j < p; j += FT / 16) s += Kl[j * ldk + k] * ztl[j];
-                scratch[FT + gr * 16 + k] = s;    // second half of scratch: the Gram pass below uses the first
+                scratch[FT + gr * 16 + k] = k < QP ? kcol_dot(Kl, ldk, k, ztl, gr, FT / 16, p) : 0.0;
             }
         } else {
             for (int j = tid; j < ldr; j += FT) {
@@ -340,15 +402,15 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
                     g.s.W[(size_t)a * p + j] = wl[j];
                 }
             }
-            for (int k = tid; k < qpad; k += FT) {
-                const double c = k < q ? ztl[ldr + 1 + k] / tt : 0.0;
-                g.s.zpc[ldr + k] = c;
-                if (k < q) g.s.C[(size_t)a * q + k] = c;
+            if (tid < 16) {
+                const double c = tid < q ? ztl[ldr + 1 + tid] / tt : 0.0;
+                g.s.zpc[ldr + tid] = c;
+                if (tid < q) g.s.C[(size_t)a * q + tid] = c;
             }
         }
         if (tid == 0) g.s.TT[a] = tt;
     }
-    if (!g.do_b) return;
+    if (!g.do_b) { JCH_STAMP(15); return; }
 
     // ------------------------------------------------------------------ phase B
     if (q > 1) {
@@ -362,53 +424,70 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             if (act) {
                 while (e >= q - k1) { e -= q - k1; ++k1; }
                 const int k2 = k1 + e;
-                for (int j = gr; j < p; j += FT / 64) s += Kl[j * ldk + k1] * Kl[j * ldk + k2];
+                for (int j = gr; j < p; j += 8 * (FT / 64)) {
+                    double x1[8], x2[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = min(j + u * (FT / 64), p - 1);
+                        x1[u] = Kl[jj * ldk + k1];
+                        x2[u] = Kl[jj * ldk + k2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += (j + u * (FT / 64) < p) ? x1[u] * x2[u] : 0.0;
+                }
             }
             scratch[gr * 64 + el] = s;
             __syncthreads();
+            JCH_STAMP(5);
             if (act && gr == 0) {
                 double t = 0.0;
+#pragma unroll
                 for (int gg = 0; gg < FT / 64; ++gg) t += scratch[gg * 64 + el];
                 const int k2 = k1 + e;
                 G0[k1 * lda + k2] = t;
                 G0[k2 * lda + k1] = t;
             }
             __syncthreads();
+            JCH_STAMP(6);
         }
     } else {
         if (tid == 0) vl[0] = 1.0;
         __syncthreads();
     }
-    if (rec && g.do_a && tid < q) {   // finish Z_a (its partials were written before the Gram barriers)
+    if (rec && g.do_a && tid < QP) {   // finish Z_a (its partials were written before the Gram barriers)
         double t = 0.0;
+#pragma unroll
         for (int gg = 0; gg < FT / 16; ++gg) t += scratch[FT + gg * 16 + tid];
-        Zl[a * q + tid] = t / ztl[ldr];
+        Zl[a * QP + tid] = t / ztl[ldr];
     }
     if (q > 1 && wv == 0) {
-        if (!dominant_by_squaring(q, lda, G0, A0, A1, vl, g.s.dbg ? g.s.dbg + anext : nullptr)) {
-            for (int e = lane; e < q * lda; e += 64) A0[e] = G0[e];
+        if (!dominant_by_squaring<QP>(q, lda, G0, A0, A1, vl, g.s.dbg ? g.s.dbg + anext : nullptr)) {
+            for (int e = lane; e < QP * lda; e += 64) A0[e] = G0[e];
             wavesync();
             jacobi_wave(q, lda, A0, A1, V0, V1, csl, vl, g.s.dbg ? g.s.dbg + anext : nullptr);
         }
     }
     __syncthreads();
+    JCH_STAMP(8);
     if (rec) {
         if (tid < anext) {   // u = Z v
             double u = 0.0;
-            for (int k = 0; k < q; ++k) u += Zl[tid * q + k] * vl[k];
+#pragma unroll
+            for (int k = 0; k < QP; ++k) u += Zl[tid * QP + k] * vl[k];
             ul[tid] = u;
         }
-        for (int e = tid; e < anext * q; e += FT) g.s.Z[e] = Zl[e];
+        for (int e = tid; e < anext * QP; e += FT) g.s.Z[e] = Zl[e];
     }
     // w_raw = K v ; ||w_raw||
     double wr[JCH_SWEEP_MAXP / FT];
     double ssq = 0.0;
 #pragma unroll
     for (int it = 0; it < JCH_SWEEP_MAXP / FT; ++it) {
-        const int j = tid + it * FT;
+        const int j = min(tid + it * FT, p - 1);
         double wv_ = 0.0;
-        if (j < p)
-            for (int k = 0; k < q; ++k) wv_ += Kl[j * ldk + k] * vl[k];
+#pragma unroll
+        for (int k = 0; k < QP; ++k) wv_ += Kl[j * ldk + k] * vl[k];
+        if (tid + it * FT >= p) wv_ = 0.0;
         wr[it] = wv_;
         ssq += wv_ * wv_;
     }
@@ -428,8 +507,8 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
                     if (it == 0) {
 #pragma unroll
                         for (int i = 0; i < 32; i += 2) {
-                            if (i < a_old) r0 += rreg[i] * ul[i];
-                            if (i + 1 < a_old) r1 += rreg[i + 1] * ul[i + 1];
+                            r0 += rreg[i] * ul[min(i, g.nlv - 1)];          // rreg is 0 beyond a_old
+                            r1 += rreg[i + 1] * ul[min(i + 1, g.nlv - 1)];
                         }
                         i0 = a_old < 32 ? a_old : 32;
                     }
@@ -443,31 +522,40 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             g.s.r[j] = rn;
         }
     }
+    JCH_STAMP(15);
 }
 
 size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv)
 {
-    const int ldk = q | 1, lda = q + 1;
-    return sizeof(double) * ((size_t)p * ldk + (ldr + 2 + qpad) + 2 * (size_t)ldr + 2 * FT + 64 + 64 + nlv + (size_t)nlv * q +
-                             5 * (size_t)q * lda + 2 * (q + 2) + 8);
+    (void)qpad;
+    const int QP = q <= 1 ? 1 : (q <= 2 ? 2 : (q <= 4 ? 4 : (q <= 8 ? 8 : 16)));
+    const int ldk = QP | 1, lda = QP + 2;
+    return sizeof(double) * ((size_t)p * ldk + (ldr + 18) + 2 * (size_t)ldr + 2 * FT + 32 + ((nlv + 1) & ~1) + (size_t)nlv * QP +
+                             5 * (size_t)QP * lda + 2 * (QP + 2) + 8);
 }
 
 int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
                                   int do_a, int do_b, int nslice, int ldz)
 {
+    if (qpad != 16) return jch_fail(ctx, JCH_EINVAL, "internal: fast small-state kernel needs q <= 16");
     lvf_args g;
     g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.a = a; g.nlv = nlv; g.algo = algo;
-    g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz;
-    static int skip = -1;
-    if (skip < 0) { const char *e = getenv("JCH_LV_SKIP"); skip = e ? atoi(e) : 0; }
-    g.skip = skip;
+    g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz; g.skip = 0;
     const size_t lds = jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv);
     static bool attr_set = false;
     if (!attr_set) {
-        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_lv_update_fast, dim3(1), dim3(FT), lds, ctx->stream, g);
+    if (q <= 1) hipLaunchKernelGGL(k_lv_update_fast<1>, dim3(1), dim3(FT), lds, ctx->stream, g);
+    else if (q <= 2) hipLaunchKernelGGL(k_lv_update_fast<2>, dim3(1), dim3(FT), lds, ctx->stream, g);
+    else if (q <= 4) hipLaunchKernelGGL(k_lv_update_fast<4>, dim3(1), dim3(FT), lds, ctx->stream, g);
+    else if (q <= 8) hipLaunchKernelGGL(k_lv_update_fast<8>, dim3(1), dim3(FT), lds, ctx->stream, g);
+    else hipLaunchKernelGGL(k_lv_update_fast<16>, dim3(1), dim3(FT), lds, ctx->stream, g);
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }

@@ -171,7 +171,8 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
                            tcol, part, ldpart);
     (void)jch_ev(ctx);  // (end)
     int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
-    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, nslice), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
+    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
+    if (nslice > 1) nslice = JCH_ZT_SLICES;   // slices beyond the used ones hold zeros: the consumer sums all of them
     if (max_slices == 1 && nslice > 1) {  // consumer wants one vector (all-reduce / generic small-state kernel)
         hipLaunchKernelGGL(k_reduce_slices, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, zt, ldz, m, nslice);
         nslice = 1;
