@@ -3,6 +3,10 @@
 // One read + one write of the row-major working copy Xr per LV; K_next on v_mfma_f64_16x16x4_f64 exactly as
 // in the prologue kernel K2 (prologue.hip).  The reference allocates an n x p outer-product temporary here.
 // Bound: HBM, 2*n*ldr*8 bytes per launch.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "jch_internal.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -108,9 +112,159 @@ __global__ __launch_bounds__(256) void k_reduce_kpart2(const double *__restrict_
     K[e] = s;
 }
 
+// ---- streaming variant for q <= 4 (cfg4: q = 1): same register-resident row layout as the sweep (sweep.hip) —
+// no LDS transpose, 16-B coalesced loads and stores, K_next accumulated like zp.  Per-block partials
+// part[b][k * ldr + c] are summed in fixed order by k_reduce_kstream (deterministic).
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+template <int KC, int R, int Q>
+__global__ __launch_bounds__(256) void k_deflate_stream(double *__restrict__ Xr, int64_t n, int ldr, double *__restrict__ Yr,
+                                                         int qpad, const double *__restrict__ dw,
+                                                         const double *__restrict__ tcol, const double *__restrict__ zpc,
+                                                         double *__restrict__ part, int ldpart)
+{
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [4][Q][KC*128]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v2f64 zpf[KC], kacc[Q][KC];
+    bool in[KC];
+    double cf[Q];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 2 * lane + 128 * k;
+        in[k] = col < ldr;
+        zpf[k] = in[k] ? *reinterpret_cast<const v2f64 *>(zpc + col) : v2f64{0.0, 0.0};
+#pragma unroll
+        for (int y = 0; y < Q; ++y) kacc[y][k] = v2f64{0.0, 0.0};
+    }
+#pragma unroll
+    for (int y = 0; y < Q; ++y) cf[y] = zpc[ldr + y];
+    const int64_t ngroups = (n + R - 1) / R;
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wv; g < ngroups; g += gstride) {
+        const int64_t row0 = g * R;
+        v2f64 x[R][KC];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const bool live = row0 + rr < n;
+            const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xr + (size_t)(row0 + rr) * (size_t)ldr) + lane;
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                x[rr][k] = (live && in[k]) ? __builtin_nontemporal_load(rp + 64 * k) : v2f64{0.0, 0.0};
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int64_t row = row0 + rr;
+            if (row < n) {   // wave-uniform
+                const double t = tcol[row], dv = dw[row];
+                v2f64 *wp = reinterpret_cast<v2f64 *>(Xr + (size_t)row * (size_t)ldr) + lane;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    x[rr][k].x -= t * zpf[k].x;
+                    x[rr][k].y -= t * zpf[k].y;
+                    if (in[k]) __builtin_nontemporal_store(x[rr][k], wp + 64 * k);
+                }
+#pragma unroll
+                for (int y = 0; y < Q; ++y) {
+                    const double yn = Yr[(size_t)row * qpad + y] - t * cf[y];
+                    if (lane == y) Yr[(size_t)row * qpad + y] = yn;
+                    const double s = dv * yn;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        kacc[y][k].x += s * x[rr][k].x;
+                        kacc[y][k].y += s * x[rr][k].y;
+                    }
+                }
+            }
+        }
+    }
+    double *prow = part + (size_t)blockIdx.x * ldpart;
+#pragma unroll
+    for (int y = 0; y < Q; ++y) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            *reinterpret_cast<v2f64 *>(red + (size_t)(wv * Q + y) * (KC * 128) + 2 * lane + 128 * k) = kacc[y][k];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Q * ldr; e += 256) {
+        const int y = e / ldr, c = e - y * ldr;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(size_t)(w * Q + y) * (KC * 128) + c];
+        prow[e] = s;
+    }
+}
+
+// K[c][y] = sum_b part[b][y*ldr + c]   (fixed order: 16 interleaved block streams, then combined)
+__global__ __launch_bounds__(1024) void k_reduce_kstream(const double *__restrict__ part, int nb, int ldpart, int ldr, int p,
+                                                         int Q, int qpad, double *__restrict__ K)
+{
+    __shared__ double sc[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + cl;     // index into [Q][ldr]
+    double s = 0.0;
+    if (e < Q * ldr)
+        for (int b = g; b < nb; b += 16) s += part[(size_t)b * ldpart + e];
+    sc[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && e < Q * ldr) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sc[k][cl];
+        const int y = e / ldr, c = e - y * ldr;
+        if (c < p) K[(size_t)c * qpad + y] = t;
+    }
+}
+
+template <int KC, int R, int Q>
+static int32_t launch_deflate_stream(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, const double *d,
+                                     const double *tcol, const double *zpc, double *Knext)
+{
+    const size_t lds = sizeof(double) * 4 * Q * KC * 128;
+    static int bpc = 0;
+    if (bpc == 0) {
+        int nblk = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_deflate_stream<KC, R, Q>, 256, lds);
+        bpc = (e == hipSuccess && nblk > 0) ? nblk : 2;
+        if (lds > 64 * 1024)
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_deflate_stream<KC, R, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const int64_t ngroups = (n + R - 1) / R;
+    int64_t nb64 = std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * bpc);
+    const int nb = (int)std::max<int64_t>(nb64, 1);
+    const int ldpart = (Q * ldr + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nb * ldpart));
+    double *part = (double *)ctx->kpart.ptr;
+    (void)jch_ev(ctx);
+    hipLaunchKernelGGL((k_deflate_stream<KC, R, Q>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, Yr, qpad, d, tcol, zpc,
+                       part, ldpart);
+    (void)jch_ev(ctx);
+    if (Knext) {
+        // pad columns of K (y >= q) must stay zero: they are never written here and were zeroed by the prologue
+        hipLaunchKernelGGL(k_reduce_kstream, dim3((Q * ldr + 63) / 64), dim3(1024), 0, ctx->stream, part, nb, ldpart, ldr, p, Q,
+                           qpad, Knext);
+        JCH_TRY(jch_allreduce_f64(ctx, Knext, (size_t)p * qpad));
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
 int32_t jch_launch_deflate(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q,
                            const double *d, const double *tcol, const double *zpc, double *Knext)
 {
+    if (q <= 4 && !getenv("JCH_DEFLATE_TILE")) {
+#define JCH_DS(KC, R) do { \
+        if (q == 1) return launch_deflate_stream<KC, R, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext); \
+        if (q == 2) return launch_deflate_stream<KC, R, 2>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext); \
+        return launch_deflate_stream<KC, R, 4>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext); } while (0)
+        if (ldr <= 128) JCH_DS(1, 4);
+        if (ldr <= 256) JCH_DS(2, 4);
+        if (ldr <= 512) JCH_DS(4, 2);
+        if (ldr <= 1024) JCH_DS(8, 1);
+        if (ldr <= 2048) {   // Q x KC accumulators: keep registers in check at the widest rows
+            if (q == 1) return launch_deflate_stream<16, 1, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
+            if (q == 2) return launch_deflate_stream<16, 1, 2>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
+        }
+#undef JCH_DS
+    }
     const int ptiles = (ldr + 63) / 64, kp_rows = ptiles * 64, ygroups = qpad / 16;
     const int64_t nchunks = (n + 63) / 64;
     int nbx = (ctx->cus * 3 + ptiles - 1) / ptiles;
