@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--q", type=int, default=10)
     ap.add_argument("--nlv", type=int, default=25)
     ap.add_argument("--algo", choices=["plskern", "plsnipals"], default="plskern")
+    ap.add_argument("--dtype", choices=["f64", "bf16"], default="f64", help="bf16 = storage mode of BASELINE configs[2]")
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -111,13 +112,20 @@ def main():
     Y = J.colmajor_empty(n, q, dev)
     ctx.check(lib.jch_fill_uniform(ctx._h, X.data_ptr(), n, p, n, row0, n_total, 20250112))
     ctx.check(lib.jch_fill_uniform(ctx._h, Y.data_ptr(), n, q, n, row0, n_total, 20250113))
+    bf16 = args.dtype == "bf16"
+    if bf16:   # round-to-nearest-even to bf16 storage; the f64 originals are dropped
+        Xb = J.colmajor_empty(n, p, dev, dtype=torch.bfloat16); Xb.copy_(X); X = Xb
+        Yb = J.colmajor_empty(n, q, dev, dtype=torch.bfloat16); Yb.copy_(Y); Y = Yb
+        del Xb, Yb
+        torch.cuda.empty_cache()
     kmax = min(nlv, p, n_total)
     T = J.colmajor_empty(n, kmax, dev)
     wn = torch.empty(n, dtype=torch.float64, device=dev)
     P = np.zeros((p, kmax), order="F"); R = np.zeros((p, kmax), order="F"); W = np.zeros((p, kmax), order="F")
     Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
     xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
-    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.F64, loc=_lib.LOC_DEVICE, inplace=0, reserved=0)
+    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0,
+                        reserved=0)
     got = C.c_int32(0)
     entry = lib.jch_plskern_fit if args.algo == "plskern" else lib.jch_plsnipals_fit
 
@@ -161,13 +169,14 @@ def main():
             "metric": f"latent-variables/sec ({args.algo} n={n_total:.0e} p={p} q={q} nlv={nlv})".replace("e+0", "e"),
             "value": value, "unit": "LV/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": value / README_PLSKERN_LVS if (args.algo == "plskern" and (n_total, p, q, nlv) == (1_000_000, 500, 10, 25)) else None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg2 (BASELINE.json configs[1]): {args.algo} n={n_total} p={p} q={q} nlv={nlv} Float64, "
+            "vs_baseline": value / README_PLSKERN_LVS if (args.algo == "plskern" and not bf16 and (n_total, p, q, nlv) == (1_000_000, 500, 10, 25)) else None,
+            "dtype": "bf16 storage / f32 rows / f64 state" if bf16 else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.algo} n={n_total} p={p} q={q} nlv={nlv} {'bf16-stored' if bf16 else 'Float64'} "
+                                   f"({'BASELINE.json configs[1]' if (args.algo, n_total, p, q, nlv, bf16) == ('plskern', 1000000, 500, 10, 25, False) else 'variant'}), "
                                    f"X/Y device-resident column-major, rows sharded over {world} GPU(s)",
                        "n": n_total, "p": p, "q": q, "nlv": k, "rows_per_gpu": n, "timed": "prologue + LV loop, device-resident"},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.algo, n, p),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if bf16 else pmc_traffic(args.algo, n, p),
                          "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches},
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
                                    "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps},

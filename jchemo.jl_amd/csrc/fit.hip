@@ -33,7 +33,9 @@ int32_t validate(jch_ctx *ctx, const fit_io &io, const char *who)
         return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld > %d not supported by the fused sweep yet", who, (long long)d->p,
                         JCH_SWEEP_MAXP);
     if (d->nlv < 1) return jch_fail(ctx, JCH_EINVAL, "%s: nlv=%d must be >= 1", who, d->nlv);
-    if (d->dtype != JCH_F64) return jch_fail(ctx, JCH_EINVAL, "%s: dtype %d not supported (f64 only in this build)", who, d->dtype);
+    if (d->dtype != JCH_F64 && d->dtype != JCH_BF16) return jch_fail(ctx, JCH_EINVAL, "%s: unknown dtype %d", who, d->dtype);
+    if (d->dtype == JCH_BF16 && (d->loc != JCH_LOC_DEVICE || d->inplace))
+        return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage needs device-resident inputs and inplace = 0", who);
     if (d->loc != JCH_LOC_HOST && d->loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "%s: bad loc %d", who, d->loc);
     if (!io.X || !io.Y) return jch_fail(ctx, JCH_EINVAL, "%s: X or Y is NULL", who);
     if (io.ldx < d->n || io.ldy < d->n) return jch_fail(ctx, JCH_EINVAL, "%s: ldx/ldy smaller than n", who);
@@ -100,8 +102,10 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     }
     // ---- working copies and small state
     const int nlv_cap = (int)std::min<int64_t>(d.nlv, p);  // upper bound before the global-n clamp
-    JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
-    JCH_TRY(jch_reserve(ctx, ctx->yr, sizeof(double) * (size_t)n * qpad));
+    if (d.dtype == JCH_F64) {
+        JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
+        JCH_TRY(jch_reserve(ctx, ctx->yr, sizeof(double) * (size_t)n * qpad));
+    }
     double *Xr = (double *)ctx->xr.ptr, *Yr = (double *)ctx->yr.ptr;
     double *dn = nullptr;
     if (!host && io.weights_norm) dn = io.weights_norm;
@@ -124,6 +128,36 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
 
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
+    if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
+        if (algo != 0) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
+        const bool fastb = q <= 16 && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
+        hipEvent_t evb = jch_ev(ctx);
+        int nlvb = 0;
+        JCH_TRY(jch_fit_plskern_bf16(ctx, d, io.X, io.ldx, io.Y, io.ldy, wdev, dn, Tdev, s, ldr, qpad, ldz, fastb, &nlvb));
+        hipEvent_t eve = jch_ev(ctx);
+        const size_t ev_last = ctx->ev_used - 1;
+        auto d2hb = [&](double *dst, const double *src, size_t count) -> int32_t {
+            if (dst) JCH_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+            return JCH_OK;
+        };
+        JCH_TRY(d2hb(io.P, s.P, (size_t)nlvb * p)); JCH_TRY(d2hb(io.R, s.R, (size_t)nlvb * p)); JCH_TRY(d2hb(io.W, s.W, (size_t)nlvb * p));
+        JCH_TRY(d2hb(io.C, s.C, (size_t)nlvb * q)); JCH_TRY(d2hb(io.TT, s.TT, nlvb));
+        JCH_TRY(d2hb(io.xmeans, s.mom, p)); JCH_TRY(d2hb(io.ymeans, s.mom + p, q));
+        JCH_TRY(d2hb(io.xscales, s.scl, p)); JCH_TRY(d2hb(io.yscales, s.scl + p, q));
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (io.nlv_out) *io.nlv_out = nlvb;
+        if (ctx->profiling) {
+            jch_profile &pr = ctx->prof;
+            pr.fit_ms = ev_ms(evb, eve);
+            pr.prologue_ms = ctx->ev_mark > 0 ? ev_ms(evb, ctx->ev_pool[ctx->ev_mark - 1]) : 0.0;
+            double sw = 0.0; int cnt = 0;
+            for (size_t i = ctx->ev_mark; i + 1 < ev_last; i += 2) { sw += ev_ms(ctx->ev_pool[i], ctx->ev_pool[i + 1]); ++cnt; }
+            pr.sweep_ms = sw; pr.sweep_launches = cnt; pr.nlv = nlvb;
+            pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
+            pr.sweep_bytes = (double)n * ((p + 7) & ~7) * 2.0 + 16.0 * (double)n;
+        }
+        return JCH_OK;
+    }
     hipEvent_t ev_begin = jch_ev(ctx);
     // ---- K0 weights; global row count for the nlv clamp (src/plskern.jl:116-117)
     JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr));

@@ -47,6 +47,7 @@ struct jch_ctx {
     jch_profile prof{};
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    size_t ev_mark = 0;
     // tuning knobs (env JCH_SWEEP_BLOCKS_PER_CU etc.)
     int sweep_blocks_per_cu = 0;
 };
@@ -120,6 +121,10 @@ int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p,
                                int k, int kpad, const double *bias /*[kpad]*/, double *out, int64_t ldo);
 int32_t jch_launch_weighted_ss(jch_ctx *ctx, const double *Xc, int64_t n, int p, int64_t ldx, const double *d,
                                const double *shift, const double *iscale, double *out1);
+// bf16.hip
+int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv, int64_t ldx, const void *Yv, int64_t ldy,
+                             const double *wdev, double *dn, double *Tdev, jch_small &s, int ldr_small, int qpad, int ldz,
+                             bool fast, int *nlv_out);
 // util.hip
 int32_t jch_launch_fill(jch_ctx *ctx, double *out, int64_t n, int64_t p, int64_t ld, int64_t row0, int64_t n_total,
                         uint64_t seed);

@@ -50,9 +50,9 @@ def _is_torch(a) -> bool:
     return torch is not None and isinstance(a, torch.Tensor)
 
 
-def colmajor_empty(n: int, p: int, device="cuda:0"):
-    """(n, p) float64 torch tensor with Julia's column-major strides (1, n)."""
-    return torch.empty((p, n), dtype=torch.float64, device=device).t()
+def colmajor_empty(n: int, p: int, device="cuda:0", dtype=None):
+    """(n, p) torch tensor (float64 by default) with Julia's column-major strides (1, n)."""
+    return torch.empty((p, n), dtype=dtype or torch.float64, device=device).t()
 
 
 def ensure_mat(X):
@@ -71,10 +71,10 @@ def ensure_mat(X):
     return X
 
 
-def _addr_ld(a):
+def _addr_ld(a, allow_bf16=False):
     """(address, leading dimension) of a column-major float64 matrix view; raises if not column-major."""
     if _is_torch(a):
-        if a.dtype != torch.float64:
+        if a.dtype != torch.float64 and not (allow_bf16 and a.dtype == torch.bfloat16):
             raise TypeError("expected a float64 tensor")
         n = a.shape[0]
         if a.dim() == 1:
@@ -155,9 +155,12 @@ def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Op
     P = np.zeros((p, kmax), order="F"); R = np.zeros((p, kmax), order="F"); W = np.zeros((p, kmax), order="F")
     Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
     xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
-    xa, ldx = _addr_ld(X)
-    ya, ldy = _addr_ld(Y)
-    desc = PlsDesc(n=n, p=p, q=q, nlv=int(nlv), scal=int(bool(scal)), dtype=_lib.F64,
+    bf16 = dev and X.dtype == torch.bfloat16
+    if bf16 and Y.dtype != torch.bfloat16:
+        raise TypeError("bf16 storage mode needs both X and Y as bfloat16 tensors")
+    xa, ldx = _addr_ld(X, allow_bf16=True)
+    ya, ldy = _addr_ld(Y, allow_bf16=True)
+    desc = PlsDesc(n=n, p=p, q=q, nlv=int(nlv), scal=int(bool(scal)), dtype=_lib.BF16 if bf16 else _lib.F64,
                    loc=_lib.LOC_DEVICE if dev else _lib.LOC_HOST, inplace=int(inplace), reserved=0)
     got = C.c_int32(0)
     if dev:
@@ -174,7 +177,7 @@ def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[C
     (the reference copies them first; here the library simply never writes them)."""
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
-        _addr_ld(X); _addr_ld(Y)
+        _addr_ld(X, allow_bf16=True); _addr_ld(Y, allow_bf16=True)   # bf16 tensors: storage mode of BASELINE configs[2]
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)   # layout/dtype conversion only
     return _fit("jch_plskern_fit", X, Y, weights, nlv, scal, False, ctx)
@@ -190,7 +193,7 @@ def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional
     """`plsnipals` — src/plsnipals.jl:31-35."""
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
-        _addr_ld(X); _addr_ld(Y)
+        _addr_ld(X, allow_bf16=True); _addr_ld(Y, allow_bf16=True)
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
     return _fit("jch_plsnipals_fit", X, Y, weights, nlv, scal, False, ctx)

@@ -197,3 +197,29 @@ def test_rccl_single_rank_plumbing(J):
     fm = J.plskern(X, Y, nlv=5, scal=True, ctx=c)
     _cmp(O.plskern(X, Y, nlv=5, scal=True), fm)
     c.close()
+
+
+@pytest.mark.parametrize("shape", [(20000, 500, 10, 25, False), (4099, 129, 3, 9, True), (3000, 1000, 1, 8, True)])
+def test_bf16_storage_mode(shape, J):
+    """BASELINE.json configs[2] (bf16 storage): oracle = the Float64 algorithm on the bf16-ROUNDED inputs
+    (SURVEY F6 / §8d).  Budget: 1e-3 on sign-aligned T, P, C; 1e-4 on B = R C' and predictions (measured ~1e-5)."""
+    import torch
+    n, p, q, nlv, scal = shape
+    X = CO.fill_uniform(20250112, n, p); Y = CO.fill_uniform(20250113, n, q)
+    w = 0.25 + O.splitmix64_uniform(7, 0, n) if scal else None
+    Xb = J.colmajor_empty(n, p, dtype=torch.bfloat16); Xb.copy_(torch.from_numpy(X))
+    Yb = J.colmajor_empty(n, q, dtype=torch.bfloat16); Yb.copy_(torch.from_numpy(Y))
+    Xq = Xb.to(torch.float64).cpu().numpy(); Yq = Yb.to(torch.float64).cpu().numpy()      # the rounded values
+    ref = CO.plskern(Xq, Yq, w, nlv=nlv, scal=scal)
+    tctx = J.Context(0, stream="torch")
+    fm = J.plskern(Xb, Yb, w, nlv=nlv, scal=scal, ctx=tctx)
+    T = fm.T.cpu().numpy()
+    s = O.sign_align(ref.W, fm.W)
+    errs = {f: O.rel_fro(getattr(ref, f), (T if f == "T" else getattr(fm, f)) * s) for f in ("T", "P", "C", "W", "R")}
+    errs["B"] = O.rel_fro(ref.R @ ref.C.T, fm.R @ fm.C.T)
+    assert O.rel_fro(ref.xmeans, fm.xmeans) < 1e-12 and O.rel_fro(ref.xscales, fm.xscales) < 1e-12   # fp64 from exact bf16 values
+    assert max(errs[f] for f in ("T", "P", "C", "W", "R")) < 1e-3, errs
+    assert errs["B"] < 1e-4, errs
+    with pytest.raises(J.JchError):
+        J.plsnipals(Xb, Yb, nlv=2, ctx=tctx)            # bf16 storage: plskern only, loud error otherwise
+    tctx.close()
