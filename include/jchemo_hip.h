@@ -127,6 +127,30 @@ JCH_API int32_t jch_affine_gemm(jch_ctx *ctx, int32_t loc, const double *X, int6
 JCH_API int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int64_t n, int64_t p, int64_t ldx,
                         const double *d, const double *shift, const double *scale, double *sstot);
 
+/*
+ * jch_lwplsr_predict — the prediction path of kNN-LWPLSR, batched over the m queries: replaces getknn
+ * (src/getknn.jl:29-57), the wdist weight loop (src/lwplsr.jl:152-159, src/wdist.jl:64-75) and locwlv
+ * (src/locwlv.jl:9-48, `Threads.@threads` over queries: one weighted plskern + 1-row predict per query).
+ *   Xtrain n x p, Ytrain n x 1, Xq m x p                                   [loc], column-major
+ *   Ztrain n x dd, Zq m x dd: the space the neighbours are searched in (global PLS scores, already whitened by
+ *     the host side for metric = "mahal": scores * inv(chol(cov).U), src/getknn.jl:37-49)      [loc]
+ *   k neighbours (clamped to n), h / tol: weight shape and floor; scal; nlv range nlv_lo..nlv_hi (contiguous)
+ *   pred  m x (nlv_hi - nlv_lo + 1), ROW-major per query: pred[i*le + a]                          [HOST]
+ *   ind_out (m x k, 0-based, row-major), dist_out, w_out (m x k): optional                       [HOST]
+ * q == 1 only in the batched kernel (other q: the host mirror loops jch_plskern_fit per query).
+ */
+JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
+                                   const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt,
+                                   const double *Zq, int64_t ldzq, int64_t dd, const double *Xq, int64_t m, int64_t ldxq,
+                                   int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi,
+                                   double *pred, int32_t *ind_out, double *dist_out, double *w_out);
+
+/* jch_weighted_cov — S = (A - 1 mu')' D (A - 1 mu') (d x d, d <= 64), D = diag(weights / sum); weights NULL = ones:
+ * `Statistics.cov(Xtrain, corrected = false)` of getknn's Mahalanobis branch (src/getknn.jl:38).  A n x d [loc];
+ * S (column-major d x d) and mu (d, may be NULL) HOST. */
+JCH_API int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, int64_t n, int64_t d, int64_t lda,
+                                 const double *weights, double *S, double *mu);
+
 /* ---- harness utilities (bench / tests) ---------------------------------------------------------- */
 /* Fill device matrix out (n x p, column-major ld) with rows [row0,row0+n) of the n_total x p matrix
  * whose element (i,j) is splitmix64-uniform(seed, i + j*n_total) — the README's `rand(n,p)` stand-in

@@ -1,0 +1,486 @@
+// kNN-LWPLSR prediction path (BASELINE.json configs[4]):
+//   K9  k_knn_weights   brute-force k nearest neighbours in a (whitened) score space + `wdist` weights
+//                       replaces getknn (src/getknn.jl:29-57: NearestNeighbors.BruteTree + knn(sorted)) and the
+//                       per-query weight loop of predict(::Lwplsr) (src/lwplsr.jl:152-159, src/wdist.jl:64-75,
+//                       mad: src/utility.jl:679)
+//   K8  k_locw_plskern  one workgroup per query: gather the k neighbour rows, weighted `plskern` on them and
+//                       the 1-row predictions for the whole nlv range
+//                       replaces locwlv (src/locwlv.jl:9-48: Threads.@threads over queries, plskern + predict per query)
+// The reference runs m independent small fits on CPU threads; here a query's whole fit lives in one workgroup:
+// its k x p block (0.8 MB at cfg5) is gathered once into an L2/MALL-resident scratch slab and swept once per LV.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "jch_internal.h"
+
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------- row-major copy of a column-major matrix
+__global__ __launch_bounds__(256) void k_to_rowmajor(const double *__restrict__ Xc, int64_t ldx, int64_t n, int p,
+                                                     double *__restrict__ Xr, int ldr)
+{
+    __shared__ double xt[64 * 65];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = blockIdx.y * 64;
+    const int64_t nchunks = (n + 63) / 64;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t i0 = c * 64;
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int col = wv + 4 * k, j = j0 + col;
+            const int64_t i = i0 + lane;
+            xt[lane * 65 + col] = (i < n && j < p) ? Xc[(size_t)i + (size_t)j * (size_t)ldx] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int row = wv + 4 * k, j = j0 + lane;
+            const int64_t i = i0 + row;
+            if (i < n && j < ldr) Xr[(size_t)i * ldr + j] = xt[row * 65 + lane];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- K9: kNN + weights
+#define KNN_QB 4       // queries per workgroup (each loaded training value serves 4 queries)
+#define KNN_CAP 1024   // candidate buffer per query (LDS); k <= KNN_CAP - 256
+
+// bitonic sort of KNN_CAP (key, idx) pairs in LDS, ascending by (key, idx); 256 threads
+__device__ static void bitonic_sort_cap(double *key, int *idx)
+{
+    const int tid = threadIdx.x;
+    for (int size = 2; size <= KNN_CAP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < KNN_CAP / 2; t += 256) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double a = key[lo], b = key[hi];
+                const int ia = idx[lo], ib = idx[hi];
+                const bool gt = (a > b) || (a == b && ia > ib) || (a != a && b == b);   // NaN sorts last
+                if (gt == up) { key[lo] = b; key[hi] = a; idx[lo] = ib; idx[hi] = ia; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct knn_args {
+    const double *Zt; int64_t ldzt; int64_t n;   // train scores, column-major n x dd
+    const double *Zq; int64_t ldzq; int m;       // query scores, column-major m x dd
+    int dd, k;
+    double h, cri, tol;
+    int *ind;      // [m][k]
+    double *dist;  // [m][k]
+    double *w;     // [m][k]
+};
+
+__global__ __launch_bounds__(256) void k_knn_weights(knn_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *bkey = lds;                                            // [QB][CAP]
+    int *bidx = reinterpret_cast<int *>(bkey + KNN_QB * KNN_CAP);  // [QB][CAP]
+    double *zq = reinterpret_cast<double *>(bidx + KNN_QB * KNN_CAP);  // [QB][dd]
+    double *tau = zq + KNN_QB * g.dd;                              // [QB]
+    int *cnt = reinterpret_cast<int *>(tau + KNN_QB);              // [QB]
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * KNN_QB;
+    const int nq = min(KNN_QB, g.m - q0);
+    for (int e = tid; e < KNN_QB * g.dd; e += 256) {
+        const int qq = e / g.dd, c = e - qq * g.dd;
+        zq[e] = qq < nq ? g.Zq[(size_t)(q0 + qq) + (size_t)c * (size_t)g.ldzq] : 0.0;
+    }
+    if (tid < KNN_QB) { tau[tid] = __builtin_inf(); cnt[tid] = 0; }
+    __syncthreads();
+    const int k = g.k;
+    for (int64_t base = 0; base < g.n; base += 256) {
+        const int64_t i = base + tid;
+        double d2[KNN_QB];
+#pragma unroll
+        for (int qq = 0; qq < KNN_QB; ++qq) d2[qq] = 0.0;
+        if (i < g.n) {
+            for (int c = 0; c < g.dd; ++c) {
+                const double x = g.Zt[(size_t)i + (size_t)c * (size_t)g.ldzt];
+#pragma unroll
+                for (int qq = 0; qq < KNN_QB; ++qq) { const double e = x - zq[qq * g.dd + c]; d2[qq] += e * e; }
+            }
+#pragma unroll
+            for (int qq = 0; qq < KNN_QB; ++qq)
+                if (qq < nq && (d2[qq] < tau[qq] || (d2[qq] == tau[qq] && cnt[qq] < k))) {
+                    const int pos = atomicAdd(&cnt[qq], 1);
+                    bkey[qq * KNN_CAP + pos] = d2[qq];
+                    bidx[qq * KNN_CAP + pos] = (int)i;
+                }
+        }
+        __syncthreads();
+        for (int qq = 0; qq < nq; ++qq) {
+            if (cnt[qq] > KNN_CAP - 256) {   // compact: keep the k best, raise the bar (block-uniform decision)
+                const int c0 = cnt[qq];
+                for (int e = c0 + tid; e < KNN_CAP; e += 256) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
+                bitonic_sort_cap(bkey + qq * KNN_CAP, bidx + qq * KNN_CAP);
+                if (tid == 0) { cnt[qq] = k; tau[qq] = bkey[qq * KNN_CAP + k - 1]; }
+                __syncthreads();
+            }
+        }
+    }
+    // final ordering + weights, one query at a time
+    for (int qq = 0; qq < nq; ++qq) {
+        const int c0 = cnt[qq];
+        for (int e = c0 + tid; e < KNN_CAP; e += 256) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
+        double *key = bkey + qq * KNN_CAP;
+        int *idx = bidx + qq * KNN_CAP;
+        bitonic_sort_cap(key, idx);
+        const int kk = min(k, c0);
+        int *oi = g.ind + (size_t)(q0 + qq) * k;
+        double *od = g.dist + (size_t)(q0 + qq) * k, *ow = g.w + (size_t)(q0 + qq) * k;
+        for (int e = tid; e < kk; e += 256) { oi[e] = idx[e]; key[e] = sqrt(key[e]); od[e] = key[e]; }
+        __syncthreads();
+        // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
+        const double med = (kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]);
+        __syncthreads();
+        // the distances are saved in the output array; |d - med| is sorted in place in the candidate buffer
+        for (int e = tid; e < KNN_CAP; e += 256) {
+            const double v = e < kk ? fabs(od[e] - med) : __builtin_inf();
+            key[e] = v;
+            idx[e] = e;
+        }
+        bitonic_sort_cap(key, idx);
+        const double zmad = 1.4826 * ((kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]));
+        const double cutoff = med + g.cri * zmad;
+        __syncthreads();
+        // weights; max with NaN propagation (Julia's `maximum` returns NaN if any NaN is present)
+        double wmax = -__builtin_inf();
+        bool anynan = false;
+        for (int e = 0; e < kk; ++e) {   // every thread scans the same k values: k <= 768, cheap and branch-uniform
+            const double dv = od[e];
+            const double wv = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
+            if (wv != wv) anynan = true;
+            if (wv > wmax) wmax = wv;
+        }
+        if (anynan) wmax = __builtin_nan("");
+        for (int e = tid; e < kk; e += 256) {
+            const double dv = od[e];
+            double wv = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
+            wv = wv / wmax;
+            if (wv != wv) wv = 1.0;
+            if (wv < g.tol) wv = g.tol;
+            ow[e] = wv;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- K8: batched local weighted plskern (q == 1)
+struct locw_args {
+    const double *Xrm; int ldr; int p;      // row-major training X (uncentred)
+    const double *Y; int64_t ldy;           // training y (column-major n x 1)
+    const double *Xq; int64_t ldxq; int m;  // queries, column-major m x p
+    const int *ind; const double *w; int k; // neighbours / weights [m][k]
+    int scal, nlv_lo, nlv_hi;
+    double *scratch; size_t slab;           // per-block slab: Xg [k][ldr], P [nlv][ldr], R [nlv][ldr]
+    double *pred;                           // [m][le]  (q == 1), le = nlv_hi - nlv_lo + 1
+};
+
+template <int KC>
+__global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = g.p, ldr = g.ldr, k = g.k;
+    double *dl = lds;                 // [k]   normalised weights
+    double *yc = dl + k;              // [k]   centred/scaled y
+    double *mu = yc + k;              // [ldr] local means
+    double *sg = mu + ldr;            // [ldr] local scales
+    double *Kv = sg + ldr;            // [ldr] kernel vector X'Dy (q = 1)
+    double *wv_ = Kv + ldr;           // [ldr] w
+    double *rv = wv_ + ldr;           // [ldr] r
+    double *xq = rv + ldr;            // [ldr] centred/scaled query
+    double *zred = xq + ldr;          // [4][KC*128]
+    double *sc = zred + 4 * KC * 128; // [128] scratch scalars; dots w.P_l at sc[64 + l]
+    int *idx = reinterpret_cast<int *>(sc + 128);  // [k]
+    double *Xg = g.scratch + (size_t)blockIdx.x * g.slab;
+    double *Pm = Xg + (size_t)k * ldr;
+    double *Rm = Pm + (size_t)g.nlv_hi * ldr;
+    const int le = g.nlv_hi - g.nlv_lo + 1;
+    const int nlvloc = min(min(k, p), g.nlv_hi);
+
+    for (int qi = blockIdx.x; qi < g.m; qi += gridDim.x) {
+        __syncthreads();
+        // ---- weights (mweight), neighbour ids, y
+        double s = 0.0;
+        for (int e = tid; e < k; e += 256) { idx[e] = g.ind[(size_t)qi * k + e]; s += g.w[(size_t)qi * k + e]; }
+        const double sw = jch_block_sum<256>(s, sc);
+        double sy = 0.0, ymin = __builtin_inf(), ymax = -__builtin_inf();
+        for (int e = tid; e < k; e += 256) {
+            const double d = g.w[(size_t)qi * k + e] / sw, y = g.Y[idx[e]];
+            dl[e] = d; yc[e] = y; sy += d * y;
+            ymin = fmin(ymin, y); ymax = fmax(ymax, y);
+        }
+        const double ymean = jch_block_sum<256>(sy, sc);
+        // constant-y shortcut (src/locwlv.jl:25-28)
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) { ymin = fmin(ymin, __shfl_xor(ymin, o, 64)); ymax = fmax(ymax, __shfl_xor(ymax, o, 64)); }
+        if (lane == 0) { sc[8 + wv] = ymin; sc[12 + wv] = ymax; }
+        __syncthreads();
+        const double gmin = fmin(fmin(sc[8], sc[9]), fmin(sc[10], sc[11])), gmax = fmax(fmax(sc[12], sc[13]), fmax(sc[14], sc[15]));
+        __syncthreads();
+        if (gmin == gmax) {
+            for (int a = tid; a < le; a += 256) g.pred[(size_t)qi * le + a] = gmin;
+            continue;
+        }
+        // ---- local weighted means / stds of X (thread per column; rows gathered from the row-major copy)
+        for (int j = tid; j < ldr; j += 256) {
+            double m1 = 0.0;
+            if (j < p)
+                for (int e = 0; e < k; ++e) m1 += dl[e] * g.Xrm[(size_t)idx[e] * ldr + j];
+            double sd = 1.0;
+            if (g.scal && j < p) {
+                double v = 0.0;
+                for (int e = 0; e < k; ++e) { const double z = g.Xrm[(size_t)idx[e] * ldr + j] - m1; v += dl[e] * z * z; }
+                sd = sqrt(v);
+            }
+            mu[j] = m1; sg[j] = sd;
+        }
+        double ysd = 1.0;
+        if (g.scal) {
+            double v = 0.0;
+            for (int e = tid; e < k; e += 256) { const double z = yc[e] - ymean; v += dl[e] * z * z; }
+            ysd = sqrt(jch_block_sum<256>(v, sc));
+        }
+        __syncthreads();
+        for (int e = tid; e < k; e += 256) yc[e] = g.scal ? (yc[e] - ymean) / ysd : yc[e] - ymean;
+        // ---- gather + centre/scale into the slab; centred query; K = X' D y
+        for (int e = wv; e < k; e += 4) {
+            const double *src = g.Xrm + (size_t)idx[e] * ldr;
+            double *dst = Xg + (size_t)e * ldr;
+            for (int j = lane; j < ldr; j += 64) dst[j] = j < p ? (g.scal ? (src[j] - mu[j]) / sg[j] : src[j] - mu[j]) : 0.0;
+        }
+        for (int j = tid; j < ldr; j += 256)
+            xq[j] = j < p ? (g.scal ? (g.Xq[(size_t)qi + (size_t)j * (size_t)g.ldxq] - mu[j]) / sg[j]
+                                    : g.Xq[(size_t)qi + (size_t)j * (size_t)g.ldxq] - mu[j]) : 0.0;
+        __syncthreads();
+        for (int j = tid; j < ldr; j += 256) {
+            double s2 = 0.0;
+            if (j < p)
+                for (int e = 0; e < k; ++e) s2 += (dl[e] * yc[e]) * Xg[(size_t)e * ldr + j];
+            Kv[j] = s2;
+        }
+        __syncthreads();
+        double predrun = ymean;   // nlv = 0: the intercept alone (src/plskern.jl:207-217 with B = 0)
+        if (tid == 0 && g.nlv_lo == 0) g.pred[(size_t)qi * le] = predrun;
+        // ---- LV loop (src/plskern.jl:149-175 with q == 1)
+        for (int a = 0; a < nlvloc; ++a) {
+            double s2 = 0.0;
+            for (int j = tid; j < p; j += 256) s2 += Kv[j] * Kv[j];
+            const double nrm = sqrt(jch_block_sum<256>(s2, sc));
+            for (int j = tid; j < ldr; j += 256) wv_[j] = j < p ? Kv[j] / nrm : 0.0;
+            __syncthreads();
+            for (int l = wv; l < a; l += 4) {   // dots w . P_l
+                double s3 = 0.0;
+                for (int j = lane; j < p; j += 64) s3 += wv_[j] * Pm[(size_t)l * ldr + j];
+                s3 = jch_wave_sum(s3);
+                if (lane == 0) sc[64 + l] = s3;
+            }
+            __syncthreads();
+            for (int j = tid; j < ldr; j += 256) {
+                double rj = wv_[j];
+                for (int l = 0; l < a; ++l) rj -= sc[64 + l] * Rm[(size_t)l * ldr + j];
+                rv[j] = j < p ? rj : 0.0;
+            }
+            __syncthreads();
+            // fused sweep over the gathered rows (same structure as k_sweep, sweep.hip)
+            v2f64 rf[KC], zp[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int col = 2 * lane + 128 * c;
+                rf[c] = col < ldr ? *reinterpret_cast<const v2f64 *>(rv + col) : v2f64{0.0, 0.0};
+                zp[c] = v2f64{0.0, 0.0};
+            }
+            double tt = 0.0;
+            for (int e = wv; e < k; e += 4) {
+                const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xg + (size_t)e * ldr) + lane;
+                v2f64 x[KC];
+                double s4 = 0.0;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    x[c] = (2 * lane + 128 * c < ldr) ? rp[64 * c] : v2f64{0.0, 0.0};
+                    s4 += x[c].x * rf[c].x + x[c].y * rf[c].y;
+                }
+                const double t = jch_wave_sum(s4);
+                const double dt = dl[e] * t;
+                tt += dt * t;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) { zp[c].x += dt * x[c].x; zp[c].y += dt * x[c].y; }
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * c) = zp[c];
+            if (lane == 0) sc[wv] = tt;
+            __syncthreads();
+            const double ttot = ((sc[0] + sc[1]) + sc[2]) + sc[3];
+            // c = K'r / tt ; tq = xq . r
+            double s5 = 0.0, s6 = 0.0;
+            for (int j = tid; j < p; j += 256) { s5 += Kv[j] * rv[j]; s6 += xq[j] * rv[j]; }
+            __syncthreads();
+            const double cc = jch_block_sum<256>(s5, sc) / ttot;
+            const double tq = jch_block_sum<256>(s6, sc + 32);
+            for (int j = tid; j < ldr; j += 256) {
+                const double z = ((zred[j] + zred[KC * 128 + j]) + zred[2 * KC * 128 + j]) + zred[3 * KC * 128 + j];
+                Kv[j] -= z * cc;
+                Pm[(size_t)a * ldr + j] = z / ttot;
+                Rm[(size_t)a * ldr + j] = rv[j];
+            }
+            predrun += tq * cc * ysd;
+            const int kk = a + 1;
+            if (tid == 0 && kk >= g.nlv_lo && kk <= g.nlv_hi) g.pred[(size_t)qi * le + (kk - g.nlv_lo)] = predrun;
+            __syncthreads();
+        }
+        // requested nlv beyond what the local model has: predict clamps to the model's nlv (src/plskern.jl:228-229)
+        for (int kk = nlvloc + 1 + tid; kk <= g.nlv_hi; kk += 256)
+            if (kk >= g.nlv_lo) g.pred[(size_t)qi * le + (kk - g.nlv_lo)] = predrun;
+    }
+}
+
+template <int KC>
+static int32_t launch_locw(jch_ctx *ctx, locw_args &g)
+{
+    const size_t lds = sizeof(double) * (2 * (size_t)g.k + 6 * (size_t)g.ldr + 4 * KC * 128 + 128) + sizeof(int) * (size_t)g.k + 64;
+    static bool attr = false;
+    if (!attr) {
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_locw_plskern<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k / p too large for the batched local-PLS kernel");
+    int nb = std::min(g.m, ctx->cus * 2);
+    g.slab = ((size_t)g.k * g.ldr + 2 * (size_t)g.nlv_hi * g.ldr + 31) & ~(size_t)31;
+    JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
+    g.scratch = (double *)ctx->xstage.ptr;
+    hipLaunchKernelGGL(k_locw_plskern<KC>, dim3(nb), dim3(256), lds, ctx->stream, g);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
+                                      const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt,
+                                      const double *Zq, int64_t ldzq, int64_t dd, const double *Xq, int64_t m, int64_t ldxq,
+                                      int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi,
+                                      double *pred, int32_t *ind_out, double *dist_out, double *w_out)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!Xtrain || !Ytrain || !Ztrain || !Zq || !Xq || !pred || n < 1 || p < 1 || m < 1 || dd < 1 || k < 1 || nlv_lo < 0 ||
+        nlv_hi < nlv_lo || ldx < n || ldy < n || ldzt < n || ldzq < m || ldxq < m)
+        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad arguments");
+    if (q != 1) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: the batched local-PLS kernel handles q == 1 (got q=%lld)", (long long)q);
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad loc");
+    if (p > JCH_SWEEP_MAXP) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: p > %d not supported", JCH_SWEEP_MAXP);
+    if (k > n) k = (int32_t)n;                                    // src/getknn.jl:33
+    if (k > KNN_CAP - 256) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k > %d not supported", KNN_CAP - 256);
+    if (nlv_hi > 48) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: nlv > 48 not supported");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const int ldr = ((int)p + 1) & ~1, le = nlv_hi - nlv_lo + 1;
+    // ---- stage host inputs
+    const double *dX = Xtrain, *dY = Ytrain, *dZt = Ztrain, *dZq = Zq, *dXq = Xq;
+    int64_t ldxd = ldx, ldyd = ldy, ldztd = ldzt, ldzqd = ldzq, ldxqd = ldxq;
+    if (loc == JCH_LOC_HOST) {
+        const size_t need = sizeof(double) * ((size_t)n * p + (size_t)n + (size_t)n * dd + (size_t)m * dd + (size_t)m * p);
+        JCH_TRY(jch_reserve(ctx, ctx->xq, need));
+        double *b = (double *)ctx->xq.ptr;
+        auto up = [&](const double *src, int64_t rows, int64_t cols, int64_t ld, const double *&dst, int64_t &ldd) -> int32_t {
+            if (ld == rows) JCH_HIP(ctx, hipMemcpyAsync(b, src, sizeof(double) * (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream));
+            else JCH_HIP(ctx, hipMemcpy2DAsync(b, sizeof(double) * rows, src, sizeof(double) * ld, sizeof(double) * rows, cols, hipMemcpyHostToDevice, ctx->stream));
+            dst = b; ldd = rows; b += (size_t)rows * cols;
+            return JCH_OK;
+        };
+        JCH_TRY(up(Xtrain, n, p, ldx, dX, ldxd)); JCH_TRY(up(Ytrain, n, 1, ldy, dY, ldyd)); JCH_TRY(up(Ztrain, n, dd, ldzt, dZt, ldztd));
+        JCH_TRY(up(Zq, m, dd, ldzq, dZq, ldzqd)); JCH_TRY(up(Xq, m, p, ldxq, dXq, ldxqd));
+    }
+    // ---- workspace: row-major X, neighbour lists, predictions
+    JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * ((size_t)m * k * 2 + (size_t)m * le) + sizeof(int) * (size_t)m * k + 256));
+    double *Xrm = (double *)ctx->xr.ptr;
+    double *ddist = (double *)ctx->gemm_out.ptr, *dw = ddist + (size_t)m * k, *dpred = dw + (size_t)m * k;
+    int *dind = (int *)(dpred + (size_t)m * le);
+    {
+        const int ptiles = (ldr + 63) / 64;
+        const int64_t nchunks = (n + 63) / 64;
+        int nbx = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, (ctx->cus * 4 + ptiles - 1) / ptiles));
+        hipLaunchKernelGGL(k_to_rowmajor, dim3(nbx, ptiles), dim3(256), 0, ctx->stream, dX, ldxd, n, (int)p, Xrm, ldr);
+    }
+    {
+        knn_args a;
+        a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
+        a.h = h; a.cri = 4.0; a.tol = tol; a.ind = dind; a.dist = ddist; a.w = dw;
+        const size_t lds = (sizeof(double) + sizeof(int)) * KNN_QB * KNN_CAP + sizeof(double) * (KNN_QB * (size_t)dd + KNN_QB) + sizeof(int) * KNN_QB + 64;
+        if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: score dimension %lld too large", (long long)dd);
+        static bool attr = false;
+        if (!attr) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_weights, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        hipLaunchKernelGGL(k_knn_weights, dim3((unsigned)((m + KNN_QB - 1) / KNN_QB)), dim3(256), lds, ctx->stream, a);
+    }
+    {
+        locw_args g;
+        g.Xrm = Xrm; g.ldr = ldr; g.p = (int)p; g.Y = dY; g.ldy = ldyd; g.Xq = dXq; g.ldxq = ldxqd; g.m = (int)m;
+        g.ind = dind; g.w = dw; g.k = k; g.scal = scal; g.nlv_lo = nlv_lo; g.nlv_hi = nlv_hi; g.pred = dpred;
+        g.scratch = nullptr; g.slab = 0;
+        if (ldr <= 128) JCH_TRY(launch_locw<1>(ctx, g));
+        else if (ldr <= 256) JCH_TRY(launch_locw<2>(ctx, g));
+        else if (ldr <= 512) JCH_TRY(launch_locw<4>(ctx, g));
+        else if (ldr <= 1024) JCH_TRY(launch_locw<8>(ctx, g));
+        else JCH_TRY(launch_locw<16>(ctx, g));
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le, hipMemcpyDeviceToHost, ctx->stream));
+    if (ind_out) JCH_HIP(ctx, hipMemcpyAsync(ind_out, dind, sizeof(int) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist_out) JCH_HIP(ctx, hipMemcpyAsync(dist_out, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+    if (w_out) JCH_HIP(ctx, hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JCH_OK;
+}
+
+// Weighted (uncorrected) covariance of the columns of A (n x d, d <= 64): S = (A - 1 mu')' D (A - 1 mu'), the
+// `Statistics.cov(Xtrain, corrected = false)` of getknn's Mahalanobis branch (src/getknn.jl:38).  Reuses K0/K1/K2
+// with Y = A.  S (d x d, column-major) and mu (d) on the HOST.
+extern "C" int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, int64_t n, int64_t d, int64_t lda,
+                                    const double *weights, double *S, double *mu)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!A || !S || n < 1 || d < 1 || d > JCH_MAXQ || lda < n) return jch_fail(ctx, JCH_EINVAL, "jch_weighted_cov: bad arguments (d <= %d)", JCH_MAXQ);
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_weighted_cov: bad loc");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const int dd = (int)d, ldr = (dd + 1) & ~1, qpad = ((dd + 15) / 16) * 16;
+    const double *dA = A, *dw = weights;
+    int64_t ldad = lda;
+    if (loc == JCH_LOC_HOST) {
+        JCH_TRY(jch_reserve(ctx, ctx->xq, sizeof(double) * ((size_t)n * d + (size_t)n)));
+        double *b = (double *)ctx->xq.ptr;
+        if (lda == n) JCH_HIP(ctx, hipMemcpyAsync(b, A, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, ctx->stream));
+        else JCH_HIP(ctx, hipMemcpy2DAsync(b, sizeof(double) * n, A, sizeof(double) * lda, sizeof(double) * n, d, hipMemcpyHostToDevice, ctx->stream));
+        dA = b; ldad = n;
+        if (weights) {
+            JCH_HIP(ctx, hipMemcpyAsync(b + (size_t)n * d, weights, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            dw = b + (size_t)n * d;
+        }
+    }
+    JCH_TRY(jch_reserve(ctx, ctx->dnorm, sizeof(double) * (size_t)n));
+    JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
+    JCH_TRY(jch_reserve(ctx, ctx->yr, sizeof(double) * (size_t)n * qpad));
+    JCH_TRY(jch_reserve(ctx, ctx->small, sizeof(double) * ((size_t)dd * qpad + 4 * (size_t)dd + 64) + 4096));
+    double *K = (double *)ctx->small.ptr, *mom = K + (size_t)dd * qpad, *scl = mom + 2 * dd, *hdr = scl + 2 * dd;
+    double *dn = (double *)ctx->dnorm.ptr;
+    JCH_TRY(jch_launch_weights(ctx, dw, n, dn, hdr));
+    JCH_TRY(jch_launch_moments(ctx, dA, ldad, dA, ldad, dn, n, dd, dd, nullptr, mom));
+    std::vector<double> ones(2 * (size_t)dd, 1.0);
+    JCH_HIP(ctx, hipMemcpyAsync(scl, ones.data(), sizeof(double) * 2 * dd, hipMemcpyHostToDevice, ctx->stream));
+    JCH_TRY(jch_launch_center_xty(ctx, const_cast<double *>(dA), ldad, const_cast<double *>(dA), ldad, dn, n, dd, dd, mom, scl, false,
+                                  (double *)ctx->xr.ptr, ldr, (double *)ctx->yr.ptr, qpad, K, false));
+    std::vector<double> hK((size_t)dd * qpad), hm(dd);
+    JCH_HIP(ctx, hipMemcpyAsync(hK.data(), K, sizeof(double) * hK.size(), hipMemcpyDeviceToHost, ctx->stream));
+    JCH_HIP(ctx, hipMemcpyAsync(hm.data(), mom, sizeof(double) * dd, hipMemcpyDeviceToHost, ctx->stream));
+    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < dd; ++i)
+        for (int j = 0; j < dd; ++j) S[i + (size_t)j * dd] = hK[(size_t)i * qpad + j];
+    if (mu) for (int i = 0; i < dd; ++i) mu[i] = hm[i];
+    return JCH_OK;
+}

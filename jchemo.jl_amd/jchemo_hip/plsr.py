@@ -257,6 +257,8 @@ def coef(fm: Plsr, *, nlv: Optional[int] = None):
 def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Optional[Context] = None):
     """src/plskern.jl:226-238: a collection of nlv becomes the contiguous range max(0,min):min(a,max); one
     value -> matrix, several -> list of matrices.  All values are computed in ONE pass over X."""
+    if isinstance(fm, Lwplsr):
+        return lwplsr_predict(fm, X, nlv=nlv, ctx=ctx)
     a = fm.P.shape[1]
     if nlv is None:
         rng = [a]
@@ -297,3 +299,124 @@ def summary(fm: Plsr, X, *, ctx: Optional[Context] = None):
     tt_adj = np.sum(fm.P ** 2, axis=0) * fm.TT
     pvar = tt_adj / ss.value
     return dict(nlv=np.arange(1, nlv + 1), var=tt_adj / n, pvar=pvar, cumpvar=np.cumsum(pvar))
+
+
+# ---------------------------------------------------------------------------------- kNN-LWPLSR (src/lwplsr.jl)
+@dataclass
+class Lwplsr:
+    """src/lwplsr.jl:1-12 — same fields."""
+    X: object
+    Y: object
+    fm: Optional[Plsr]
+    metric: str
+    h: float
+    k: int
+    nlv: int
+    tol: float
+    scal: bool
+    verbose: bool = False
+
+
+@dataclass
+class LwplsrPred:
+    """The NamedTuple returned by `predict(::Lwplsr, X)` (src/lwplsr.jl:165): pred is a matrix for one nlv, else a
+    list of matrices; listnn holds 0-based row indices (Julia: 1-based)."""
+    pred: object
+    listnn: np.ndarray
+    listd: np.ndarray
+    listw: np.ndarray
+
+
+def lwplsr(X, Y, *, nlvdis: int, metric: str, h: float, k: int, nlv: int, tol: float = 1e-4, scal: bool = False,
+           verbose: bool = False, ctx: Optional[Context] = None) -> Lwplsr:
+    """`lwplsr(X, Y; nlvdis, metric, h, k, nlv, tol = 1e-4, scal = false)` — src/lwplsr.jl:114-126: stores the data and
+    (nlvdis > 0) a global plskern fit whose scores define the neighbourhood space."""
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    if metric not in ("eucl", "mahal"):
+        raise ValueError(f"metric must be 'eucl' or 'mahal', got {metric!r}")
+    fm = None if nlvdis == 0 else plskern(X, Y, nlv=nlvdis, scal=scal, ctx=ctx)
+    return Lwplsr(X, Y, fm, metric, h, k, nlv, tol, scal, verbose)
+
+
+def _cov_uncorrected(A, ctx):
+    A = ensure_mat(A)
+    dev = _is_torch(A)
+    n, d = A.shape
+    S = np.empty((d, d), order="F")
+    aa, lda = _addr_ld(A)
+    if dev:
+        torch.cuda.current_stream(A.device).synchronize()
+    ctx.check(_lib.load().jch_weighted_cov(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, aa, n, d, lda, None, S.ctypes.data, None))
+    return S
+
+
+def _knn_space(obj: Lwplsr, Xq, ctx):
+    """The two matrices neighbours are searched in (src/lwplsr.jl:139-151 + the whitening of src/getknn.jl:37-49)."""
+    if obj.fm is None:
+        Zt, Zq = obj.X, Xq
+        try:
+            _addr_ld(Zt)
+        except (ValueError, TypeError):
+            Zt = _as_colmajor_copy(Zt)
+        if obj.scal:   # colstd(object.X) (unweighted) on both sides
+            xs = plskern(obj.X, obj.Y, nlv=1, scal=True, ctx=ctx).xscales
+            D = np.diag(1.0 / xs)
+            Zt, Zq = _affine(Zt, None, None, D, None, ctx), _affine(Zq, None, None, D, None, ctx)
+    else:
+        Zt, Zq = obj.fm.T, transform(obj.fm, Xq, ctx=ctx)
+    if obj.metric == "mahal":
+        d = Zt.shape[1]
+        if d > 64:
+            raise NotImplementedError("Mahalanobis neighbours in more than 64 dimensions are not supported (use nlvdis > 0)")
+        S = _cov_uncorrected(Zt, ctx)
+        if d == 1:
+            Uinv = np.array([[1.0 / np.sqrt(S[0, 0])]])
+        else:
+            try:
+                Uinv = np.linalg.inv(np.linalg.cholesky(S).T)        # inv(cholesky(S).U)
+            except np.linalg.LinAlgError:
+                Uinv = np.diag(1.0 / np.diag(S))                     # sic, src/getknn.jl:43
+        Zt, Zq = _affine(Zt, None, None, Uinv, None, ctx), _affine(Zq, None, None, Uinv, None, ctx)
+    return Zt, Zq
+
+
+def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None) -> LwplsrPred:
+    """`predict(object::Lwplsr, X; nlv)` — src/lwplsr.jl:134-166."""
+    X = ensure_mat(X)
+    try:
+        _addr_ld(X)
+    except (ValueError, TypeError):
+        X = _as_colmajor_copy(X)
+    Xt, Yt = obj.X, obj.Y
+    try:
+        _addr_ld(Xt); _addr_ld(Yt)
+    except (ValueError, TypeError):
+        Xt, Yt = _as_colmajor_copy(Xt), _as_colmajor_copy(Yt)
+    dev = _is_torch(X)
+    if dev != _is_torch(Xt):
+        raise TypeError("training data and queries must both be host arrays or both device tensors")
+    ctx = ctx or default_context((X.device.index or 0) if dev else 0)
+    a = obj.nlv
+    if nlv is None:
+        lo = hi = a
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        lo, hi = max(int(vals.min()), 0), min(int(vals.max()), a)
+    n, p = Xt.shape
+    m, q = X.shape[0], Yt.shape[1]
+    hi = min(hi, p)                                            # src/locwlv.jl:14
+    le = hi - lo + 1
+    k = min(obj.k, n)
+    Zt, Zq = _knn_space(obj, X, ctx)
+    if q != 1:
+        raise NotImplementedError("the batched local-PLS kernel handles q == 1; q > 1 is not wired yet")
+    pred = np.empty((m, le))
+    ind = np.empty((m, k), dtype=np.int32); dist = np.empty((m, k)); w = np.empty((m, k))
+    xa, ldx = _addr_ld(Xt); ya, ldy = _addr_ld(Yt); za, ldz = _addr_ld(Zt); qa, ldq = _addr_ld(Zq); xqa, ldxq = _addr_ld(X)
+    if dev:
+        torch.cuda.current_stream(X.device).synchronize()
+    ctx.check(_lib.load().jch_lwplsr_predict(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, ya, q, ldy, za, ldz,
+                                             qa, ldq, Zt.shape[1], xqa, m, ldxq, k, float(obj.h), float(obj.tol), int(obj.scal), lo, hi,
+                                             pred.ctypes.data, ind.ctypes.data, dist.ctypes.data, w.ctypes.data))
+    preds = [pred[:, i:i + 1].copy() for i in range(le)]
+    return LwplsrPred(preds[0] if le == 1 else preds, ind, dist, w)

@@ -335,3 +335,124 @@ def sign_align(ref_W: np.ndarray, new_W: np.ndarray) -> np.ndarray:
 def rel_fro(a: np.ndarray, b: np.ndarray) -> float:
     den = np.linalg.norm(a)
     return float(np.linalg.norm(a - b) / (den if den > 0 else 1.0))
+
+
+# --------------------------------------------------------------------------
+# kNN-LWPLSR (BASELINE.json configs[4])
+# --------------------------------------------------------------------------
+def mad(x) -> float:
+    """src/utility.jl:679 — 1.4826 * median(|x - median(x)|)."""
+    x = np.asarray(x, dtype=np.float64)
+    return 1.4826 * float(np.median(np.abs(x - np.median(x))))
+
+
+def wdist(d, *, h: float = 2.0, cri: float = 4.0, squared: bool = False) -> np.ndarray:
+    """src/wdist.jl:58-75."""
+    d = np.array(d, dtype=np.float64, copy=True)
+    if squared:
+        d = d ** 2
+    zmed = float(np.median(d))
+    zmad = mad(d)
+    cutoff = zmed + cri * zmad
+    with np.errstate(all="ignore"):
+        w = np.where(d <= cutoff, np.exp(-d / (h * zmad)), 0.0)
+        w = w / np.max(w)
+    w[np.isnan(w)] = 1.0
+    return w
+
+
+def getknn(Xtrain, X, *, k: int = 1, metric: str = "eucl"):
+    """src/getknn.jl:29-57 — brute-force k nearest neighbours, sorted by increasing distance (unsquared).
+    Returns (ind (m, k) 0-based, d (m, k)).  Ties are broken by index (NearestNeighbors leaves them arbitrary)."""
+    Xtrain = ensure_mat(Xtrain); X = ensure_mat(X)
+    n, p = Xtrain.shape
+    k = min(k, n)
+    if metric == "mahal":
+        S = np.cov(Xtrain, rowvar=False, bias=True).reshape(p, p)
+        if p == 1:
+            Uinv = np.array([[1.0 / np.sqrt(S[0, 0])]])
+        else:
+            try:
+                U = np.linalg.cholesky(S).T                      # S = U'U
+                Uinv = np.linalg.inv(U)
+            except np.linalg.LinAlgError:
+                Uinv = np.diag(1.0 / np.diag(S))                 # sic (getknn.jl:43)
+        Xtrain = Xtrain @ Uinv
+        X = X @ Uinv
+    elif metric != "eucl":
+        raise ValueError(metric)
+    ind = np.empty((X.shape[0], k), dtype=np.int64)
+    dist = np.empty((X.shape[0], k))
+    for i in range(X.shape[0]):
+        d2 = np.sum((Xtrain - X[i]) ** 2, axis=1)
+        order = np.lexsort((np.arange(n), d2))[:k]
+        ind[i] = order
+        dist[i] = np.sqrt(d2[order])
+    return ind, dist
+
+
+def locwlv(Xtrain, Ytrain, X, *, listnn, listw=None, nlv, scal: bool = False):
+    """src/locwlv.jl:9-48 with fun = plskern.  Returns pred (m, q, le_nlv) for nlv = max(0,min):min(p,max)."""
+    Xtrain = ensure_mat(Xtrain); Ytrain = ensure_mat(Ytrain); X = ensure_mat(X)
+    p = Xtrain.shape[1]; m = X.shape[0]; q = Ytrain.shape[1]
+    vals = np.atleast_1d(np.asarray(nlv))
+    rng = list(range(max(0, int(vals.min())), min(p, int(vals.max())) + 1))
+    zpred = np.empty((m, q, len(rng)))
+    for i in range(m):
+        s = np.asarray(listnn[i])
+        zY = Ytrain[s, :]
+        if q == 1 and len(np.unique(zY)) == 1:
+            zpred[i, :, :] = zY[0, 0]
+            continue
+        w = None if listw is None else listw[i]
+        fm = plskern(Xtrain[s, :], zY, w, nlv=max(rng), scal=scal)
+        for a, kk in enumerate(rng):
+            zpred[i, :, a] = predict(fm, X[i:i + 1, :], nlv=kk)[0]
+    return zpred, rng
+
+
+@dataclass
+class Lwplsr:
+    """src/lwplsr.jl:1-12."""
+    X: np.ndarray
+    Y: np.ndarray
+    fm: Optional[Plsr]
+    metric: str
+    h: float
+    k: int
+    nlv: int
+    tol: float
+    scal: bool
+
+
+def lwplsr(X, Y, *, nlvdis: int, metric: str, h: float, k: int, nlv: int, tol: float = 1e-4, scal: bool = False) -> Lwplsr:
+    """src/lwplsr.jl:114-126."""
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    fm = None if nlvdis == 0 else plskern(X, Y, nlv=nlvdis, scal=scal)
+    return Lwplsr(np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64), fm, metric, h, k, nlv, tol, scal)
+
+
+def lwplsr_predict(obj: Lwplsr, X, *, nlv=None):
+    """src/lwplsr.jl:134-166.  Returns dict(pred (m,q,le) , rng, listnn, listd, listw)."""
+    X = ensure_mat(X)
+    a = obj.nlv
+    if nlv is None:
+        rng_req = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng_req = list(range(max(int(vals.min()), 0), min(int(vals.max()), a) + 1))
+    if obj.fm is None:
+        if obj.scal:
+            xs = np.sqrt(colvar(obj.X, np.ones(obj.X.shape[0])))
+            ind, d = getknn(obj.X / xs, X / xs, k=obj.k, metric=obj.metric)
+        else:
+            ind, d = getknn(obj.X, X, k=obj.k, metric=obj.metric)
+    else:
+        ind, d = getknn(obj.fm.T, transform(obj.fm, X), k=obj.k, metric=obj.metric)
+    listw = np.empty_like(d)
+    for i in range(d.shape[0]):
+        w = wdist(d[i], h=obj.h)
+        w[w < obj.tol] = obj.tol
+        listw[i] = w
+    pred, rng = locwlv(obj.X, obj.Y, X, listnn=ind, listw=listw, nlv=rng_req, scal=obj.scal)
+    return dict(pred=pred, rng=rng, listnn=ind, listd=d, listw=listw)

@@ -223,3 +223,42 @@ def test_bf16_storage_mode(shape, J):
     with pytest.raises(J.JchError):
         J.plsnipals(Xb, Yb, nlv=2, ctx=tctx)            # bf16 storage: plskern only, loud error otherwise
     tctx.close()
+
+
+@pytest.mark.parametrize("case", [dict(n=2000, p=60, m=41, k=50, nlvdis=8, nlv=6, metric="mahal", scal=False, h=1.0),
+                                  dict(n=1500, p=33, m=10, k=40, nlvdis=5, nlv=9, metric="eucl", scal=True, h=2.0),
+                                  dict(n=20000, p=500, m=48, k=200, nlvdis=20, nlv=15, metric="mahal", scal=False, h=1.0)])
+def test_lwplsr_predict(case, J, ctx):
+    """BASELINE.json configs[4] shape (last case: cfg5 with fewer rows/queries): kNN in the (whitened) global-score
+    space, wdist weights, one weighted local plskern per query, predictions for nlv = 0..nlv (src/lwplsr.jl:134-166)."""
+    c = case
+    X = CO.fill_uniform(20250112, c["n"], c["p"])
+    y = (X[:, :5] @ np.array([1.0, -2.0, 0.5, 3.0, 1.5]) + np.sin(3 * X[:, 5]) + 0.05 * CO.fill_uniform(20250113, c["n"], 1)[:, 0])
+    Xq = CO.fill_uniform(20250115, c["m"], c["p"])
+    kw = dict(nlvdis=c["nlvdis"], metric=c["metric"], h=c["h"], k=c["k"], nlv=c["nlv"], scal=c["scal"])
+    ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, c["nlv"] + 1))
+    fm = J.lwplsr(X, y, ctx=ctx, **kw)
+    res = J.predict(fm, Xq, nlv=range(0, c["nlv"] + 1), ctx=ctx)
+    # neighbours: identical sets in identical order (ties have measure zero for these inputs); distances / weights
+    same = np.mean(res.listnn == ref["listnn"])
+    assert same > 0.999, same
+    assert O.rel_fro(ref["listd"], res.listd) < 1e-9
+    assert O.rel_fro(ref["listw"], res.listw) < 1e-7
+    pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)            # m x le
+    assert pred.shape == ref["pred"][:, 0, :].shape
+    assert O.rel_fro(ref["pred"][:, 0, :], pred) < 1e-7
+    one = J.predict(fm, Xq, nlv=3, ctx=ctx)
+    assert isinstance(one.pred, np.ndarray) and O.rel_fro(ref["pred"][:, 0, 3], one.pred[:, 0]) < 1e-7
+
+
+def test_lwplsr_constant_neighbourhood(J, ctx):
+    """q == 1 and all neighbour y equal -> that constant for every nlv (src/locwlv.jl:25-28)."""
+    n, p = 300, 12
+    X = O.rand_matrix(1, n, p)
+    y = np.where(X[:, 0] > 0.5, 2.0, -1.0)
+    fm = J.lwplsr(X, y, nlvdis=0, metric="eucl", h=1.0, k=5, nlv=3, ctx=ctx)
+    Xq = X[:7] + 1e-9
+    ref = O.lwplsr_predict(O.lwplsr(X, y, nlvdis=0, metric="eucl", h=1.0, k=5, nlv=3), Xq, nlv=range(0, 4))
+    res = J.predict(fm, Xq, nlv=range(0, 4), ctx=ctx)
+    pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)
+    assert np.allclose(pred, ref["pred"][:, 0, :], rtol=1e-8, atol=1e-10)
