@@ -147,3 +147,33 @@ def test_sharded_equals_unsharded():
     assert O.rel_fro(ref.T, np.vstack(sh.T) * s) < 1e-11
     for f in ("P", "R", "W", "C"):
         assert O.rel_fro(getattr(ref, f), getattr(sh, f) * s) < 1e-11
+
+
+def test_lwplsr_oracle_pieces():
+    """Pins the kNN-LWPLSR restatement (src/getknn.jl, src/wdist.jl, src/locwlv.jl) against third-party code."""
+    from scipy.spatial.distance import cdist
+    from sklearn.neighbors import NearestNeighbors
+    Xt = O.rand_matrix(1, 300, 6); Xq = O.rand_matrix(2, 9, 6)
+    ind, d = O.getknn(Xt, Xq, k=7, metric="eucl")
+    nn = NearestNeighbors(n_neighbors=7, algorithm="brute").fit(Xt)
+    d2, i2 = nn.kneighbors(Xq)
+    assert np.array_equal(ind, i2) and np.allclose(d, d2, rtol=1e-12)
+    ind, d = O.getknn(Xt, Xq, k=7, metric="mahal")
+    VI = np.linalg.inv(np.cov(Xt, rowvar=False, bias=True))
+    D = cdist(Xq, Xt, "mahalanobis", VI=VI)
+    assert np.array_equal(ind, np.argsort(D, axis=1)[:, :7]) and np.allclose(d, np.sort(D, axis=1)[:, :7], rtol=1e-9)
+    assert O.getknn(Xt, Xq, k=10_000)[0].shape == (9, 300)                       # k clamped to n (getknn.jl:33)
+    # wdist: max weight 1 at the smallest distance, zero beyond median + 4 MAD, NaN -> 1 for identical distances
+    dd = np.array([0.1, 0.2, 0.25, 0.3, 5.0])
+    w = O.wdist(dd, h=2.0)
+    assert w[0] == 1.0 and w[-1] == 0.0 and np.all(np.diff(w) <= 0)
+    assert np.allclose(w[:4], np.exp(-dd[:4] / (2.0 * O.mad(dd))) / np.exp(-dd[0] / (2.0 * O.mad(dd))))
+    assert np.all(O.wdist(np.full(5, 0.3)) == 1.0)
+    # locwlv: the prediction for nlv = 0 is the weighted neighbour mean; more LVs reduce the training residual
+    X = O.rand_matrix(3, 200, 8); y = X[:, 0] - 2 * X[:, 1] + 0.01 * O.rand_matrix(4, 200, 1)[:, 0]
+    fm = O.lwplsr(X, y, nlvdis=0, metric="eucl", h=2.0, k=30, nlv=4)
+    r = O.lwplsr_predict(fm, X[:20], nlv=range(0, 5))
+    w0 = r["listw"][0] / r["listw"][0].sum()
+    assert abs(r["pred"][0, 0, 0] - w0 @ y[r["listnn"][0]]) < 1e-12
+    err = [np.abs(r["pred"][:, 0, a] - y[:20]).mean() for a in range(5)]
+    assert err[4] < err[0] * 0.2
