@@ -171,7 +171,9 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     const int nlv = (int)std::min<int64_t>(std::min<int64_t>(n_total, p), d.nlv);
     // small-state fast path (smallstate_fast.hip): everything in LDS, q <= 16
     const bool fast = q <= 16 && nlv <= 1024 && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
-    const int max_slices = (fast && ctx->nranks == 1) ? JCH_ZT_SLICES : 1;
+    // the fast small-state kernel sums the second-stage slices itself; with several GPUs the [slices][ldz] block is
+    // all-reduced as one message (still latency-bound at 32 KB) instead of being collapsed by an extra launch
+    const int max_slices = fast ? JCH_ZT_SLICES : 1;
     int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
     JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
@@ -187,11 +189,11 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (algo == 0) {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
-            JCH_TRY(jch_allreduce_f64(ctx, s.zt, (size_t)ldr + 1));  // ONE collective per LV: [zp (p), tt]
+            JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1));  // ONE collective per LV: [zp (p), tt]
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
         } else {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
-            JCH_TRY(jch_allreduce_f64(ctx, s.zt, (size_t)ldr + 1 + qpad));  // [zp_raw, tt, c_raw]
+            JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1 + qpad));  // [zp_raw, tt, c_raw]
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast));
             const bool last = a + 1 == nlv;
             if (!last || inplace) {

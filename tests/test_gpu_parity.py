@@ -262,3 +262,55 @@ def test_lwplsr_constant_neighbourhood(J, ctx):
     res = J.predict(fm, Xq, nlv=range(0, 4), ctx=ctx)
     pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)
     assert np.allclose(pred, ref["pred"][:, 0, :], rtol=1e-8, atol=1e-10)
+
+
+def test_full_size_cfg2_vs_oracle(J):
+    """BASELINE.json configs[1] at FULL size (n = 1e6, p = 500, q = 10, nlv = 25, Float64, device-resident): the
+    north-star parity statement itself — sign-aligned T, P, C within 1e-6 relative Frobenius of the CPU oracle on
+    the same seeded inputs — plus size-independent invariants computed on the device."""
+    import torch
+    n, p, q, nlv = 1_000_000, 500, 10, 25
+    tctx = J.Context(0, stream="torch")
+    lib = J.load()
+    X = J.colmajor_empty(n, p); Y = J.colmajor_empty(n, q)
+    tctx.check(lib.jch_fill_uniform(tctx._h, X.data_ptr(), n, p, n, 0, n, 20250112))
+    tctx.check(lib.jch_fill_uniform(tctx._h, Y.data_ptr(), n, q, n, 0, n, 20250113))
+    fm = J.plskern(X, Y, nlv=nlv, ctx=tctx)
+    T, d = fm.T, fm.weights
+    # invariants on the device (SURVEY §4.1): T'DT = diag(TT), R'P = I, ||w|| = 1, T = Xc R on a row sample
+    G = (T.t() @ (d[:, None] * T)).cpu().numpy()
+    assert np.abs(G - np.diag(fm.TT)).max() < 1e-9 * fm.TT.max()
+    assert np.abs(fm.R.T @ fm.P - np.eye(nlv)).max() < 1e-8
+    assert np.abs(np.linalg.norm(fm.W, axis=0) - 1).max() < 1e-12
+    rows = torch.arange(0, n, 997, device="cuda")
+    Xs = X[rows].cpu().numpy() - fm.xmeans
+    assert O.rel_fro(Xs @ fm.R, T[rows].cpu().numpy()) < 1e-9
+    # the oracle on identical inputs (host generator == device generator, tests above)
+    Xh = CO.fill_uniform(20250112, n, p); Yh = CO.fill_uniform(20250113, n, q)
+    ref = CO.plskern_(Xh, Yh, None, nlv=nlv)
+    s = O.sign_align(ref.W, fm.W)
+    errs = {"T": O.rel_fro(ref.T, T.cpu().numpy() * s), "P": O.rel_fro(ref.P, fm.P * s), "C": O.rel_fro(ref.C, fm.C * s),
+            "R": O.rel_fro(ref.R, fm.R * s), "B": O.rel_fro(ref.R @ ref.C.T, fm.R @ fm.C.T)}
+    print("cfg2 full-size parity:", {k_: f"{v:.2e}" for k_, v in errs.items()})
+    assert max(errs.values()) < TOL, errs
+    tctx.close()
+
+
+def test_cfg4_shape_plsnipals_structured(J, ctx):
+    """BASELINE.json configs[3] shape (plsnipals, p = 2000, q = 1, nlv = 50) at n = 20000 on spectra-like inputs
+    (60 latent sources + noise: on iid columns PLS1 runs out of Krylov directions after ~10 LVs and every
+    implementation returns rounding noise)."""
+    n, p, nlv, r = 20000, 2000, 50, 60
+    S = CO.fill_uniform(1, n, r); L = CO.fill_uniform(2, r, p)
+    X = np.asfortranarray(S @ L + 0.1 * CO.fill_uniform(3, n, p))
+    y = np.asfortranarray((S[:, :8] @ np.arange(1.0, 9.0) + 0.05 * CO.fill_uniform(4, n, 1)[:, 0]).reshape(-1, 1))
+    ref = CO.plsnipals(X, y, nlv=nlv)
+    fm = J.plsnipals(X, y, nlv=nlv, ctx=ctx)
+    s = O.sign_align(ref.W, fm.W)
+    errs = {f: O.rel_fro(getattr(ref, f), getattr(fm, f) * s) for f in FIELDS}
+    assert ref.TT.min() > 1e-9 * ref.TT.max(), "test data ill-posed"
+    assert max(errs.values()) < TOL, errs
+    Xg, yg = X.copy(order="F"), y.copy(order="F")
+    Xo, yo = X.copy(order="F"), y.copy(order="F")
+    CO.plsnipals_(Xo, yo, nlv=nlv); J.plsnipals_(Xg, yg, nlv=nlv, ctx=ctx)      # deflated X, Y (north star: "deflated X")
+    assert O.rel_fro(Xo, Xg) < TOL and O.rel_fro(yo, yg) < TOL
