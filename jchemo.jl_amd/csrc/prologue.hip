@@ -5,6 +5,9 @@
 // Input X, Y are column-major (Julia); the working copy Xr is ROW-major (ld = ldr, even, pad column zero)
 // so the per-LV sweep streams whole rows.  K2 is the one real tall-skinny GEMM of the fit and runs on
 // v_mfma_f64_16x16x4_f64 (A = X tile^T, B = d.*Y tile, N = q padded to 16).
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "jch_internal.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -60,7 +63,7 @@ template <bool VAR>
 __global__ __launch_bounds__(256) void k_moments(const double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
                                                   int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                   int64_t chunk, const double *__restrict__ means,
-                                                  double *__restrict__ colpart)
+                                                  double *__restrict__ colpart, int aligned16)
 {
     __shared__ double sc[4];
     const int j = blockIdx.x;
@@ -69,6 +72,25 @@ __global__ __launch_bounds__(256) void k_moments(const double *__restrict__ Xc, 
     const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
     const double m = VAR ? means[j] : 0.0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (aligned16) {   // 16-B loads: two consecutive rows per lane
+        typedef double v2 __attribute__((ext_vector_type(2)));
+        int64_t i = i0 + 2 * threadIdx.x;
+        for (; i + 1536 + 1 < i1; i += 2048) {
+            v2 a0 = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(col + i)), a1 = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(col + i + 512)),
+               a2 = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(col + i + 1024)), a3 = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(col + i + 1536));
+            const v2 d0 = *reinterpret_cast<const v2 *>(d + i), d1 = *reinterpret_cast<const v2 *>(d + i + 512),
+                     d2 = *reinterpret_cast<const v2 *>(d + i + 1024), d3 = *reinterpret_cast<const v2 *>(d + i + 1536);
+            if (VAR) { a0 -= m; a1 -= m; a2 -= m; a3 -= m; a0 *= a0; a1 *= a1; a2 *= a2; a3 *= a3; }
+            s0 += d0.x * a0.x; s0 += d0.y * a0.y; s1 += d1.x * a1.x; s1 += d1.y * a1.y;
+            s2 += d2.x * a2.x; s2 += d2.y * a2.y; s3 += d3.x * a3.x; s3 += d3.y * a3.y;
+        }
+        for (; i < i1; i += 512) {
+            double a0 = col[i], a1 = i + 1 < i1 ? col[i + 1] : 0.0;
+            if (VAR) { a0 -= m; a0 *= a0; a1 = i + 1 < i1 ? (a1 - m) * (a1 - m) : 0.0; }
+            s0 += d[i] * a0;
+            if (i + 1 < i1) s0 += d[i + 1] * a1;
+        }
+    } else {
     int64_t i = i0 + threadIdx.x;
     for (; i + 768 < i1; i += 1024) {
         double a0 = __builtin_nontemporal_load(col + i), a1 = __builtin_nontemporal_load(col + i + 256),
@@ -81,6 +103,7 @@ __global__ __launch_bounds__(256) void k_moments(const double *__restrict__ Xc, 
         double a0 = col[i];
         if (VAR) { a0 -= m; a0 *= a0; }
         s0 += d[i] * a0;
+    }
     }
     double s = jch_block_sum<256>((s0 + s1) + (s2 + s3), sc);
     if (threadIdx.x == 0) colpart[(size_t)blockIdx.y * (size_t)(p + q) + j] = s;
@@ -117,12 +140,15 @@ int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const do
     if (S < 1) S = 1;
     JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * (size_t)S * m + 4096 * sizeof(double)));
     double *colpart = (double *)ctx->colpart.ptr;
+    // 16-B loads need every column start 16-B aligned (chunk is a multiple of 256 rows)
+    const int al16 = (ldx % 2 == 0) && ((uintptr_t)Xc % 16 == 0) && (q == 0 || ((ldy % 2 == 0) && ((uintptr_t)Yc % 16 == 0))) &&
+                     ((uintptr_t)d % 16 == 0) && !getenv("JCH_K1_V1");
     if (means)
         hipLaunchKernelGGL(k_moments<true>, dim3(m, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk,
-                           means, colpart);
+                           means, colpart, al16);
     else
         hipLaunchKernelGGL(k_moments<false>, dim3(m, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk,
-                           means, colpart);
+                           means, colpart, al16);
     hipLaunchKernelGGL(k_colreduce, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, colpart, S, m, 0, out);
     JCH_TRY(jch_allreduce_f64(ctx, out, (size_t)m));
     if (means && do_sqrt) hipLaunchKernelGGL(k_sqrt_inplace, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, out, m);
@@ -142,7 +168,7 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
                                                      int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                      const double *__restrict__ mom, const double *__restrict__ scl,
                                                      double *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
-                                                     double *__restrict__ Kpart, int kp_rows)
+                                                     double *__restrict__ Kpart, int kp_rows, int dbg_skip)
 {
     __shared__ double xt[64 * XT_LD];
     __shared__ double yt[64 * YT_LD];
@@ -215,7 +241,7 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
             }
         }
         // ---- row-major store (y group 0 only): (row wv+4k, col lane)
-        if (yg == 0) {
+        if (yg == 0 && !(dbg_skip & 2)) {
 #pragma unroll 4
             for (int k = 0; k < 16; ++k) {
                 const int row = wv + 4 * k, j = j0 + lane;
@@ -225,12 +251,14 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
         }
         // ---- XtY on the matrix cores: wave wv owns columns j0+16wv .. +15
         //      A[m = x column][k = row] , B[k = row][n = y column]; lane l: (k = l>>4, m|n = l&15)
+        if (!(dbg_skip & 1)) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int row = 4 * kk + (lane >> 4);
             const double a = xt[row * XT_LD + 16 * wv + (lane & 15)];
             const double b = yt[row * YT_LD + (lane & 15)];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
         }
         __syncthreads();
     }
@@ -239,6 +267,114 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int j = j0 + 16 * wv + (lane >> 4) + 4 * reg;
+        if (j < kp_rows) kp[(size_t)j * qpad + yg * 16 + (lane & 15)] = acc[reg];
+    }
+}
+
+// ---- K2, 16-byte variant (used when the column-major input is 16-B aligned with an even ld): tile = 128 rows x 32
+// columns, every global access is 16 B per lane (8-B accesses reach only ~0.55-0.7 of the 16-B rate on this part;
+// the 64x64 / 8-B kernel above is the fallback for odd leading dimensions).
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+#define X2_LD 34
+template <bool WRITEBACK, bool SCAL>
+__global__ __launch_bounds__(256) void k_center_xty_v2(double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
+                                                        int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
+                                                        const double *__restrict__ mom, const double *__restrict__ scl,
+                                                        double *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
+                                                        double *__restrict__ Kpart, int kp_rows)
+{
+    __shared__ __attribute__((aligned(16))) double xt[128 * X2_LD];
+    __shared__ double yt[128 * YT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = blockIdx.y * 32;
+    const int yg = blockIdx.z;
+    const int64_t nchunks = (n + 127) / 128;
+    double cm[8], cs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = j0 + wv + 4 * k;
+        cm[k] = j < p ? mom[j] : 0.0;
+        cs[k] = (SCAL && j < p) ? scl[j] : 1.0;
+    }
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    v2f64 xr[8];
+    int64_t c = blockIdx.x;
+    auto prefetch = [&](int64_t cc) {
+        const int64_t i = cc * 128 + 2 * lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = j0 + wv + 4 * k;
+            if (j < p && i + 1 < n) xr[k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(Xc + (size_t)i + (size_t)j * (size_t)ldx));
+            else if (j < p && i < n) xr[k] = v2f64{Xc[(size_t)i + (size_t)j * (size_t)ldx], 0.0};
+            else xr[k] = v2f64{0.0, 0.0};
+        }
+    };
+    if (c < nchunks) prefetch(c);
+    for (; c < nchunks; c += gridDim.x) {
+        const int64_t i0 = c * 128;
+        // ---- Y tile: 128 rows x 16 cols
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + 256 * k, row = e & 127, col = e >> 7;
+            const int yc = yg * 16 + col;
+            const int64_t i = i0 + row;
+            double v = 0.0, dv = 0.0;
+            if (i < n && yc < q) {
+                v = Yc[(size_t)i + (size_t)yc * (size_t)ldy] - mom[p + yc];
+                if (SCAL) v /= scl[p + yc];
+                dv = d[i];
+            }
+            if (blockIdx.y == 0 && i < n) Yr[(size_t)i * qpad + yc] = v;
+            yt[row * YT_LD + col] = dv * v;
+        }
+        // ---- X tile: centre/scale the prefetched registers into LDS (and back into the caller's array)
+        {
+            const int64_t i = i0 + 2 * lane;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int col = wv + 4 * k, j = j0 + col;
+                v2f64 v = v2f64{0.0, 0.0};
+                if (j < p) {
+                    if (i < n) v.x = SCAL ? (xr[k].x - cm[k]) / cs[k] : xr[k].x - cm[k];
+                    if (i + 1 < n) v.y = SCAL ? (xr[k].y - cm[k]) / cs[k] : xr[k].y - cm[k];
+                    if (WRITEBACK && yg == 0) {
+                        if (i + 1 < n) *reinterpret_cast<v2f64 *>(Xc + (size_t)i + (size_t)j * (size_t)ldx) = v;
+                        else if (i < n) Xc[(size_t)i + (size_t)j * (size_t)ldx] = v.x;
+                    }
+                }
+                xt[(2 * lane) * X2_LD + col] = v.x;
+                xt[(2 * lane + 1) * X2_LD + col] = v.y;
+            }
+        }
+        __syncthreads();
+        if (c + gridDim.x < nchunks) prefetch(c + gridDim.x);
+        // ---- row-major store (y group 0 only): 16 lanes x 16 B per row, 4 rows per wave-instruction
+        if (yg == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = 16 * k + 4 * wv + (lane >> 4), cp = 2 * (lane & 15), j = j0 + cp;
+                const int64_t i = i0 + row;
+                if (i < n && j < ldr)
+                    __builtin_nontemporal_store(*reinterpret_cast<const v2f64 *>(xt + row * X2_LD + cp),
+                                                reinterpret_cast<v2f64 *>(Xr + (size_t)i * ldr + j));
+            }
+        }
+        // ---- XtY: wave wv owns column group (wv & 1) over the row half (wv >> 1)
+        {
+            const int cg = wv & 1, rh = wv >> 1;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int row = 64 * rh + 4 * kk + (lane >> 4);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[row * X2_LD + 16 * cg + (lane & 15)], yt[row * YT_LD + (lane & 15)], acc,
+                                                           0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    double *kp = Kpart + ((size_t)(blockIdx.x * 2 + (wv >> 1)) * kp_rows) * qpad;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int j = j0 + 16 * (wv & 1) + (lane >> 4) + 4 * reg;
         if (j < kp_rows) kp[(size_t)j * qpad + yg * 16 + (lane & 15)] = acc[reg];
     }
 }
@@ -258,25 +394,42 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                               int p, int q, const double *mom, const double *scl, bool writeback, double *Xr, int ldr,
                               double *Yr, int qpad, double *K, bool scal)
 {
-    const int ptiles = (ldr + 63) / 64;
-    const int kp_rows = ptiles * 64;
+    // measured (cfg2): the 128x32 / 16-B tile is 1.1 ms SLOWER than the 64x64 / 8-B tile (its 256-B row segments are
+    // mostly partial 128-B lines); kept behind JCH_K2_V2 for experiments only
+    const bool v2 = (ldx % 2 == 0) && (((uintptr_t)Xc) % 16 == 0) && getenv("JCH_K2_V2");
+    const int tw = v2 ? 32 : 64, th = v2 ? 128 : 64;   // tile width (columns) / height (rows)
+    const int ptiles = (ldr + tw - 1) / tw;
+    const int kp_rows = ptiles * tw;
     const int ygroups = qpad / 16;
-    const int64_t nchunks = (n + 63) / 64;
+    const int64_t nchunks = (n + th - 1) / th;
     int nbx = (ctx->cus * 3 + ptiles * ygroups - 1) / (ptiles * ygroups);
     if (nbx < 1) nbx = 1;
     if (nbx > nchunks) nbx = (int)(nchunks > 0 ? nchunks : 1);
-    JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * qpad));
+    const int nslots = v2 ? 2 * nbx : nbx;             // v2: two row halves per block accumulate separately
+    JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nslots * kp_rows * qpad));
     double *Kpart = (double *)ctx->kpart.ptr;
     dim3 grid(nbx, ptiles, ygroups);
     const bool wb_fused = writeback && ygroups == 1;
+    static int dbg_skip = -1;
+    if (dbg_skip < 0) { const char *e = getenv("JCH_K2_SKIP"); dbg_skip = e ? atoi(e) : 0; }
+    if (v2) {
+#define JCH_K2V2(WB, SC) hipLaunchKernelGGL((k_center_xty_v2<WB, SC>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
+                                            mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows)
+        if (wb_fused && scal) JCH_K2V2(true, true);
+        else if (wb_fused) JCH_K2V2(true, false);
+        else if (scal) JCH_K2V2(false, true);
+        else JCH_K2V2(false, false);
+#undef JCH_K2V2
+    } else {
 #define JCH_K2(WB, SC) hipLaunchKernelGGL((k_center_xty<WB, SC>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
-                                          mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows)
-    if (wb_fused && scal) JCH_K2(true, true);
-    else if (wb_fused) JCH_K2(true, false);
-    else if (scal) JCH_K2(false, true);
-    else JCH_K2(false, false);
+                                          mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip)
+        if (wb_fused && scal) JCH_K2(true, true);
+        else if (wb_fused) JCH_K2(true, false);
+        else if (scal) JCH_K2(false, true);
+        else JCH_K2(false, false);
 #undef JCH_K2
-    hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad,
+    }
+    hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nslots, kp_rows, p, qpad,
                        K);
     JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
     JCH_HIP(ctx, hipGetLastError());

@@ -15,7 +15,7 @@ module JchemoHIP
 
 using LinearAlgebra
 
-export Plsr, plskern, plskern!, plsnipals, plsnipals!, transform, coef, predict, summary_plsr, JchCtx
+export Plsr, Lwplsr, plskern, plskern!, plsnipals, plsnipals!, lwplsr, transform, coef, predict, summary_plsr, JchCtx
 
 const LIB = get(ENV, "JCHEMO_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libjchemo_hip.so"))
 
@@ -177,6 +177,51 @@ function summary_plsr(object::Plsr, X; ctx = default_ctx())
     tt_adj = vec(sum(object.P .^ 2, dims = 1)) .* object.TT
     pvar = tt_adj / ss[]
     (explvarx = (nlv = 1:nlv, var = tt_adj / n, pvar = pvar, cumpvar = cumsum(pvar)),)
+end
+
+# ---- kNN-LWPLSR (src/lwplsr.jl) -------------------------------------------------------------------
+struct Lwplsr                     # same fields as the reference's struct (src/lwplsr.jl:1-12)
+    X; Y; fm; metric::String; h::Real; k::Int; nlv::Int; tol::Real; scal::Bool; verbose::Bool
+end
+
+"`lwplsr(X, Y; nlvdis, metric, h, k, nlv, tol = 1e-4, scal = false)` — src/lwplsr.jl:114-126."
+function lwplsr(X, Y; nlvdis, metric, h, k, nlv, tol = 1e-4, scal = false, verbose = false, ctx = default_ctx())
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    fm = nlvdis == 0 ? nothing : plskern(X, Y; nlv = nlvdis, scal = scal, ctx = ctx)
+    Lwplsr(X, Y, fm, metric, h, k, nlv, tol, scal, verbose)
+end
+
+function _cov(A, ctx)             # Statistics.cov(A, corrected = false) on the device (src/getknn.jl:38)
+    n, d = size(A); S = zeros(d, d)
+    GC.@preserve A check(ctx, ccall((:jch_weighted_cov, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, _loc(A), pointer(A), n, d, stride(A, 2), C_NULL, S, C_NULL))
+    S
+end
+
+"`predict(object::Lwplsr, X; nlv)` — src/lwplsr.jl:134-166: neighbours, weights and the m local fits in one call."
+function predict(object::Lwplsr, X; nlv = nothing, ctx = default_ctx())
+    X = ensure_mat(X); m = size(X, 1); n, p = size(object.X); q = size(object.Y, 2)
+    a = object.nlv
+    rng = nlv === nothing ? (a:a) : (max(minimum(nlv), 0):min(maximum(nlv), a, p))
+    Zt, Zq = object.fm === nothing ? (object.X, X) : (object.fm.T, transform(object.fm, X; ctx = ctx))
+    if object.metric == "mahal"
+        S = _cov(Zt, ctx); d = size(S, 1)
+        Uinv = d == 1 ? fill(1 / sqrt(S[1, 1]), 1, 1) : (isposdef(S) ? Matrix(inv(cholesky(Hermitian(S)).U)) : Matrix(Diagonal(1 ./ diag(S))))
+        Zt = _affine(Zt, nothing, nothing, Uinv, nothing, ctx); Zq = _affine(Zq, nothing, nothing, Uinv, nothing, ctx)
+    end
+    k = min(object.k, n); le = length(rng)
+    pred = zeros(le, m); ind = zeros(Int32, k, m); dist = zeros(k, m); w = zeros(k, m)   # row-major per query == Julia columns
+    Xt = object.X; Yt = object.Y
+    GC.@preserve Xt Yt Zt Zq X check(ctx, ccall((:jch_lwplsr_predict, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
+         Int64, Ptr{Float64}, Int64, Int64, Int32, Float64, Float64, Int32, Int32, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, _loc(Xt), pointer(Xt), n, p, stride(Xt, 2), pointer(Yt), q, max(stride(Yt, 2), n), pointer(Zt), stride(Zt, 2),
+        pointer(Zq), stride(Zq, 2), size(Zt, 2), pointer(X), m, stride(X, 2), k, object.h, object.tol, object.scal ? 1 : 0,
+        first(rng), last(rng), pred, ind, dist, w))
+    preds = [reshape(pred[i, :], m, 1) for i in 1:le]
+    (pred = le == 1 ? preds[1] : preds, listnn = [Int.(ind[:, i]) .+ 1 for i in 1:m], listd = [dist[:, i] for i in 1:m],
+     listw = [w[:, i] for i in 1:m])
 end
 
 end # module
