@@ -29,9 +29,9 @@ int32_t validate(jch_ctx *ctx, const fit_io &io, const char *who)
     if (d->n < 1 || d->p < 1 || d->q < 1) return jch_fail(ctx, JCH_EINVAL, "%s: empty input (n=%lld p=%lld q=%lld)", who,
                                                          (long long)d->n, (long long)d->p, (long long)d->q);
     if (d->q > JCH_MAXQ) return jch_fail(ctx, JCH_EINVAL, "%s: q=%lld > %d not supported", who, (long long)d->q, JCH_MAXQ);
-    if (d->p > JCH_SWEEP_MAXP)
-        return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld > %d not supported by the fused sweep yet", who, (long long)d->p,
-                        JCH_SWEEP_MAXP);
+    if (d->p > JCH_SWEEP_MAXP && d->dtype != JCH_F64)
+        return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld > %d is supported for Float64 only", who, (long long)d->p, JCH_SWEEP_MAXP);
+    if (d->p > (1 << 20)) return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld too large", who, (long long)d->p);
     if (d->nlv < 1) return jch_fail(ctx, JCH_EINVAL, "%s: nlv=%d must be >= 1", who, d->nlv);
     if (d->dtype != JCH_F64 && d->dtype != JCH_BF16) return jch_fail(ctx, JCH_EINVAL, "%s: unknown dtype %d", who, d->dtype);
     if (d->dtype == JCH_BF16 && (d->loc != JCH_LOC_DEVICE || d->inplace))
@@ -130,7 +130,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
     if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
         if (algo != 0) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
-        const bool fastb = q <= 16 && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
+        const bool fastb = q <= 16 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
         hipEvent_t evb = jch_ev(ctx);
         int nlvb = 0;
         JCH_TRY(jch_fit_plskern_bf16(ctx, d, io.X, io.ldx, io.Y, io.ldy, wdev, dn, Tdev, s, ldr, qpad, ldz, fastb, &nlvb));
@@ -170,7 +170,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     }
     const int nlv = (int)std::min<int64_t>(std::min<int64_t>(n_total, p), d.nlv);
     // small-state fast path (smallstate_fast.hip): everything in LDS, q <= 16
-    const bool fast = q <= 16 && nlv <= 1024 && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
+    const bool fast = q <= 16 && nlv <= 1024 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
     // the fast small-state kernel sums the second-stage slices itself; with several GPUs the [slices][ldz] block is
     // all-reduced as one message (still latency-bound at 32 KB) instead of being collapsed by an extra launch
     const int max_slices = fast ? JCH_ZT_SLICES : 1;

@@ -208,5 +208,7 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
     if (ldr <= 1024) JCH_SWEEP_CASE(8, 2);
     if (ldr <= 2048) JCH_SWEEP_CASE(16, 1);
 #undef JCH_SWEEP_CASE
-    return jch_fail(ctx, JCH_EINVAL, "fused sweep supports p <= %d (got ld %d)", JCH_SWEEP_MAXP, ldr);
+    // wider rows: two-pass fallback (sweep_wide.hip), single reduced vector
+    *nslice_out = 1;
+    return jch_launch_sweep_wide(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt);
 }
