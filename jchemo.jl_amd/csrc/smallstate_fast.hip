@@ -175,9 +175,10 @@ __device__ static bool dominant_by_squaring(int q, int lda, const double *G, dou
     int extra = -1, it = 0;
     bool ok = false;
     for (; it < 24; ++it) {
-        double t = 0.0;
+        double tp[4] = {0.0, 0.0, 0.0, 0.0};   // 4 partial sums: short dependent chains (one wave alone on its SIMD)
 #pragma unroll
-        for (int k = 0; k < QP; ++k) t += A[k * lda + k];
+        for (int k = 0; k < QP; ++k) tp[k & 3] += A[k * lda + k];
+        const double t = (tp[0] + tp[1]) + (tp[2] + tp[3]);
         // A = (previous A)^2 / tr(previous A)^2, so t = sum(lambda^2)/(sum lambda)^2 -> 1 as A -> rank one
         if (it > 0 && extra < 0 && (1.0 - t) < 1e-12) extra = 1;   // then ONE more squaring: rho ~5e-13 -> ~1e-25
         if (extra == 0) { ok = true; break; }
@@ -189,10 +190,10 @@ __device__ static bool dominant_by_squaring(int q, int lda, const double *G, dou
         for (int s = 0; s < NS; ++s) {
             const int k1 = k1s[s] < 0 ? 0 : k1s[s], k2 = k2s[s];
             const double *ra = A + k1 * lda, *rb = A + k2 * lda;
-            double acc = 0.0;
+            double ap[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < QP; ++k) acc += ra[k] * rb[k];
-            acc *= isc2;
+            for (int k = 0; k < QP; ++k) ap[k & 3] += ra[k] * rb[k];
+            const double acc = ((ap[0] + ap[1]) + (ap[2] + ap[3])) * isc2;
             if (k1s[s] >= 0) {
                 Bn[k1 * lda + k2] = acc;
                 Bn[k2 * lda + k1] = acc;
@@ -413,7 +414,33 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     if (!g.do_b) { JCH_STAMP(15); return; }
 
     // ------------------------------------------------------------------ phase B
-    if (q > 1) {
+    if constexpr (QP == 16) {
+        // Gram G = K'K on the matrix cores: v_mfma_f64_16x16x4 with A = B^T = a 4-row slab of K (the SAME register
+        // is both operands: lane l holds K[j0 + (l>>4)][l&15]); each wave takes every 8th slab, partials combined in LDS.
+        typedef double v4f64 __attribute__((ext_vector_type(4)));
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int j0 = 4 * wv; j0 < p; j0 += 4 * (FT / 64)) {
+            const int row = j0 + (lane >> 4);
+            const double x = Kl[min(row, p - 1) * ldk + (lane & 15)];
+            const double xz = row < p ? x : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xz, xz, acc, 0, 0, 0);
+        }
+        double *gsc = csl + 2 * (QP + 2) + 8;   // [FT/64][256]
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) gsc[wv * 256 + reg * 64 + lane] = acc[reg];
+        __syncthreads();
+        JCH_STAMP(5);
+        if (tid < 256) {
+            double t = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < FT / 64; ++w8) t += gsc[w8 * 256 + tid];
+            const int reg = tid >> 6, l = tid & 63;
+            const int m = (l >> 4) + 4 * reg, nn = l & 15;    // D[m][n]: n = lane&15, m = (lane>>4) + 4 reg
+            G0[m * lda + nn] = t;
+        }
+        __syncthreads();
+        JCH_STAMP(6);
+    } else if (q > 1) {
         // Gram G = K'K: upper entries e -> (k1, k2), rows split over FT/64 groups
         const int nent = q * (q + 1) / 2;
         const int el = tid & 63, gr = tid >> 6;
@@ -531,7 +558,7 @@ size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv)
     const int QP = q <= 1 ? 1 : (q <= 2 ? 2 : (q <= 4 ? 4 : (q <= 8 ? 8 : 16)));
     const int ldk = QP | 1, lda = QP + 2;
     return sizeof(double) * ((size_t)p * ldk + (ldr + 18) + 2 * (size_t)ldr + 2 * FT + 32 + ((nlv + 1) & ~1) + (size_t)nlv * QP +
-                             5 * (size_t)QP * lda + 2 * (QP + 2) + 8);
+                             5 * (size_t)QP * lda + 2 * (QP + 2) + 8 + (QP == 16 ? (FT / 64) * 256 : 0));
 }
 
 int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
