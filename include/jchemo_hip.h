@@ -151,6 +151,14 @@ JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtra
 JCH_API int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, int64_t n, int64_t d, int64_t lda,
                                  const double *weights, double *S, double *mu);
 
+/* jch_score_sums — sufficient statistics of prediction scores over the rows selected by `mask` (NULL = all rows), per
+ * prediction column c = level * q + k:  sums[c*6 + 0..5] = { sum e, sum e^2, sum y e, sum y, sum y^2, row count },
+ * e = y - pred.  msep / rmsep / ssr / bias / r2 / cor2 (src/scores.jl:25-32,54-62,155-158,190-196,268,426-429) follow on
+ * the host; this is what gridscorelv / gridcvlv (src/gridscore.jl:167-221, src/gridcv.jl:187-228) evaluate per nlv.
+ *   Pred m x ncol (ncol multiple of q), Y m x q, mask m [loc]; sums ncol x 6 HOST. */
+JCH_API int32_t jch_score_sums(jch_ctx *ctx, int32_t loc, const double *Pred, int64_t m, int64_t ncol, int64_t ldp,
+                               const double *Y, int64_t q, int64_t ldy, const double *mask, double *sums);
+
 /* ---- harness utilities (bench / tests) ---------------------------------------------------------- */
 /* Fill device matrix out (n x p, column-major ld) with rows [row0,row0+n) of the n_total x p matrix
  * whose element (i,j) is splitmix64-uniform(seed, i + j*n_total) — the README's `rand(n,p)` stand-in

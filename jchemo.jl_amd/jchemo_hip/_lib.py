@@ -24,7 +24,7 @@ SYMBOLS = (
     "jch_version", "jch_ctx_create", "jch_ctx_destroy", "jch_last_error", "jch_comm_unique_id",
     "jch_ctx_comm_init", "jch_ctx_comm_info", "jch_plskern_fit", "jch_plsnipals_fit", "jch_affine_gemm",
     "jch_weighted_ss", "jch_fill_uniform", "jch_ctx_set_profiling", "jch_ctx_get_profile", "jch_lwplsr_predict",
-    "jch_weighted_cov",
+    "jch_weighted_cov", "jch_score_sums",
 )
 
 
@@ -73,6 +73,7 @@ def load():
     L.jch_lwplsr_predict.argtypes = [vp, i32, dp, i64, i64, i64, dp, i64, i64, dp, i64, dp, i64, i64, dp, i64, i64, i32,
                                      C.c_double, C.c_double, i32, i32, i32, dp, dp, dp, dp]
     L.jch_weighted_cov.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp]
+    L.jch_score_sums.argtypes = [vp, i32, dp, i64, i64, i64, dp, i64, i64, dp, dp]
     L.jch_fill_uniform.argtypes = [vp, dp, i64, i64, i64, i64, i64, C.c_uint64]
     L.jch_ctx_set_profiling.argtypes = [vp, i32]
     L.jch_ctx_get_profile.argtypes = [vp, C.POINTER(Profile)]

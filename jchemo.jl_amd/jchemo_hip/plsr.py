@@ -420,3 +420,152 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None) -
                                              pred.ctypes.data, ind.ctypes.data, dist.ctypes.data, w.ctypes.data))
     preds = [pred[:, i:i + 1].copy() for i in range(le)]
     return LwplsrPred(preds[0] if le == 1 else preds, ind, dist, w)
+
+
+# ---------------------------------------------------------------------------------- scores / grid search (§8f rank 1)
+def _score_sums(pred, Y, mask, ctx):
+    """Device statistics of jch_score_sums: returns array (levels, q, 6)."""
+    pred = ensure_mat(pred); Y = ensure_mat(Y)
+    try:
+        _addr_ld(pred)
+    except (ValueError, TypeError):
+        pred = _as_colmajor_copy(pred)
+    try:
+        _addr_ld(Y)
+    except (ValueError, TypeError):
+        Y = _as_colmajor_copy(Y)
+    dev = _is_torch(pred)
+    if dev != _is_torch(Y):
+        raise TypeError("pred and Y must both be host arrays or both device tensors")
+    m, ncol = pred.shape
+    q = Y.shape[1]
+    if Y.shape[0] != m or ncol % q:
+        raise ValueError("DimensionMismatch between predictions and Y")
+    ctx = ctx or default_context((pred.device.index or 0) if dev else 0)
+    pa, ldp = _addr_ld(pred); ya, ldy = _addr_ld(Y)
+    ma = None
+    if mask is not None:
+        mask = mask if _is_torch(mask) == dev else (torch.as_tensor(np.asarray(mask, dtype=np.float64), device=pred.device) if dev else mask.cpu().numpy())
+        mask = mask.to(torch.float64).contiguous() if dev else np.ascontiguousarray(mask, dtype=np.float64)
+        ma = mask.data_ptr() if dev else mask.ctypes.data
+    sums = np.empty((ncol, 6))
+    if dev:
+        torch.cuda.current_stream(pred.device).synchronize()
+    ctx.check(_lib.load().jch_score_sums(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, pa, m, ncol, ldp, ya, q, ldy, ma, sums.ctypes.data))
+    return sums.reshape(ncol // q, q, 6)
+
+
+def _score_from_sums(name: str, S: np.ndarray) -> np.ndarray:
+    """S: (levels, q, 6) = {sum e, sum e^2, sum y e, sum y, sum y^2, count}.  Formulas: src/scores.jl."""
+    se, see, sye, sy, syy, cnt = (S[..., i] for i in range(6))
+    if name == "ssr":
+        return see
+    if name == "msep":
+        return see / cnt
+    if name == "rmsep":
+        return np.sqrt(see / cnt)
+    if name == "bias":
+        return -se / cnt
+    if name == "r2":
+        return 1 - (see / cnt) / (syy / cnt - (sy / cnt) ** 2)
+    if name == "cor2":
+        sp, spp, spy = sy - se, syy - 2 * sye + see, syy - sye        # sums of pred, pred^2, pred*y
+        cov = spy / cnt - (sp / cnt) * (sy / cnt)
+        return cov ** 2 / ((spp / cnt - (sp / cnt) ** 2) * (syy / cnt - (sy / cnt) ** 2))
+    raise ValueError(name)
+
+
+def _make_score(name):
+    def score(pred, Y, *, ctx: Optional[Context] = None):
+        return _score_from_sums(name, _score_sums(pred, Y, None, ctx))[0].reshape(1, -1)
+    score.__name__ = name
+    score.__doc__ = f"`{name}(pred, Y)` — src/scores.jl; 1 x q, computed from device-side sums."
+    score._jch_name = name
+    return score
+
+
+msep, rmsep, ssr, bias, r2, cor2 = (_make_score(nm) for nm in ("msep", "rmsep", "ssr", "bias", "r2", "cor2"))
+
+
+def segmkf(n: int, K: int, *, rep: int = 1, seed=None):
+    """src/segm.jl:44-57 — K-fold segments (0-based indices), `rep` replications."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(rep):
+        perm = rng.permutation(n)
+        out.append([np.sort(perm[j::K]) for j in range(K)])
+    return out
+
+
+def segmts(n: int, m: int, *, rep: int = 1, seed=None):
+    """src/segm.jl:135-149 — one test segment of m rows per replication."""
+    rng = np.random.default_rng(seed)
+    return [[np.sort(rng.choice(n, size=m, replace=False))] for _ in range(rep)]
+
+
+def _nlv_range(nlv, p):
+    vals = np.atleast_1d(np.asarray(nlv))
+    return list(range(max(0, int(vals.min())), min(p, int(vals.max())) + 1))
+
+
+def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, ctx: Optional[Context] = None, **kwargs):
+    """`gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv)` — src/gridscore.jl:167-221 (pars = nothing): one fit at
+    max(nlv), predictions for the whole range in ONE pass over X, scores from device-side sums.
+    Returns dict(nlv=[...], res=(le_nlv, q))."""
+    if pars is not None:
+        raise NotImplementedError("pars grids are not wired yet")
+    rng = _nlv_range(nlv, ensure_mat(Xtrain).shape[1])
+    fm = fun(Xtrain, Ytrain, nlv=max(rng), ctx=ctx, **kwargs)
+    name = getattr(score, "_jch_name", None)
+    if name is None:   # arbitrary user score(pred, Y): evaluated on what predict returns
+        pred = predict(fm, X, nlv=rng, ctx=ctx)
+        pred = [pred] if len(rng) == 1 else pred
+        return dict(nlv=rng, res=np.vstack([np.asarray(score(pr, Y)).reshape(1, -1) for pr in pred]))
+    q = fm.C.shape[0]
+    Bs, ints = zip(*(coef(fm, nlv=k) for k in rng))
+    P = _affine(X, None, None, np.concatenate(Bs, axis=1), np.concatenate([i.reshape(-1) for i in ints]), ctx)
+    return dict(nlv=rng, res=_score_from_sums(name, _score_sums(P, Y, None, ctx)))
+
+
+def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] = None, **kwargs):
+    """`gridcvlv(X, Y; segm, score, fun, nlv)` — src/gridcv.jl:187-228 (pars = nothing).  The reference copies
+    rmrow(X, s) for every segment; here X stays where it is and each fold is ONE weighted fit with weight 0 on the
+    held-out rows (identical means / XtY / loadings), whose scores T on the held-out rows already are their
+    transformed rows: predictions for every nlv are T[:, :a] * C[:, :a]' — a GEMM on the n x nlv scores, no second
+    pass over X.  Returns dict(nlv, res (le, q) mean over folds, res_rep (nrep, nsegm, le, q))."""
+    if pars is not None:
+        raise NotImplementedError("pars grids are not wired yet")
+    name = getattr(score, "_jch_name", None)
+    if name is None or fun not in (plskern, plsnipals):
+        raise NotImplementedError("gridcvlv: score must be one of msep/rmsep/ssr/bias/r2/cor2 and fun plskern/plsnipals")
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    try:
+        _addr_ld(X); _addr_ld(Y)
+    except (ValueError, TypeError):
+        X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
+    dev = _is_torch(X)
+    n, p = X.shape
+    q = Y.shape[1]
+    rng = _nlv_range(nlv, p)
+    rep_out = []
+    for listsegm in segm:
+        zres = []
+        for s in listsegm:
+            s = np.asarray(s)
+            held = np.zeros(n); held[s] = 1.0
+            w = 1.0 - held
+            if dev:
+                held = torch.as_tensor(held, device=X.device); w = torch.as_tensor(w, device=X.device)
+            kfit = min(max(rng), n - len(s))                                   # the reference clamps with the TRAINING rows
+            fm = fun(X, Y, w, nlv=kfit, ctx=ctx, **kwargs)
+            k = fm.P.shape[1]
+            # B_c[l, a*q + j] = C[j, l] * yscale_j for l < min(a, k); bias = ymeans
+            Bc = np.zeros((k, len(rng) * q))
+            for ai, a in enumerate(rng):
+                kk = min(a, k)
+                Bc[:kk, ai * q:(ai + 1) * q] = (fm.C[:, :kk] * fm.yscales[:, None]).T
+            Pm = _affine(fm.T, None, None, Bc, np.tile(fm.ymeans, len(rng)), ctx)
+            zres.append(_score_from_sums(name, _score_sums(Pm, Y, held, ctx)))
+        rep_out.append(np.stack(zres))
+    res_rep = np.stack(rep_out)
+    return dict(nlv=rng, res=res_rep.mean(axis=(0, 1)), res_rep=res_rep)

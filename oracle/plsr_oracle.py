@@ -456,3 +456,84 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None):
         listw[i] = w
     pred, rng = locwlv(obj.X, obj.Y, X, listnn=ind, listw=listw, nlv=rng_req, scal=obj.scal)
     return dict(pred=pred, rng=rng, listnn=ind, listd=d, listw=listw)
+
+
+# --------------------------------------------------------------------------
+# Validation / tuning helpers: scores, segments, gridscorelv, gridcvlv
+# --------------------------------------------------------------------------
+def residreg(pred, Y):
+    """src/scores.jl:241."""
+    return ensure_mat(Y) - ensure_mat(pred)
+
+
+def msep(pred, Y):
+    """src/scores.jl:155-158."""
+    return np.mean(residreg(pred, Y) ** 2, axis=0).reshape(1, -1)
+
+
+def rmsep(pred, Y):
+    """src/scores.jl:268."""
+    return np.sqrt(msep(pred, Y))
+
+
+def ssr(pred, Y):
+    """src/scores.jl:426-429."""
+    return np.sum(residreg(pred, Y) ** 2, axis=0).reshape(1, -1)
+
+
+def bias(pred, Y):
+    """src/scores.jl:25-28."""
+    return (-np.mean(residreg(pred, Y), axis=0)).reshape(1, -1)
+
+
+def r2(pred, Y):
+    """src/scores.jl:190-196."""
+    Y = ensure_mat(Y)
+    M = np.tile(Y.mean(axis=0), (Y.shape[0], 1))
+    return 1 - msep(pred, Y) / msep(M, Y)
+
+
+def cor2(pred, Y):
+    """src/scores.jl:54-62."""
+    pred = ensure_mat(pred); Y = ensure_mat(Y)
+    return np.array([[np.corrcoef(pred[:, k], Y[:, k])[0, 1] ** 2 for k in range(Y.shape[1])]])
+
+
+def rmrow(X, s):
+    """src/utility.jl:1020-1023 (s: 0-based indices here)."""
+    keep = np.setdiff1d(np.arange(np.asarray(X).shape[0]), np.asarray(s))
+    return np.asarray(X)[keep]
+
+
+def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None):
+    """src/gridscore.jl:167-221 with pars = nothing: fit once at max(nlv), predict for the whole (clamped) range,
+    score each.  Returns (nlv values, res (le_nlv, q))."""
+    assert pars is None
+    Xtrain = ensure_mat(Xtrain); Ytrain = ensure_mat(Ytrain)
+    p = Xtrain.shape[1]
+    vals = np.atleast_1d(np.asarray(nlv))
+    rng = list(range(max(0, int(vals.min())), min(p, int(vals.max())) + 1))
+    fm = fun(Xtrain, Ytrain, nlv=max(rng))
+    pred = predict(fm, X, nlv=rng)
+    pred = [pred] if len(rng) == 1 else pred
+    res = np.vstack([score(pr, Y) for pr in pred])
+    return rng, res
+
+
+def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None):
+    """src/gridcv.jl:187-228 with pars = nothing.  segm: list (replications) of lists (segments) of 0-based row
+    indices.  Returns (nlv values, res = mean over all (repl, segm) (le_nlv, q), res_rep (nrep, nsegm, le_nlv, q))."""
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    p = X.shape[1]
+    vals = np.atleast_1d(np.asarray(nlv))
+    rng = list(range(max(0, int(vals.min())), min(p, int(vals.max())) + 1))
+    rep = []
+    for listsegm in segm:
+        zres = []
+        for s in listsegm:
+            s = np.asarray(s)
+            _, r = gridscorelv(rmrow(X, s), rmrow(Y, s), X[s, :], Y[s, :], score=score, fun=fun, nlv=rng)
+            zres.append(r)
+        rep.append(np.stack(zres))
+    res_rep = np.stack(rep)
+    return rng, res_rep.mean(axis=(0, 1)), res_rep

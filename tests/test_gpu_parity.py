@@ -312,3 +312,40 @@ def test_cfg4_shape_plsnipals_structured(J, ctx):
     Xo, yo = X.copy(order="F"), y.copy(order="F")
     CO.plsnipals_(Xo, yo, nlv=nlv); J.plsnipals_(Xg, yg, nlv=nlv, ctx=ctx)      # deflated X, Y (north star: "deflated X")
     assert O.rel_fro(Xo, Xg) < TOL and O.rel_fro(yo, yg) < TOL
+
+
+def test_scores_and_gridscorelv(J, ctx):
+    """§8f rank 1: scores from device-side sums and gridscorelv == the oracle (src/scores.jl, src/gridscore.jl:167-221)."""
+    n, p, q, m = 3000, 40, 3, 700
+    X = CO.fill_uniform(1, n, p); Xt = CO.fill_uniform(2, m, p)
+    B = CO.fill_uniform(3, p, q) - 0.5
+    Y = X @ B + 0.1 * CO.fill_uniform(4, n, q); Yt = Xt @ B + 0.1 * CO.fill_uniform(5, m, q)
+    fm = O.plskern(X, Y, nlv=6)
+    pred = O.predict(fm, Xt, nlv=4)
+    for nm in ("msep", "rmsep", "ssr", "bias", "r2", "cor2"):
+        assert np.allclose(getattr(J, nm)(pred, Yt, ctx=ctx), getattr(O, nm)(pred, Yt), rtol=1e-9, atol=1e-12), nm
+    rng, ref = O.gridscorelv(X, Y, Xt, Yt, score=O.rmsep, fun=O.plskern, nlv=range(0, 9))
+    res = J.gridscorelv(X, Y, Xt, Yt, score=J.rmsep, fun=J.plskern, nlv=range(0, 9), ctx=ctx)
+    assert res["nlv"] == rng and np.allclose(res["res"], ref, rtol=1e-8)
+    custom = J.gridscorelv(X, Y, Xt, Yt, score=lambda pr, yy: O.msep(pr, yy), fun=J.plskern, nlv=[2, 5], ctx=ctx)   # user score
+    assert np.allclose(custom["res"], O.gridscorelv(X, Y, Xt, Yt, score=O.msep, fun=O.plskern, nlv=[2, 5])[1], rtol=1e-8)
+
+
+@pytest.mark.parametrize("scal", [False, True])
+def test_gridcvlv_zero_weight_folds(scal, J, ctx):
+    """gridcvlv (src/gridcv.jl:187-228): K-fold CV where each fold is a weighted fit with weight 0 on the held-out
+    rows (no rmrow copies) and predictions come from the scores T — must equal the oracle's copy-based CV."""
+    n, p, q = 1200, 30, 2
+    X = CO.fill_uniform(1, n, p)
+    B = CO.fill_uniform(3, p, q) - 0.5
+    Y = X @ B + 0.2 * CO.fill_uniform(4, n, q)
+    segm = J.segmkf(n, 4, rep=2, seed=7)
+    assert sorted(np.concatenate(segm[0]).tolist()) == list(range(n))
+    ofun = (lambda a, b, nlv: O.plskern(a, b, nlv=nlv, scal=scal))
+    rng, ref, ref_rep = O.gridcvlv(X, Y, segm=segm, score=O.msep, fun=ofun, nlv=range(0, 8))
+    res = J.gridcvlv(X, Y, segm=segm, score=J.msep, fun=J.plskern, nlv=range(0, 8), ctx=ctx, scal=scal)
+    assert res["nlv"] == rng
+    assert np.allclose(res["res_rep"], ref_rep, rtol=1e-7) and np.allclose(res["res"], ref, rtol=1e-7)
+    best = int(np.argmin(res["res"][:, 0]))
+    assert best >= 2                                         # the signal needs a few LVs; nlv = 0 is the worst
+    assert res["res"][0, 0] > res["res"][best, 0]

@@ -177,3 +177,27 @@ def test_lwplsr_oracle_pieces():
     assert abs(r["pred"][0, 0, 0] - w0 @ y[r["listnn"][0]]) < 1e-12
     err = [np.abs(r["pred"][:, 0, a] - y[:20]).mean() for a in range(5)]
     assert err[4] < err[0] * 0.2
+
+
+def test_scores_and_grid_oracle():
+    """Pins the §8f restatements (src/scores.jl, src/gridscore.jl:167-221, src/gridcv.jl:187-228)."""
+    from sklearn.metrics import mean_squared_error, r2_score
+    X = O.rand_matrix(1, 300, 12); B = O.rand_matrix(2, 12, 2) - 0.5
+    Y = X @ B + 0.1 * O.rand_matrix(3, 300, 2)
+    Xt = O.rand_matrix(4, 80, 12); Yt = Xt @ B + 0.1 * O.rand_matrix(5, 80, 2)
+    fm = O.plskern(X, Y, nlv=5)
+    pred = O.predict(fm, Xt)
+    assert np.allclose(O.msep(pred, Yt)[0], mean_squared_error(Yt, pred, multioutput="raw_values"))
+    assert np.allclose(O.r2(pred, Yt)[0], r2_score(Yt, pred, multioutput="raw_values"))
+    assert np.allclose(O.rmsep(pred, Yt) ** 2, O.ssr(pred, Yt) / 80)
+    assert np.allclose(O.bias(pred, Yt)[0], (pred - Yt).mean(axis=0))
+    rng, res = O.gridscorelv(X, Y, Xt, Yt, score=O.rmsep, fun=O.plskern, nlv=range(-3, 99))
+    assert rng == list(range(0, 13)) and res.shape == (13, 2)                    # clamped to 0:p
+    assert np.allclose(res[5], O.rmsep(pred, Yt)[0])
+    assert np.allclose(res[0], O.rmsep(np.tile(Y.mean(0), (80, 1)), Yt)[0])      # nlv = 0 predicts the training mean
+    segm = [[np.arange(0, 300, 3), np.arange(1, 300, 3), np.arange(2, 300, 3)]]
+    rng, cv, rep = O.gridcvlv(X, Y, segm=segm, score=O.msep, fun=O.plskern, nlv=range(0, 6))
+    assert rep.shape == (1, 3, 6, 2) and np.allclose(cv, rep.mean(axis=(0, 1)))
+    s = segm[0][1]
+    _, one = O.gridscorelv(O.rmrow(X, s), O.rmrow(Y, s), X[s], Y[s], score=O.msep, fun=O.plskern, nlv=range(0, 6))
+    assert np.allclose(rep[0, 1], one)
