@@ -163,7 +163,7 @@ int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const do
 // WRITEBACK (plskern!/plsnipals! semantics) stores the centred X back into the caller's column-major
 // array; it is only legal when each X element is read by exactly one block (one y group).  Y is never
 // written here (every column tile re-reads the raw Y rows): the launcher exports Yr afterwards.
-template <bool WRITEBACK, bool SCAL>
+template <bool WRITEBACK, bool SCAL, bool V16>
 __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
                                                      int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                      const double *__restrict__ mom, const double *__restrict__ scl,
@@ -176,26 +176,47 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
     const int j0 = blockIdx.y * 64;
     const int yg = blockIdx.z;
     const int64_t nchunks = (n + 63) / 64;
-    // per-thread column constants: this thread always handles columns j0 + wv + 4k of the X tile
-    double cm[16], cs[16];
+    // per-thread column constants.  8-B path: lane = row, columns j0 + wv + 4k (k < 16).
+    // V16 path (even ld, 16-B aligned base): lane = (row pair lane&31, column parity lane>>5), columns
+    // j0 + 2 (wv + 4k) + (lane>>5) (k < 8): every global load is 16 B (two consecutive rows of one column) —
+    // 8-B accesses reach only ~0.55-0.7 of the 16-B rate on this part.
+    typedef double v2f64_ __attribute__((ext_vector_type(2)));
+    constexpr int NK = V16 ? 8 : 16;
+    const int lp = lane & 31, ch = lane >> 5;
+    double cm[NK], cs[NK];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int j = j0 + wv + 4 * k;
+    for (int k = 0; k < NK; ++k) {
+        const int j = V16 ? j0 + 2 * (wv + 4 * k) + ch : j0 + wv + 4 * k;
         cm[k] = j < p ? mom[j] : 0.0;
         cs[k] = (SCAL && j < p) ? scl[j] : 1.0;  // divisor, used only when scaling (cscale!: (x - u) / v)
     }
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     // software pipeline: the global loads of chunk c+1 are in flight while chunk c is stored / multiplied
     double xr[16];
-    int64_t c = blockIdx.x;
-    if (c < nchunks) {
-        const int64_t i = c * 64 + lane;
+    auto prefetch = [&](int64_t cc) {
+        if constexpr (V16) {
+            const int64_t i = cc * 64 + 2 * lp;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = j0 + wv + 4 * k;
-            xr[k] = (i < n && j < p) ? __builtin_nontemporal_load(Xc + (size_t)i + (size_t)j * (size_t)ldx) : 0.0;
+            for (int k = 0; k < 8; ++k) {
+                const int j = j0 + 2 * (wv + 4 * k) + ch;
+                v2f64_ v = {0.0, 0.0};
+                if (j < p) {
+                    if (i + 1 < n) v = __builtin_nontemporal_load(reinterpret_cast<const v2f64_ *>(Xc + (size_t)i + (size_t)j * (size_t)ldx));
+                    else if (i < n) v.x = Xc[(size_t)i + (size_t)j * (size_t)ldx];
+                }
+                xr[2 * k] = v.x; xr[2 * k + 1] = v.y;
+            }
+        } else {
+            const int64_t i = cc * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int j = j0 + wv + 4 * k;
+                xr[k] = (i < n && j < p) ? __builtin_nontemporal_load(Xc + (size_t)i + (size_t)j * (size_t)ldx) : 0.0;
+            }
         }
-    }
+    };
+    int64_t c = blockIdx.x;
+    if (c < nchunks) prefetch(c);
     for (; c < nchunks; c += gridDim.x) {
         const int64_t i0 = c * 64;
         // ---- Y tile: 64 rows x 16 cols, element e = tid + 256k -> (row e&63, col e>>6)
@@ -214,7 +235,24 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
             yt[row * YT_LD + col] = dv * v;
         }
         // ---- X tile: centre/scale the prefetched registers into LDS (and back into the caller's array)
-        {
+        if constexpr (V16) {
+            const int64_t i = i0 + 2 * lp;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int col = 2 * (wv + 4 * k) + ch, j = j0 + col;
+                v2f64_ v = {0.0, 0.0};
+                if (j < p) {
+                    if (i < n) v.x = SCAL ? (xr[2 * k] - cm[k]) / cs[k] : xr[2 * k] - cm[k];
+                    if (i + 1 < n) v.y = SCAL ? (xr[2 * k + 1] - cm[k]) / cs[k] : xr[2 * k + 1] - cm[k];
+                    if (WRITEBACK && yg == 0) {
+                        if (i + 1 < n) *reinterpret_cast<v2f64_ *>(Xc + (size_t)i + (size_t)j * (size_t)ldx) = v;
+                        else if (i < n) Xc[(size_t)i + (size_t)j * (size_t)ldx] = v.x;
+                    }
+                }
+                xt[(2 * lp) * XT_LD + col] = v.x;
+                xt[(2 * lp + 1) * XT_LD + col] = v.y;
+            }
+        } else {
             const int64_t i = i0 + lane;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -229,17 +267,7 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
         }
         __syncthreads();
         // ---- prefetch the next chunk
-        {
-            const int64_t cn = c + gridDim.x;
-            if (cn < nchunks) {
-                const int64_t i = cn * 64 + lane;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int j = j0 + wv + 4 * k;
-                    xr[k] = (i < n && j < p) ? __builtin_nontemporal_load(Xc + (size_t)i + (size_t)j * (size_t)ldx) : 0.0;
-                }
-            }
-        }
+        if (c + gridDim.x < nchunks) prefetch(c + gridDim.x);
         // ---- row-major store (y group 0 only): (row wv+4k, col lane)
         if (yg == 0 && !(dbg_skip & 2)) {
 #pragma unroll 4
@@ -421,12 +449,17 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
         else JCH_K2V2(false, false);
 #undef JCH_K2V2
     } else {
-#define JCH_K2(WB, SC) hipLaunchKernelGGL((k_center_xty<WB, SC>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
-                                          mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip)
-        if (wb_fused && scal) JCH_K2(true, true);
-        else if (wb_fused) JCH_K2(true, false);
-        else if (scal) JCH_K2(false, true);
-        else JCH_K2(false, false);
+        // measured (cfg2): 16-B column loads into this tile are 0.1 ms SLOWER than 8-B ones (two strided LDS writes per
+        // load); the kernel is bound by the LDS transpose + partial-line row stores, not by the load width
+        const bool v16 = (ldx % 2 == 0) && (((uintptr_t)Xc) % 16 == 0) && getenv("JCH_K2_V16");
+#define JCH_K2(WB, SC, V) hipLaunchKernelGGL((k_center_xty<WB, SC, V>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
+                                             mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip)
+#define JCH_K2D(WB, SC) do { if (v16) JCH_K2(WB, SC, true); else JCH_K2(WB, SC, false); } while (0)
+        if (wb_fused && scal) JCH_K2D(true, true);
+        else if (wb_fused) JCH_K2D(true, false);
+        else if (scal) JCH_K2D(false, true);
+        else JCH_K2D(false, false);
+#undef JCH_K2D
 #undef JCH_K2
     }
     hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nslots, kp_rows, p, qpad,
