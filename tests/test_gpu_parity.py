@@ -349,3 +349,16 @@ def test_gridcvlv_zero_weight_folds(scal, J, ctx):
     best = int(np.argmin(res["res"][:, 0]))
     assert best >= 2                                         # the signal needs a few LVs; nlv = 0 is the worst
     assert res["res"][0, 0] > res["res"][best, 0]
+
+
+def test_lwplsr_multiresponse(J, ctx):
+    """q > 1: neighbours/weights from the batched kernel, local fits through the unbatched device plskern."""
+    n, p, q, m = 800, 25, 3, 6
+    X = O.rand_matrix(1, n, p); B = O.rand_matrix(2, p, q) - 0.5
+    Y = X @ B + np.sin(2 * X[:, :q]) + 0.05 * O.rand_matrix(3, n, q)
+    Xq = O.rand_matrix(4, m, p)
+    kw = dict(nlvdis=6, metric="mahal", h=1.5, k=60, nlv=5)
+    ref = O.lwplsr_predict(O.lwplsr(X, Y, **kw), Xq, nlv=range(0, 6))
+    res = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=range(0, 6), ctx=ctx)
+    assert np.array_equal(res.listnn, ref["listnn"])
+    assert O.rel_fro(ref["pred"], np.stack(res.pred, axis=2)) < 1e-8
