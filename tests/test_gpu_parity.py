@@ -362,3 +362,43 @@ def test_lwplsr_multiresponse(J, ctx):
     res = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=range(0, 6), ctx=ctx)
     assert np.array_equal(res.listnn, ref["listnn"])
     assert O.rel_fro(ref["pred"], np.stack(res.pred, axis=2)) < 1e-8
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 1, 1), (3, 5, 2, 4), (1, 3, 1, 2), (7, 1, 3, 2), (65, 129, 16, 3), (129, 2, 2, 2)])
+@pytest.mark.parametrize("alg", ["kern", "nipals"])
+def test_tiny_and_boundary_shapes(shape, alg, J, ctx):
+    """Smallest shapes and tile-boundary shapes (n, p around 64/128, q = 16 = one full y group): same NaN/Inf
+    pattern and same finite values as the oracle.  n = 1: the centred data is all zero -> 0/0 everywhere (H9)."""
+    n, p, q, nlv = shape
+    X = O.rand_matrix(11, n, p); Y = O.rand_matrix(12, n, q)
+    with np.errstate(all="ignore"):
+        ref = (O.plskern if alg == "kern" else O.plsnipals)(X, Y, nlv=nlv) if n > 1 else None
+    fm = (J.plskern if alg == "kern" else J.plsnipals)(X, Y, nlv=nlv, ctx=ctx)
+    assert fm.T.shape == (n, min(n, p, nlv))
+    if n == 1:
+        assert not np.all(np.isfinite(fm.C))
+        return
+    k = max(1, min(n - 1, p, nlv))       # with n points the centred data has rank <= n-1: later LVs are 0/0 noise
+    s = O.sign_align(ref.W[:, :k], fm.W[:, :k])
+    for f in ("T", "P", "C"):
+        assert O.rel_fro(getattr(ref, f)[:, :k], getattr(fm, f)[:, :k] * s) < 1e-8, f
+    assert np.allclose(ref.xmeans, fm.xmeans) and np.allclose(ref.ymeans, fm.ymeans)
+
+
+def test_zero_weights_and_constant_column(J, ctx):
+    """Zero weights drop rows exactly (what gridcvlv relies on); an all-zero X column with scal = true gives a zero
+    scale and NaN/Inf exactly where the oracle has them (the reference has no guard, utility.jl:482-487)."""
+    n, p, q = 200, 12, 2
+    X = O.rand_matrix(1, n, p); Y = O.rand_matrix(2, n, q)
+    w = np.ones(n); w[::3] = 0.0
+    keep = w > 0
+    a = J.plskern(X, Y, w, nlv=4, scal=True, ctx=ctx)
+    b = O.plskern(X[keep], Y[keep], nlv=4, scal=True)
+    s = O.sign_align(b.W, a.W)
+    assert O.rel_fro(b.P, a.P * s) < 1e-10 and O.rel_fro(b.T, a.T[keep] * s) < 1e-10
+    Xc = X.copy(); Xc[:, 5] = 0.0        # an all-zero column: mean and variance are exactly 0 in every summation order
+    with np.errstate(all="ignore"):      # q = 1 branch (no SVD: LAPACK would throw on the NaN matrix for q > 1)
+        r = O.plskern(Xc, Y[:, :1], nlv=2, scal=True)
+    g = J.plskern(Xc, Y[:, :1], nlv=2, scal=True, ctx=ctx)
+    assert r.xscales[5] == 0.0 and g.xscales[5] == 0.0
+    assert np.array_equal(np.isfinite(r.P), np.isfinite(g.P)) and not np.all(np.isfinite(g.P))
