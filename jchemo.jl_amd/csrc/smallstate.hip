@@ -269,28 +269,35 @@ int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int
     return JCH_OK;
 }
 
-// R = W inv(P'W)   (src/plsnipals.jl:95) — once per plsnipals fit; single workgroup, Gauss-Jordan with
-// partial pivoting on the nlv x nlv matrix held in global scratch (s.zt region is too small: uses s.K? no —
-// caller provides scratch via s.hdr + 4; see fit.hip).
+// R = W inv(P'W)   (src/plsnipals.jl:95) — once per plsnipals fit, three small launches:
+//   k_nipals_M    M = P'W (nlv x nlv), one wave per entry, many blocks
+//   k_nipals_inv  Gauss-Jordan with partial pivoting, single workgroup (matrices in global scratch)
+//   k_nipals_Rmul R = W * Mi, one thread per output
 struct nipR_args {
     const double *P, *W;
     double *R, *M, *Mi;
     int p, nlv;
 };
-__global__ __launch_bounds__(NT) void k_nipals_R(nipR_args g)
+__global__ __launch_bounds__(NT) void k_nipals_M(nipR_args g)
+{
+    const int m = g.nlv, p = g.p, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (e >= m * m) return;
+    const int i = e / m, j = e % m;
+    double s0 = 0.0, s1 = 0.0;
+    int k = lane;
+    for (; k + 64 < p; k += 128) {
+        s0 += g.P[(size_t)i * p + k] * g.W[(size_t)j * p + k];
+        s1 += g.P[(size_t)i * p + k + 64] * g.W[(size_t)j * p + k + 64];
+    }
+    for (; k < p; k += 64) s0 += g.P[(size_t)i * p + k] * g.W[(size_t)j * p + k];
+    const double s = jch_wave_sum(s0 + s1);
+    if (lane == 0) { g.M[e] = s; g.Mi[e] = (i == j) ? 1.0 : 0.0; }
+}
+__global__ __launch_bounds__(NT) void k_nipals_inv(nipR_args g)
 {
     __shared__ int piv_s;
-    const int m = g.nlv, p = g.p, tid = threadIdx.x;
-    // M = P' W   (m x m, row-major [i][j]);  P, W stored [lv][p]
-    for (int e = tid >> 6; e < m * m; e += NT / 64) {
-        const int i = e / m, j = e % m, lane = tid & 63;
-        double s = 0.0;
-        for (int k = lane; k < p; k += 64) s += g.P[(size_t)i * p + k] * g.W[(size_t)j * p + k];
-        s = jch_wave_sum(s);
-        if (lane == 0) { g.M[e] = s; g.Mi[e] = (i == j) ? 1.0 : 0.0; }
-    }
-    __threadfence();
-    __syncthreads();
+    const int m = g.nlv, tid = threadIdx.x;
     for (int c = 0; c < m; ++c) {
         if (tid == 0) {
             int piv = c; double best = fabs(g.M[c * m + c]);
@@ -327,13 +334,16 @@ __global__ __launch_bounds__(NT) void k_nipals_R(nipR_args g)
         __threadfence();
         __syncthreads();
     }
-    // R[j][k] = sum_i W[i][k] * Mi[i][j]      (R = W * inv(P'W), stored [lv][p])
-    for (int e = tid; e < m * p; e += NT) {
-        const int j = e / p, k = e % p;
-        double s = 0.0;
-        for (int i = 0; i < m; ++i) s += g.W[(size_t)i * p + k] * g.Mi[i * m + j];
-        g.R[(size_t)j * p + k] = s;
-    }
+}
+__global__ __launch_bounds__(NT) void k_nipals_Rmul(nipR_args g)
+{
+    const int m = g.nlv, p = g.p;
+    const int e = blockIdx.x * NT + threadIdx.x;     // R[j][k] = sum_i W[i][k] * Mi[i][j]   (stored [lv][p])
+    if (e >= m * p) return;
+    const int j = e / p, k = e - j * p;
+    double s = 0.0;
+    for (int i = 0; i < m; ++i) s += g.W[(size_t)i * p + k] * g.Mi[i * m + j];
+    g.R[(size_t)j * p + k] = s;
 }
 
 int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv)
@@ -343,7 +353,9 @@ int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv)
     g.P = s.P; g.W = s.W; g.R = s.R; g.p = p; g.nlv = nlv;
     g.M = (double *)ctx->gemm_b.ptr;
     g.Mi = g.M + (size_t)nlv * nlv;
-    hipLaunchKernelGGL(k_nipals_R, dim3(1), dim3(NT), 0, ctx->stream, g);
+    hipLaunchKernelGGL(k_nipals_M, dim3((nlv * nlv + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, ctx->stream, g);
+    hipLaunchKernelGGL(k_nipals_inv, dim3(1), dim3(NT), 0, ctx->stream, g);
+    hipLaunchKernelGGL(k_nipals_Rmul, dim3((nlv * p + NT - 1) / NT), dim3(NT), 0, ctx->stream, g);
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }
