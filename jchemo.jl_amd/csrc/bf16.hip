@@ -177,6 +177,50 @@ __global__ __launch_bounds__(256) void k_reduce_kpart_b(const double *__restrict
     K[e] = s;
 }
 
+// Sum R per-lane partials s[0..R) over the 64 lanes of a wave and return all R totals in every lane.
+// Halving butterfly: at each of the first log2(R) steps a lane keeps one half of its values and ships the other half
+// to its partner (R/2 + R/4 + ... + 1 shuffles instead of 6 R), three plain butterfly steps finish the remaining
+// lane bits, v_readlane broadcasts the totals.  Fixed order -> deterministic.
+template <int R>
+__device__ __forceinline__ void wave_sum_rows(float (&s)[R], float (&t)[R])
+{
+    static_assert(R == 2 || R == 4 || R == 8, "R");
+    const int lane = threadIdx.x & 63;
+    float cur[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) cur[i] = s[i];
+    int width = R;
+    int bit = 32;
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        if (width > 1) {
+            const int half = width / 2;
+            const bool hi = (lane & bit) != 0;
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) {
+                if (i < half) {
+                    const float mine = hi ? cur[half + i] : cur[i];
+                    const float other = hi ? cur[i] : cur[half + i];
+                    cur[i] = mine + __shfl_xor(other, bit, 64);
+                }
+            }
+            width = half;
+            bit >>= 1;
+        }
+    }
+    float c = cur[0];
+    for (int o = bit; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    // row r lives in the lanes whose top log2(R) bits spell r (bit 5 = most significant)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int src = 0;
+        if (R == 8) src = ((r >> 2) & 1) * 32 + ((r >> 1) & 1) * 16 + (r & 1) * 8;
+        if (R == 4) src = ((r >> 1) & 1) * 32 + (r & 1) * 16;
+        if (R == 2) src = (r & 1) * 32;
+        t[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), src));
+    }
+}
+
 // ---------------------------------------------------------------- K4 (bf16 storage): fused sweep, fp32 row arithmetic
 // lane l owns columns 8l..8l+7 (+512k): one 16-B load per row chunk.  rt, off: see the header comment.
 template <int KC, int R>
@@ -210,6 +254,7 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
             for (int k = 0; k < KC; ++k) x[rr][k] = (live && in[k]) ? __builtin_nontemporal_load(rp + 64 * k) : v4u32{0u, 0u, 0u, 0u};
         }
         double tsel = 0.0;
+        float sp[R], tr[R];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             float s = 0.f;
@@ -217,10 +262,13 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
             for (int k = 0; k < KC; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s += bflo(x[rr][k][e]) * rf[k][2 * e] + bfhi(x[rr][k][e]) * rf[k][2 * e + 1];
+            sp[rr] = s;
+        }
+        wave_sum_rows<R>(sp, tr);
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        for (int rr = 0; rr < R; ++rr) {
             const bool live = row0 + rr < n;
-            const float t = s - off;
+            const float t = tr[rr] - off;
             const float dtf = live ? (float)dw[row0 + rr] * t : 0.f;
             tt += (double)dtf * (double)t;
             st += (double)dtf;
@@ -312,14 +360,16 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
             JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_bf16<KC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int64_t ngroups = (n + R - 1) / R;
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * bpc));
+    static int bpc_env = -1;
+    if (bpc_env < 0) { const char *e = getenv("JCH_BF16_BPC"); bpc_env = e ? atoi(e) : 0; }
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * (bpc_env > 0 ? bpc_env : bpc)));
     const int m = ldr_b + 2, ldpart = (m + 7) & ~7;
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->part.ptr;
     (void)jch_ev(ctx);
     hipLaunchKernelGGL((k_sweep_bf16<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rt, off, tcol, part, ldpart);
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL(k_reduce_part_b, dim3((m + 63) / 64), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, zt_raw);
+    JCH_TRY(jch_launch_reduce_rows(ctx, part, nb, ldpart, m, zt_raw));
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }
@@ -376,7 +426,11 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     for (int a = 0; a < nlv; ++a) {
         hipLaunchKernelGGL(k_bf16_make_rt, dim3(1), dim3(256), 0, ctx->stream, s.r, p, ldr_b, s.mom, s.scl, rt, off);
         double *tcol = Tdev + (size_t)a * (size_t)n;
-        if (ldr_b <= 512) JCH_TRY((launch_sweep_bf16_t<1, 8>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
+        static int rsel = -1;
+        if (rsel < 0) { const char *e = getenv("JCH_BF16_R"); rsel = e ? atoi(e) : 2; }   // measured at n = 1e6, p = 500: R = 8 / 4 / 2 -> 4.0 / 4.85 / 5.2 TB/s
+        if (ldr_b <= 512 && rsel == 4) JCH_TRY((launch_sweep_bf16_t<1, 4>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
+        else if (ldr_b <= 512 && rsel == 2) JCH_TRY((launch_sweep_bf16_t<1, 2>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
+        else if (ldr_b <= 512) JCH_TRY((launch_sweep_bf16_t<1, 8>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
         else if (ldr_b <= 1024) JCH_TRY((launch_sweep_bf16_t<2, 4>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
         else JCH_TRY((launch_sweep_bf16_t<4, 2>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
         JCH_TRY(jch_allreduce_f64(ctx, zt_raw, (size_t)ldr_b + 2));   // ONE collective per LV: [zp_raw, tt, st]

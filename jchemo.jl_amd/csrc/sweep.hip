@@ -136,6 +136,25 @@ __global__ __launch_bounds__(256) void k_reduce_slices(double *__restrict__ zt, 
     zt[c] = s;
 }
 
+// Fixed-order two-stage sum of `nb` partial rows (ld ldpart, m columns) into one vector `out` (used by the bf16 and
+// wide-row paths, which hand a single vector to the all-reduce / small-state kernel).
+int32_t jch_launch_reduce_rows(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *out)
+{
+    const int ldz = (m + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * (size_t)JCH_ZT_SLICES * ldz + 4096 * sizeof(double)));
+    double *tmp = (double *)ctx->colpart.ptr;
+    const int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
+    if (nslice == 1) {
+        hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, 1), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, 1, out, ldz);
+    } else {
+        hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, tmp, ldz);
+        hipLaunchKernelGGL(k_reduce_slices, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, tmp, ldz, m, JCH_ZT_SLICES);
+        JCH_HIP(ctx, hipMemcpyAsync(out, tmp, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
 template <int KC, int R, bool NT = true>
 static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                               const double *Yr, int qpad, bool nipals, double *tcol, double *zt, int ldz, int max_slices,
