@@ -62,9 +62,19 @@ def cpu_baseline(n_total, p, q, nlv, sample_rows):
     CO.plskern_(X, Y, None, nlv=nlv, scal=False)        # `plskern!` on the sample (in place, like README.md:93)
     dt = time.perf_counter() - t0
     scale = n_total / ns
+    # probe for the real reference (Julia + Jchemo) and record the outcome; never assume it
+    import shutil, subprocess
+    jl = shutil.which("julia")
+    probe = "julia: not on PATH (reference itself cannot be timed here)"
+    if jl:
+        try:
+            r = subprocess.run([jl, "-e", "using Jchemo"], capture_output=True, timeout=120)
+            probe = "julia present, `using Jchemo` " + ("works (not timed by this harness yet)" if r.returncode == 0 else "fails")
+        except Exception as e:
+            probe = f"julia present, probe failed: {e}"
     return {"value": nlv / (dt * scale), "unit": "LV/s", "cores": int(CO.lib().orc_num_threads()), "kind": "port",
             "sample": f"plskern! on the first {ns} of {n_total} rows (same p={p}, q={q}, nlv={nlv}); {dt:.2f} s measured, "
-                      f"time scaled x{scale:.2f} (memory-bound, linear in n)"}
+                      f"time scaled x{scale:.2f} (memory-bound, linear in n); {probe}"}
 
 
 def main():
