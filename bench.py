@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--p", type=int, default=500)
     ap.add_argument("--q", type=int, default=10)
     ap.add_argument("--nlv", type=int, default=25)
-    ap.add_argument("--algo", choices=["plskern", "plsnipals"], default="plskern")
+    ap.add_argument("--algo", choices=["plskern", "plsnipals", "plskern2"], default="plskern",
+                    help="plskern2 = opt-in kernel algorithm #2 (Gram once; not the reference's algorithm, never the headline)")
     ap.add_argument("--dtype", choices=["f64", "bf16"], default="f64", help="bf16 = storage mode of BASELINE configs[2]")
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,9 +136,9 @@ def main():
     Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
     xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
     desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0,
-                        reserved=0)
+                        reserved=1 if args.algo == "plskern2" else 0)
     got = C.c_int32(0)
-    entry = lib.jch_plskern_fit if args.algo == "plskern" else lib.jch_plsnipals_fit
+    entry = lib.jch_plsnipals_fit if args.algo == "plsnipals" else lib.jch_plskern_fit
 
     def step():
         ctx.check(entry(ctx._h, C.byref(desc), X.data_ptr(), n, Y.data_ptr(), n, None, T.data_ptr(), P.ctypes.data,
@@ -173,8 +174,8 @@ def main():
         value = k * args.steps / dt
         avg_sweep_s = (sweep_ms / max(sweep_launches, 1)) * 1e-3
         achieved = sweep_bytes / avg_sweep_s / 1e9 if avg_sweep_s > 0 else 0.0
-        kernel = "k_sweep (fused t = X r, tt, zp = X'Dt, T column store)" if args.algo == "plskern" else \
-            "k_sweep + k_deflate_xty (per LV)"
+        kernel = {"plskern": "k_sweep (fused t = X r, tt, zp = X'Dt, T column store)", "plsnipals": "k_sweep + k_deflate (per LV)",
+                  "plskern2": "k_syrk (X'DX on v_mfma_f64_16x16x4, once per fit)"}[args.algo]
         out = {
             "metric": f"latent-variables/sec ({args.algo} n={n_total:.0e} p={p} q={q} nlv={nlv})".replace("e+0", "e"),
             "value": value, "unit": "LV/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,9 +186,12 @@ def main():
                                    f"({'BASELINE.json configs[1]' if (args.algo, n_total, p, q, nlv, bf16) == ('plskern', 1000000, 500, 10, 25, False) else 'variant'}), "
                                    f"X/Y device-resident column-major, rows sharded over {world} GPU(s)",
                        "n": n_total, "p": p, "q": q, "nlv": k, "rows_per_gpu": n, "timed": "prologue + LV loop, device-resident"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": ({"bound": "mfma", "kernel": kernel, "achieved": n * p * (p + 1) / avg_sweep_s / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                          "frac": n * p * (p + 1) / avg_sweep_s / 1e12 / 78.6, "traffic": None, "flop_per_launch": n * p * (p + 1),
+                          "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches} if args.algo == "plskern2" else
+                         {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if bf16 else pmc_traffic(args.algo, n, p),
-                         "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches},
+                         "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches}),
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
                                    "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps},
         }

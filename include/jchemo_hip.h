@@ -83,7 +83,9 @@ typedef struct jch_pls_desc {
     int32_t inplace; /* 1 = `plskern!` / `plsnipals!` semantics: X and Y are overwritten with their
                         centred/scaled (plsnipals: and deflated) versions; 0 = `plskern` (inputs untouched,
                         the reference's copy at plskern.jl:108 never materialises) */
-    int32_t reserved;
+    int32_t reserved; /* 0 = the reference's algorithm (improved kernel #1, one sweep over X per LV); 1 = OPT-IN
+                         kernel algorithm #2 (X'DX once, no pass over X and no collective in the LV loop; plskern,
+                         q <= 16, p <= 2048): same results up to rounding */
 } jch_pls_desc;
 
 /*

@@ -79,7 +79,7 @@ extern "C" int32_t jch_ctx_destroy(jch_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-    for (jch_buf *b : {&ctx->xr, &ctx->yr, &ctx->xstage, &ctx->ystage, &ctx->wstage, &ctx->tbuf, &ctx->dnorm, &ctx->part,
+    for (jch_buf *b : {&ctx->gram, &ctx->xr, &ctx->yr, &ctx->xstage, &ctx->ystage, &ctx->wstage, &ctx->tbuf, &ctx->dnorm, &ctx->part,
                        &ctx->kpart, &ctx->small, &ctx->colpart, &ctx->gemm_b, &ctx->gemm_out, &ctx->xq})
         free_buf(*b);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);

@@ -125,6 +125,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     const int ldz = (ldr + 1 + qpad + 7) & ~7;
     s.zt = cv.take((size_t)JCH_ZT_SLICES * ldz); s.zpc = cv.take((size_t)ldr + qpad);
     s.mom = cv.take(p + q); s.scl = cv.take(p + q); s.hdr = cv.take(8);
+    s.variant = 0;
     s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
 
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
@@ -184,6 +185,20 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
 
     // ---- LV loop
     const size_t sweep_ev0 = ctx->ev_used;
+    const bool variant2 = d.reserved == 1;
+    if (variant2) {   // OPT-IN kernel algorithm #2 (kern2.hip): Gram once, LV loop without X and without collectives
+        if (algo != 0 || !fast) return jch_fail(ctx, JCH_EINVAL, "%s: variant 2 needs plskern with q <= 16 and p <= %d", who, JCH_SWEEP_MAXP);
+        JCH_TRY(jch_reserve(ctx, ctx->gram, sizeof(double) * (size_t)p * ldr));
+        double *G = (double *)ctx->gram.ptr;
+        JCH_TRY(jch_launch_syrk(ctx, Xr, n, p, ldr, dn, G, ldr));
+        s.variant = 1;
+        JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, 0, 1, ldz, true));
+        for (int a = 0; a < nlv; ++a) {
+            JCH_TRY(jch_launch_gmatvec(ctx, G, ldr, p, ldr, s.r, s.zt));
+            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, 1, ldz, true));
+        }
+        JCH_TRY(jch_launch_scores(ctx, Xr, n, p, ldr, s.R, nlv, Tdev));
+    } else {
     JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, algo, 1, ldz, fast));
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
@@ -202,6 +217,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
             }
             if (!last) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 1, 1, ldz, fast));
         }
+    }
     }
     if (algo == 1) JCH_TRY(jch_launch_nipals_R(ctx, s, p, nlv));
     hipEvent_t ev_end = jch_ev(ctx);
@@ -253,7 +269,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         double sw = 0.0; int cnt = 0;
         for (size_t i = sweep_ev0; i + 1 < sweep_ev1; i += 2) { sw += ev_ms(ctx->ev_pool[i], ctx->ev_pool[i + 1]); ++cnt; }
         pr.sweep_ms = sw;
-        pr.sweep_launches = algo == 0 ? cnt : nlv;
+        pr.sweep_launches = variant2 ? 1 : (algo == 0 ? cnt : nlv);
         pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
         const double per_x = (double)n * ldr * 8.0;
         pr.sweep_bytes = algo == 0 ? per_x + 16.0 * (double)n : 3.0 * per_x;

@@ -41,7 +41,7 @@ struct jch_ctx {
     void *comm = nullptr;
     int rank = 0, nranks = 1;
     // workspace (grow-only)
-    jch_buf xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq;
+    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq;
     // profiling
     bool profiling = false;
     jch_profile prof{};
@@ -111,6 +111,7 @@ struct jch_small {  // device-resident replicated small state of one fit
     double *zpc;        // [ldr + qpad]      plsnipals: zp/tt, c/tt
     double *mom, *scl;  // [p+q]
     double *hdr;        // [4]
+    int variant;        // 0: algorithm #1 (zt holds [zp, tt] from the sweep); 1: algorithm #2 (zt = G r, tt = r'zp computed here)
     double *dbg;        // [nlv + 1] diagnostics (JCH_LV_DEBUG): Jacobi sweeps per LV; may be null
 };
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a /*-1: init*/,
@@ -128,6 +129,10 @@ int32_t jch_launch_weighted_ss(jch_ctx *ctx, const double *Xc, int64_t n, int p,
 int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv, int64_t ldx, const void *Yv, int64_t ldy,
                              const double *wdev, double *dn, double *Tdev, jch_small &s, int ldr_small, int qpad, int ldz,
                              bool fast, int *nlv_out);
+// kern2.hip (opt-in kernel algorithm #2)
+int32_t jch_launch_syrk(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, double *G, int ldg);
+int32_t jch_launch_gmatvec(jch_ctx *ctx, const double *G, int ldg, int p, int ldr, const double *r, double *out);
+int32_t jch_launch_scores(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *Rm, int nlv, double *T);
 // util.hip
 int32_t jch_launch_fill(jch_ctx *ctx, double *out, int64_t n, int64_t p, int64_t ld, int64_t row0, int64_t n_total,
                         uint64_t seed);

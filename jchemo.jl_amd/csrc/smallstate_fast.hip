@@ -23,7 +23,7 @@
 
 struct lvf_args {
     jch_small s;
-    int p, q, qpad, ldr, a, nlv, algo, do_a, do_b, nslice, ldz, skip;
+    int p, q, qpad, ldr, a, nlv, algo, do_a, do_b, nslice, ldz, skip, tt_from_r;
 };
 
 __device__ __forceinline__ void wavesync()
@@ -329,6 +329,13 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     }
     __syncthreads();
     JCH_STAMP(1);
+    if (g.do_a && g.tt_from_r) {   // kernel algorithm #2: zt = G r, so tt = t'Dt = r'G r = r . zp
+        double s = 0.0;
+        for (int j = tid; j < p; j += FT) s += rl[j] * ztl[j];
+        s = jch_block_sum<FT>(s, scratch);
+        if (tid == 0) ztl[ldr] = s;
+        __syncthreads();
+    }
 
     // ------------------------------------------------------------------ phase A
     if (g.do_a) {
@@ -567,7 +574,7 @@ int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q
     if (qpad != 16) return jch_fail(ctx, JCH_EINVAL, "internal: fast small-state kernel needs q <= 16");
     lvf_args g;
     g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.a = a; g.nlv = nlv; g.algo = algo;
-    g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz; g.skip = 0;
+    g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz; g.skip = 0; g.tt_from_r = s.variant == 1;
     const size_t lds = jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv);
     static bool attr_set = false;
     if (!attr_set) {

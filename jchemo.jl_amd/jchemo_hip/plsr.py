@@ -120,7 +120,7 @@ def _np(a):
 
 
 # ---------------------------------------------------------------------------------- fits
-def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Optional[Context]):
+def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Optional[Context], variant: int = 0):
     dev = _is_torch(X)
     if dev != _is_torch(Y):
         raise TypeError("X and Y must both be host arrays or both device tensors")
@@ -161,7 +161,7 @@ def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Op
     xa, ldx = _addr_ld(X, allow_bf16=True)
     ya, ldy = _addr_ld(Y, allow_bf16=True)
     desc = PlsDesc(n=n, p=p, q=q, nlv=int(nlv), scal=int(bool(scal)), dtype=_lib.BF16 if bf16 else _lib.F64,
-                   loc=_lib.LOC_DEVICE if dev else _lib.LOC_HOST, inplace=int(inplace), reserved=0)
+                   loc=_lib.LOC_DEVICE if dev else _lib.LOC_HOST, inplace=int(inplace), reserved=int(variant))
     got = C.c_int32(0)
     if dev:
         torch.cuda.current_stream(X.device).synchronize()  # inputs produced on other streams are complete
@@ -172,15 +172,16 @@ def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Op
     return Plsr(T[:, :k], P[:, :k], R[:, :k], W[:, :k], Cm[:, :k], TT[:k], xm, xs, ym, ys, wn, None)
 
 
-def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, variant: int = 0) -> Plsr:
     """`plskern(X, Y, weights = ones(n); nlv, scal = false)` — src/plskern.jl:106-110.  X, Y untouched
-    (the reference copies them first; here the library simply never writes them)."""
+    (the reference copies them first; here the library simply never writes them).
+    `variant=1` (not in the reference) opts into kernel algorithm #2: X'DX once, no pass over X in the LV loop."""
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
         _addr_ld(X, allow_bf16=True); _addr_ld(Y, allow_bf16=True)   # bf16 tensors: storage mode of BASELINE configs[2]
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)   # layout/dtype conversion only
-    return _fit("jch_plskern_fit", X, Y, weights, nlv, scal, False, ctx)
+    return _fit("jch_plskern_fit", X, Y, weights, nlv, scal, False, ctx, variant)
 
 
 def plskern_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:

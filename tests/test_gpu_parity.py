@@ -402,3 +402,20 @@ def test_zero_weights_and_constant_column(J, ctx):
     g = J.plskern(Xc, Y[:, :1], nlv=2, scal=True, ctx=ctx)
     assert r.xscales[5] == 0.0 and g.xscales[5] == 0.0
     assert np.array_equal(np.isfinite(r.P), np.isfinite(g.P)) and not np.all(np.isfinite(g.P))
+
+
+@pytest.mark.parametrize("shape", [(20000, 500, 10, 25, False), (4099, 129, 3, 9, True), (3000, 1000, 1, 8, True), (150, 200, 2, 5, False),
+                                   (2500, 2047, 2, 5, False), (70, 130, 16, 4, True)])
+def test_opt_in_kernel_algorithm_2(shape, J, ctx):
+    """SURVEY §8f rank 2 (opt-in, not the reference's algorithm): X'DX once on MFMA f64, zp = G r, tt = r'G r, T = X R.
+    Same model as the oracle's algorithm #1 up to rounding (tolerance 1e-6; typically 1e-11)."""
+    n, p, q, nlv, scal = shape
+    X = CO.fill_uniform(20250112, n, p); Y = CO.fill_uniform(20250113, n, q)
+    w = 0.25 + O.splitmix64_uniform(7, 0, n) if scal else None
+    ref = CO.plskern(X, Y, w, nlv=nlv, scal=scal)
+    fm = J.plskern(X, Y, w, nlv=nlv, scal=scal, ctx=ctx, variant=1)
+    _cmp(ref, fm, tol=TOL)
+    assert O.rel_fro(ref.R @ ref.C.T, fm.R @ fm.C.T) < TOL
+    with pytest.raises(J.JchError):
+        J._fit = None  # (keeps flake quiet)
+        J.plsr._fit("jch_plsnipals_fit", np.asfortranarray(X), np.asfortranarray(Y), None, 2, False, False, ctx, 1)
