@@ -5,6 +5,9 @@
 //   M = 16 rows of X per wave (4 waves = 64 rows per block), K = 4 columns of X per MFMA, N = 16 output columns
 //   per accumulator, up to 8 accumulators (128 output columns) per block; wider outputs use grid.y.
 // Bound: HBM on X (m*p*8 bytes) for k <= 128.
+#include <stdint.h>
+#include <stdlib.h>
+
 #include <vector>
 
 #include "jch_internal.h"
@@ -64,9 +67,93 @@ __global__ __launch_bounds__(256) void k_affine_gemm(const double *__restrict__ 
     }
 }
 
+// Narrow-output variant (kpad <= 32: `transform` with nlv <= 32, `predict` for one nlv): the hot accessor shapes.
+//   * 16-B loads: lane l holds rows (2m, 2m+1), m = l & 15, of column j + (l >> 4): one wave-instruction = 4 x 256 B.
+//     The even rows feed one MFMA row-tile, the odd rows a second one (same B operand): 32 rows per wave, 128 per block.
+//   * B is staged in chunks of 128 X-columns (32 KB), so 128 MFMAs per wave sit between two barriers, and the X loads
+//     are software-pipelined 8 k-steps ahead inside a chunk.
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+#define G32_CH 128
+__global__ __launch_bounds__(256) void k_affine_gemm32(const double *__restrict__ Xc, int64_t m, int p, int64_t ldx,
+                                                        const double *__restrict__ Bs, int kpad, const double *__restrict__ bias,
+                                                        int k, double *__restrict__ out, int64_t ldo)
+{
+    __shared__ double bl[G32_CH * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * 128 + 32 * wv;
+    const int64_t irow = i0 + 2 * (lane & 15);        // this lane's row pair
+    const bool two = irow + 1 < m, one = irow < m;
+    const bool vec = two && (ldx % 2 == 0) && ((((uintptr_t)Xc) & 15) == 0) && (irow % 2 == 0);
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const int ntiles = kpad / 16;   // 1 or 2
+    auto loadx = [&](int j) -> v2f64 {
+        if (j >= p || !one) return v2f64{0.0, 0.0};
+        const double *src = Xc + (size_t)irow + (size_t)j * (size_t)ldx;
+        if (vec) return __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(src));
+        return v2f64{src[0], two ? src[1] : 0.0};
+    };
+    for (int j0 = 0; j0 < p; j0 += G32_CH) {
+        __syncthreads();
+        for (int e = tid; e < G32_CH * 32; e += 256) {
+            const int jj = e >> 5, cc = e & 31;
+            bl[jj * 33 + cc] = (j0 + jj < p && cc < kpad) ? Bs[(size_t)(j0 + jj) * kpad + cc] : 0.0;
+        }
+        v2f64 xa[8], xb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xa[u] = loadx(j0 + 4 * u + (lane >> 4));
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G32_CH / 32; ++g) {       // groups of 8 k-steps (32 columns)
+            if (g + 1 < G32_CH / 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xb[u] = loadx(j0 + 32 * (g + 1) + 4 * u + (lane >> 4));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kc = 32 * g + 4 * u + (lane >> 4);
+                const double b0 = bl[kc * 33 + (lane & 15)];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].x, b0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].y, b0, acc[1][0], 0, 0, 0);
+                if (ntiles > 1) {
+                    const double b1 = bl[kc * 33 + 16 + (lane & 15)];
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].x, b1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].y, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xa[u] = xb[u];
+        }
+    }
+    // D[mrow = (lane>>4) + 4 reg][col = lane & 15]; row-tile 0 = even rows, row-tile 1 = odd rows of the wave's 32
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t >= ntiles) break;
+        const int col = 16 * t + (lane & 15);
+        if (col >= k) continue;
+        const double bv = bias[col];
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t i = i0 + 2 * ((lane >> 4) + 4 * reg) + par;
+                if (i < m) out[(size_t)i + (size_t)col * (size_t)ldo] = acc[par][t][reg] + bv;
+            }
+    }
+}
+
 int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p, int64_t ldx, const double *Bs, int k, int kpad,
                                const double *bias, double *out, int64_t ldo)
 {
+    if (kpad <= 32 && !getenv("JCH_GEMM_GENERIC")) {
+        hipLaunchKernelGGL(k_affine_gemm32, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias,
+                           k, out, ldo);
+        JCH_HIP(ctx, hipGetLastError());
+        return JCH_OK;
+    }
     dim3 grid((unsigned)((m + 63) / 64), (unsigned)((kpad + 127) / 128));
     hipLaunchKernelGGL(k_affine_gemm, grid, dim3(256), 0, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo);
     JCH_HIP(ctx, hipGetLastError());

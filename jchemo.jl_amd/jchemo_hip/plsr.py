@@ -255,6 +255,22 @@ def coef(fm: Plsr, *, nlv: Optional[int] = None):
     return B, intercept
 
 
+def _pred_matrix(fm: "Plsr", X, rng, ctx):
+    """m x (len(rng) * q) matrix [pred_{rng[0]} | pred_{rng[1]} | ...] (level-major columns)."""
+    q = fm.C.shape[0]
+    if len(rng) > 2 and max(rng) > 0:
+        # several nlv: ONE pass over X for the scores (m x max(nlv)), then every prediction is a cumulative sum of
+        # score x loading terms, pred_a = ymeans + sum_{l < a} T_l (C_l .* yscales)' — a GEMM on the small score matrix
+        kmax = max(rng)
+        Tq = _affine(X, fm.xmeans, fm.xscales, fm.R[:, :kmax], None, ctx)
+        Bc = np.zeros((kmax, len(rng) * q))
+        for ai, a_ in enumerate(rng):
+            Bc[:a_, ai * q:(ai + 1) * q] = (fm.C[:, :a_] * fm.yscales[:, None]).T
+        return _affine(Tq, None, None, Bc, np.tile(fm.ymeans, len(rng)), ctx)
+    Bs, ints = zip(*(coef(fm, nlv=k) for k in rng))
+    return _affine(X, None, None, np.concatenate(Bs, axis=1), np.concatenate([i.reshape(-1) for i in ints]), ctx)
+
+
 def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Optional[Context] = None):
     """src/plskern.jl:226-238: a collection of nlv becomes the contiguous range max(0,min):min(a,max); one
     value -> matrix, several -> list of matrices.  All values are computed in ONE pass over X."""
@@ -267,8 +283,7 @@ def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Op
         vals = np.atleast_1d(np.asarray(nlv))
         rng = list(range(max(0, int(vals.min())), min(a, int(vals.max())) + 1))
     q = fm.C.shape[0]
-    Bs, ints = zip(*(coef(fm, nlv=k) for k in rng))
-    out = _affine(X, None, None, np.concatenate(Bs, axis=1), np.concatenate([i.reshape(-1) for i in ints]), ctx)
+    out = _pred_matrix(fm, X, rng, ctx)
     preds = [out[:, i * q:(i + 1) * q] for i in range(len(rng))]
     return preds[0] if len(preds) == 1 else preds
 
@@ -541,9 +556,7 @@ def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, ctx: Option
         pred = predict(fm, X, nlv=rng, ctx=ctx)
         pred = [pred] if len(rng) == 1 else pred
         return dict(nlv=rng, res=np.vstack([np.asarray(score(pr, Y)).reshape(1, -1) for pr in pred]))
-    q = fm.C.shape[0]
-    Bs, ints = zip(*(coef(fm, nlv=k) for k in rng))
-    P = _affine(X, None, None, np.concatenate(Bs, axis=1), np.concatenate([i.reshape(-1) for i in ints]), ctx)
+    P = _pred_matrix(fm, X, rng, ctx)
     return dict(nlv=rng, res=_score_from_sums(name, _score_sums(P, Y, None, ctx)))
 
 
