@@ -13,6 +13,8 @@
 //   k_gmatvec     zp = G r (one wave per row of G), per LV
 //   k_scores      T = Xr R  (n x nlv) on MFMA f64, row-major tile through LDS
 // Bound: MFMA f64 (n p^2 flop at 78.6 TF) for k_syrk; HBM for k_scores.
+// Measured (cfg2): k_syrk 7.4 ms = 44 TF executed (56 % of peak).  An XCD-aware block mapping (all tile pairs of one row
+// split on one XCD, to share the slabs through that L2) was tried and made no difference (7.8 ms): not L2-bound.
 #include <stdlib.h>
 
 #include <algorithm>

@@ -419,3 +419,25 @@ def test_opt_in_kernel_algorithm_2(shape, J, ctx):
     with pytest.raises(J.JchError):
         J._fit = None  # (keeps flake quiet)
         J.plsr._fit("jch_plsnipals_fit", np.asfortranarray(X), np.asfortranarray(Y), None, 2, False, False, ctx, 1)
+
+
+@pytest.mark.parametrize("pad", [2, 3])
+def test_device_leading_dimension(pad, J):
+    """Device matrices that are column slices of taller parents (ld > n; even ld takes the 16-B load paths, odd ld the
+    8-B ones) — the Julia side passes stride(X, 2) as ld."""
+    import torch
+    n, p, q, nlv = 1001, 37, 3, 6
+    X = O.rand_matrix(1, n, p); Y = O.rand_matrix(2, n, q)
+    ref = O.plskern(X, Y, nlv=nlv, scal=True)
+    Xp = J.colmajor_empty(n + pad, p); Yp = J.colmajor_empty(n + pad, q)
+    Xp.fill_(float("nan")); Yp.fill_(float("nan"))
+    Xd, Yd = Xp[:n], Yp[:n]
+    Xd.copy_(torch.from_numpy(X)); Yd.copy_(torch.from_numpy(Y))
+    assert Xd.stride() == (1, n + pad)
+    tctx = J.Context(0, stream="torch")
+    fm = J.plskern(Xd, Yd, nlv=nlv, scal=True, ctx=tctx)
+    _cmp(ref, fm, T=fm.T.cpu().numpy())
+    assert O.rel_fro(O.transform(ref, X), J.transform(fm, Xd, ctx=tctx).cpu().numpy() * O.sign_align(ref.W, fm.W)) < TIGHT
+    fm2 = J.plskern_(Xd, Yd, nlv=nlv, scal=True, ctx=tctx)           # in place through the strided view
+    assert O.rel_fro((X - ref.xmeans) / ref.xscales, Xd.cpu().numpy()) < TIGHT and torch.isnan(Xp[n:]).all()
+    tctx.close()
