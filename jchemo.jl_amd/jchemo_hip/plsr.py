@@ -276,6 +276,8 @@ def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Op
     value -> matrix, several -> list of matrices.  All values are computed in ONE pass over X."""
     if isinstance(fm, Lwplsr):
         return lwplsr_predict(fm, X, nlv=nlv, ctx=ctx)
+    if isinstance(fm, Plsrda):
+        return plsrda_predict(fm, X, nlv=nlv, ctx=ctx)
     a = fm.P.shape[1]
     if nlv is None:
         rng = [a]
@@ -602,3 +604,39 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] =
         rep_out.append(np.stack(zres))
     res_rep = np.stack(rep_out)
     return dict(nlv=rng, res=res_rep.mean(axis=(0, 1)), res_rep=res_rep)
+
+
+# ---------------------------------------------------------------------------------- PLSR-DA (§8f rank 4)
+@dataclass
+class Plsrda:
+    """src/plsrda.jl: struct Plsrda (fm::Plsr, lev, ni)."""
+    fm: Plsr
+    lev: np.ndarray
+    ni: np.ndarray
+
+
+def dummy(y):
+    """`dummy(y)` — src/utility.jl:509-519: (n x nlev 0/1 table, sorted levels).  Host-side label handling."""
+    y = np.asarray(y.cpu() if _is_torch(y) else y).reshape(-1)
+    lev = np.unique(y)
+    return (y[:, None] == lev[None, :]).astype(np.float64), lev
+
+
+def plsrda(X, y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsrda:
+    """`plsrda(X, y, weights; nlv, scal)` — src/plsrda.jl:71-77: plskern on the dummy table of the classes."""
+    Yd, lev = dummy(y)
+    yv = np.asarray(y.cpu() if _is_torch(y) else y).reshape(-1)
+    ni = np.array([(yv == l).sum() for l in lev])
+    X = ensure_mat(X)
+    if _is_torch(X):
+        Yt = colmajor_empty(Yd.shape[0], Yd.shape[1], X.device); Yt.copy_(torch.from_numpy(Yd)); Yd = Yt
+    return Plsrda(plskern(X, Yd, weights, nlv=nlv, scal=scal, ctx=ctx), lev, ni)
+
+
+def plsrda_predict(obj: Plsrda, X, *, nlv=None, ctx: Optional[Context] = None):
+    """`predict(object::Plsrda, X; nlv)` — src/plsrda.jl:95-120: (pred, posterior); lists when several nlv."""
+    post = predict(obj.fm, X, nlv=nlv, ctx=ctx)
+    many = isinstance(post, list)
+    posts = post if many else [post]
+    preds = [obj.lev[np.argmax(z.cpu().numpy() if _is_torch(z) else z, axis=1)].reshape(-1, 1) for z in posts]
+    return (preds, posts) if many else (preds[0], posts[0])

@@ -537,3 +537,34 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None):
         rep.append(np.stack(zres))
     res_rep = np.stack(rep)
     return rng, res_rep.mean(axis=(0, 1)), res_rep
+
+
+# --------------------------------------------------------------------------
+# PLSR-DA: plskern on the dummy table of the classes
+# --------------------------------------------------------------------------
+def dummy(y):
+    """src/utility.jl:509-519 — (Y n x nlev of 0/1, sorted levels)."""
+    y = np.asarray(y).reshape(-1)
+    lev = np.unique(y)
+    return (y[:, None] == lev[None, :]).astype(np.float64), lev
+
+
+def plsrda(X, y, weights=None, *, nlv: int, scal: bool = False):
+    """src/plsrda.jl:71-77 — returns (fm, lev, ni)."""
+    Y, lev = dummy(y)
+    ni = np.array([(np.asarray(y).reshape(-1) == l).sum() for l in lev])
+    return plskern(X, Y, weights, nlv=nlv, scal=scal), lev, ni
+
+
+def plsrda_predict(model, X, *, nlv=None):
+    """src/plsrda.jl:95-120 — (pred list of (m,1) labels, posterior list of (m, nlev)); one nlv -> bare arrays."""
+    fm, lev, _ = model
+    a = fm.T.shape[1]
+    if nlv is None:
+        rng = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng = list(range(max(int(vals.min()), 0), min(int(vals.max()), a) + 1))
+    post = [predict(fm, X, nlv=k) for k in rng]
+    pred = [lev[np.argmax(z, axis=1)].reshape(-1, 1) for z in post]      # ties: the first maximum, like Julia's argmax
+    return (pred[0], post[0]) if len(rng) == 1 else (pred, post)

@@ -441,3 +441,22 @@ def test_device_leading_dimension(pad, J):
     fm2 = J.plskern_(Xd, Yd, nlv=nlv, scal=True, ctx=tctx)           # in place through the strided view
     assert O.rel_fro((X - ref.xmeans) / ref.xscales, Xd.cpu().numpy()) < TIGHT and torch.isnan(Xp[n:]).all()
     tctx.close()
+
+
+def test_plsrda(J, ctx):
+    """§8f rank 4: PLSR-DA = plskern on the class dummy table + argmax (src/plsrda.jl:71-120)."""
+    n, p = 900, 20
+    X = O.rand_matrix(1, n, p)
+    score = X[:, 0] + 0.5 * X[:, 1] - X[:, 2]
+    y = np.where(score < 0.1, "a", np.where(score < 0.45, "b", "c"))
+    Xq = O.rand_matrix(2, 50, p)
+    ref = O.plsrda(X, y, nlv=5)
+    rp, rpost = O.plsrda_predict(ref, Xq, nlv=range(1, 6))
+    fm = J.plsrda(X, y, nlv=5, ctx=ctx)
+    gp, gpost = J.predict(fm, Xq, nlv=range(1, 6), ctx=ctx)
+    assert list(fm.lev) == list(ref[1]) and list(fm.ni) == list(ref[2])
+    for a in range(5):
+        assert O.rel_fro(rpost[a], gpost[a]) < TIGHT
+        assert np.array_equal(rp[a], gp[a])
+    one_pred, one_post = J.predict(fm, Xq, ctx=ctx)
+    assert one_pred.shape == (50, 1) and np.array_equal(one_pred, O.plsrda_predict(ref, Xq)[0])

@@ -13,4 +13,7 @@ python bench.py --algo plsnipals --p 2000 --q 1 --nlv 50 --steps 2 --warmup 1 --
 python bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_bf16.json 2>/dev/null
 python tools/host_rate.py > gpurun_out/final/host_rate.json 2>/dev/null
 python tools/bench_lwplsr.py 2>/dev/null | tail -1 > gpurun_out/final/lwplsr_cfg5.json
+python tools/bench_gridcv.py 2>/dev/null | tail -1 > gpurun_out/final/gridcv.json
+python tools/bench_accessors.py 2>/dev/null | tail -1 > gpurun_out/final/accessors.json
+python bench.py --algo plskern2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_plskern2.json 2>/dev/null
 ls -la gpurun_out/final
