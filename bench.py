@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--p", type=int, default=500)
     ap.add_argument("--q", type=int, default=10)
     ap.add_argument("--nlv", type=int, default=25)
-    ap.add_argument("--algo", choices=["plskern", "plsnipals", "plskern2"], default="plskern",
+    ap.add_argument("--algo", choices=["plskern", "plsnipals", "plskern2", "plssimp", "plsrosa", "plswold"], default="plskern",
                     help="plskern2 = opt-in kernel algorithm #2 (Gram once; not the reference's algorithm, never the headline)")
     ap.add_argument("--dtype", choices=["f64", "bf16"], default="f64", help="bf16 = storage mode of BASELINE configs[2]")
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000)
@@ -138,9 +138,16 @@ def main():
     desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0,
                         reserved=1 if args.algo == "plskern2" else 0)
     got = C.c_int32(0)
-    entry = lib.jch_plsnipals_fit if args.algo == "plsnipals" else lib.jch_plskern_fit
+    entry = {"plsnipals": lib.jch_plsnipals_fit, "plssimp": lib.jch_plssimp_fit, "plsrosa": lib.jch_plsrosa_fit}.get(args.algo, lib.jch_plskern_fit)
+    niter = np.zeros(kmax)
 
     def step():
+        if args.algo == "plswold":   # sibling algorithm: reference defaults tol = sqrt(eps), maxit = 200
+            ctx.check(lib.jch_plswold_fit(ctx._h, C.byref(desc), X.data_ptr(), n, Y.data_ptr(), n, None, float(np.sqrt(np.finfo(float).eps)), 200,
+                                          T.data_ptr(), P.ctypes.data, R.ctypes.data, W.ctypes.data, Cm.ctypes.data, TT.ctypes.data,
+                                          xm.ctypes.data, xs.ctypes.data, ym.ctypes.data, ys.ctypes.data, wn.data_ptr(), niter.ctypes.data,
+                                          C.byref(got)))
+            return
         ctx.check(entry(ctx._h, C.byref(desc), X.data_ptr(), n, Y.data_ptr(), n, None, T.data_ptr(), P.ctypes.data,
                         R.ctypes.data, W.ctypes.data, Cm.ctypes.data, TT.ctypes.data, xm.ctypes.data, xs.ctypes.data,
                         ym.ctypes.data, ys.ctypes.data, wn.data_ptr(), C.byref(got)))
@@ -175,7 +182,8 @@ def main():
         avg_sweep_s = (sweep_ms / max(sweep_launches, 1)) * 1e-3
         achieved = sweep_bytes / avg_sweep_s / 1e9 if avg_sweep_s > 0 else 0.0
         kernel = {"plskern": "k_sweep (fused t = X r, tt, zp = X'Dt, T column store)", "plsnipals": "k_sweep + k_deflate (per LV)",
-                  "plskern2": "k_syrk (X'DX on v_mfma_f64_16x16x4, once per fit)"}[args.algo]
+                  "plskern2": "k_syrk (X'DX on v_mfma_f64_16x16x4, once per fit)", "plssimp": "k_sweep (same fused sweep as plskern)",
+                  "plsrosa": "k_sweep (same fused sweep as plskern)", "plswold": "k_sweep + k_deflate (per LV)"}[args.algo]
         out = {
             "metric": f"latent-variables/sec ({args.algo} n={n_total:.0e} p={p} q={q} nlv={nlv})".replace("e+0", "e"),
             "value": value, "unit": "LV/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,7 +198,7 @@ def main():
                           "frac": n * p * (p + 1) / avg_sweep_s / 1e12 / 78.6, "traffic": None, "flop_per_launch": n * p * (p + 1),
                           "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches} if args.algo == "plskern2" else
                          {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if bf16 else pmc_traffic(args.algo, n, p),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if (bf16 or args.algo not in ("plskern", "plsnipals")) else pmc_traffic(args.algo, n, p),
                          "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches}),
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
                                    "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps},

@@ -111,6 +111,33 @@ JCH_API int32_t jch_plsnipals_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *
                           double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
                           double *weights_norm, int32_t *nlv_out);
 
+/* ---- sibling algorithms: same row kernels, different small state --------------------------------
+ * jch_plssimp_fit — `plssimp!` / `plssimp` (src/plssimp.jl:22-88, SIMPLS with un-normed scores); W is returned equal to R
+ *   (src/plssimp.jl:85-87).  One fused sweep over X per LV, like plskern.
+ * jch_plsrosa_fit — `plsrosa!` / `plsrosa` (src/plsrosa.jl:26-96): X never deflated, Y deflated (inplace = 1 hands back
+ *   the centred X and the deflated Y, :87), W re-orthonormalised (:77-79), R = W inv(P'W) (:94).  One fused sweep per LV:
+ *   the score orthogonalisation of :75-76 is applied to the weight vector before the sweep (t = X r), which is the same
+ *   vector in exact arithmetic.
+ * jch_plswold_fit — `plswold!` / `plswold` (src/plswold.jl:30-111): NIPALS with the inner power iteration; `tol` and
+ *   `maxit` as the reference's keywords (defaults sqrt(eps), 200); niter (nlv, HOST, as Float64 like :71) receives the
+ *   number of inner passes per LV.  The reference seeds each LV's first convergence check with `rand(p)` (:78), which
+ *   can never pass; that check is skipped here.  Rows with zero weight get finite scores here (the reference divides
+ *   by sqrt(w) = 0 at :107 and returns NaN for them).  inplace = 1 hands back X, Y deflated AND carrying the row
+ *   metric sqrt(w) (:57-58).
+ * plssimp / plswold need q <= 16, p <= 2048 and the p x q state inside LDS (JCH_EINVAL otherwise); Float64 only. */
+JCH_API int32_t jch_plssimp_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                        const double *weights, double *T, double *P, double *R, double *W, double *C,
+                        double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
+                        double *weights_norm, int32_t *nlv_out);
+JCH_API int32_t jch_plsrosa_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                        const double *weights, double *T, double *P, double *R, double *W, double *C,
+                        double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
+                        double *weights_norm, int32_t *nlv_out);
+JCH_API int32_t jch_plswold_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                        const double *weights, double tol, int32_t maxit, double *T, double *P, double *R, double *W,
+                        double *C, double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
+                        double *weights_norm, double *niter, int32_t *nlv_out);
+
 /*
  * jch_affine_gemm — out (m x k, ld ldo) = ((X - 1*shift') * diag(1/scale)) * B + 1*bias'
  * the single device primitive behind `transform` (src/plskern.jl:187-195: shift = xmeans, scale =
@@ -122,6 +149,20 @@ JCH_API int32_t jch_plsnipals_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *
 JCH_API int32_t jch_affine_gemm(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx,
                         const double *shift, const double *scale, const double *B, int64_t k,
                         const double *bias, double *out, int64_t ldo);
+
+/* jch_transform — `transform(object::Plsr, X; nlv)` (src/plskern.jl:187-195): T (m x nlv, ld ldt) [loc] =
+ * cscale(X, xmeans, xscales) * R[:, 1:nlv].  X m x p [loc]; xmeans, xscales (p), R (p x >= nlv, ld p) HOST. */
+JCH_API int32_t jch_transform(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx,
+                      const double *xmeans, const double *xscales, const double *R, int32_t nlv, double *T, int64_t ldt);
+
+/* jch_predict — `predict(object::Plsr, X; nlv)` (src/plskern.jl:226-238 through coef, :207-217) for every nlv in
+ * [nlv_lo, nlv_hi] (0 = intercept only) in ONE pass over X: pred (m x q*(nlv_hi-nlv_lo+1), ld ldo) [loc]; block b =
+ * columns b*q .. b*q+q-1 = prediction with nlv_lo + b LVs.  Model pieces (xmeans, xscales p; ymeans, yscales q;
+ * R p x nlv_fit ld p; C q x nlv_fit ld q) HOST, nlv_hi <= nlv_fit is the caller's responsibility (the reference
+ * clamps at :228). */
+JCH_API int32_t jch_predict(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx, const double *xmeans,
+                    const double *xscales, const double *ymeans, const double *yscales, const double *R, const double *C,
+                    int64_t q, int32_t nlv_lo, int32_t nlv_hi, double *pred, int64_t ldo);
 
 /* jch_weighted_ss — sum_i d_i * || (x_i - shift) / scale ||^2 : the `sstot` of `summary`
  * (src/plskern.jl:250-251).  X n x p and d (n) [loc]; shift/scale HOST; result HOST.  With a

@@ -20,7 +20,11 @@ struct fit_io {
     void *X; int64_t ldx; void *Y; int64_t ldy; const double *weights;
     double *T, *P, *R, *W, *C, *TT, *xmeans, *xscales, *ymeans, *yscales, *weights_norm;
     int32_t *nlv_out;
+    double tol = 0.0; int maxit = 0; double *niter = nullptr;   // plswold only
 };
+
+// algorithm codes of fit_impl
+enum { ALGO_KERN = 0, ALGO_NIPALS = 1, ALGO_SIMP = 2, ALGO_ROSA = 3, ALGO_WOLD = 4 };
 
 int32_t validate(jch_ctx *ctx, const fit_io &io, const char *who)
 {
@@ -71,7 +75,10 @@ float ev_ms(hipEvent_t a, hipEvent_t b)
 
 int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
 {
-    const char *who = algo == 0 ? "jch_plskern_fit" : "jch_plsnipals_fit";
+    static const char *const names[] = {"jch_plskern_fit", "jch_plsnipals_fit", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit"};
+    const char *who = names[algo];
+    // plssimp and plsrosa run the plskern-shaped loop (one fused sweep per LV), plswold the plsnipals-shaped one
+    const bool kern_like = algo == ALGO_KERN || algo == ALGO_SIMP || algo == ALGO_ROSA;
     if (!ctx) return JCH_EINVAL;
     JCH_TRY(validate(ctx, io, who));
     JCH_HIP(ctx, hipSetDevice(ctx->device));
@@ -115,7 +122,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
     const size_t small_bytes = 256 * 16 + sizeof(double) * ((size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
-                                                         (size_t)nlv_cap * q + 34 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8);
+                                                         (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
@@ -126,11 +133,12 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     s.zt = cv.take((size_t)JCH_ZT_SLICES * ldz); s.zpc = cv.take((size_t)ldr + qpad);
     s.mom = cv.take(p + q); s.scl = cv.take(p + q); s.hdr = cv.take(8);
     s.variant = 0;
+    s.niter = algo == ALGO_WOLD ? cv.take(nlv_cap) : nullptr;
     s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
 
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
     if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
-        if (algo != 0) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
+        if (algo != ALGO_KERN) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
         const bool fastb = q <= 16 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
         hipEvent_t evb = jch_ev(ctx);
         int nlvb = 0;
@@ -175,19 +183,21 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     // the fast small-state kernel sums the second-stage slices itself; with several GPUs the [slices][ldz] block is
     // all-reduced as one message (still latency-bound at 32 KB) instead of being collapsed by an extra launch
     const int max_slices = fast ? JCH_ZT_SLICES : 1;
+    if ((algo == ALGO_SIMP || algo == ALGO_WOLD) && !jch_sibling_supported(p, q, ldr, nlv))
+        return jch_fail(ctx, JCH_EINVAL, "%s: needs q <= 16, p <= %d and the p x q state inside LDS (p=%d q=%d nlv=%d)", who, JCH_SWEEP_MAXP, p, q, nlv);
     int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
     JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
     if (d.scal) JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl));
     else hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
-    JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && algo == 0, Xr, ldr, Yr, qpad, s.K, d.scal != 0));
+    JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && kern_like, Xr, ldr, Yr, qpad, s.K, d.scal != 0));
     hipEvent_t ev_prologue = jch_ev(ctx);
 
     // ---- LV loop
     const size_t sweep_ev0 = ctx->ev_used;
     const bool variant2 = d.reserved == 1;
     if (variant2) {   // OPT-IN kernel algorithm #2 (kern2.hip): Gram once, LV loop without X and without collectives
-        if (algo != 0 || !fast) return jch_fail(ctx, JCH_EINVAL, "%s: variant 2 needs plskern with q <= 16 and p <= %d", who, JCH_SWEEP_MAXP);
+        if (algo != ALGO_KERN || !fast) return jch_fail(ctx, JCH_EINVAL, "%s: variant 2 needs plskern with q <= 16 and p <= %d", who, JCH_SWEEP_MAXP);
         JCH_TRY(jch_reserve(ctx, ctx->gram, sizeof(double) * (size_t)p * ldr));
         double *G = (double *)ctx->gram.ptr;
         JCH_TRY(jch_launch_syrk(ctx, Xr, n, p, ldr, dn, G, ldr));
@@ -199,40 +209,51 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         }
         JCH_TRY(jch_launch_scores(ctx, Xr, n, p, ldr, s.R, nlv, Tdev));
     } else {
-    JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, algo, 1, ldz, fast));
+    if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, -1, nlv, 1, ldz));
+    else if (algo == ALGO_WOLD) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, 0, nlv, io.tol, io.maxit));
+    else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, kern_like ? 0 : 1, 1, ldz, fast));
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
-        if (algo == 0) {
+        if (kern_like) {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
             JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1));  // ONE collective per LV: [zp (p), tt]
-            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
+            if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
+            else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
         } else {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
             JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1 + qpad));  // [zp_raw, tt, c_raw]
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast));
             const bool last = a + 1 == nlv;
             if (!last || inplace) {
-                // X -= t zp', Y -= t c' fused with the next K = X'DY (src/plsnipals.jl:86-87,71)
+                // X -= t zp', Y -= t c' fused with the next K = X'DY (src/plsnipals.jl:86-87,71; src/plswold.jl:98-99)
                 JCH_TRY(jch_launch_deflate(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, tcol, s.zpc, last ? nullptr : s.K));
             }
-            if (!last) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 1, 1, ldz, fast));
+            if (!last) {
+                if (algo == ALGO_WOLD) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, a + 1, nlv, io.tol, io.maxit));
+                else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 1, 1, ldz, fast));
+            }
         }
     }
     }
-    if (algo == 1) JCH_TRY(jch_launch_nipals_R(ctx, s, p, nlv));
+    if (algo == ALGO_ROSA) JCH_TRY(jch_launch_rosa_orthw(ctx, s.W, p, nlv));   // src/plsrosa.jl:77-79
+    if (algo == ALGO_NIPALS || algo == ALGO_WOLD || algo == ALGO_ROSA) JCH_TRY(jch_launch_nipals_R(ctx, s, p, nlv));   // R = W inv(P'W)
     hipEvent_t ev_end = jch_ev(ctx);
     const size_t sweep_ev1 = ctx->ev_used;
 
     // ---- results
-    if (algo == 1 && inplace) {  // hand back centred + deflated X, Y in the caller's column-major arrays
-        JCH_TRY(jch_launch_export_colmajor(ctx, Xr, ldr, Yr, qpad, n, p, q, Xc, ldxc, Yc, ldyc));
+    if (!kern_like && inplace) {  // hand back centred + deflated X, Y in the caller's column-major arrays
+        // (plswold! additionally leaves the row metric sqrt(w) on them, src/plswold.jl:57-58)
+        JCH_TRY(jch_launch_export_colmajor(ctx, Xr, ldr, Yr, qpad, n, p, q, Xc, ldxc, Yc, ldyc, algo == ALGO_WOLD ? dn : nullptr));
     }
+    if (algo == ALGO_ROSA && inplace) JCH_TRY(jch_launch_ydeflate_all(ctx, Yc, ldyc, Tdev, n, s.C, q, nlv));   // src/plsrosa.jl:87
     auto d2h = [&](double *dst, const double *src, size_t count) -> int32_t {
         if (dst) JCH_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
         return JCH_OK;
     };
-    JCH_TRY(d2h(io.P, s.P, (size_t)nlv * p)); JCH_TRY(d2h(io.R, s.R, (size_t)nlv * p)); JCH_TRY(d2h(io.W, s.W, (size_t)nlv * p));
+    JCH_TRY(d2h(io.P, s.P, (size_t)nlv * p)); JCH_TRY(d2h(io.R, s.R, (size_t)nlv * p));
+    JCH_TRY(d2h(io.W, algo == ALGO_SIMP ? s.R : s.W, (size_t)nlv * p));   // SIMPLS has no W: R in its place (src/plssimp.jl:85-87)
     JCH_TRY(d2h(io.C, s.C, (size_t)nlv * q)); JCH_TRY(d2h(io.TT, s.TT, nlv));
+    if (algo == ALGO_WOLD) JCH_TRY(d2h(io.niter, s.niter, nlv));
     JCH_TRY(d2h(io.xmeans, s.mom, p)); JCH_TRY(d2h(io.ymeans, s.mom + p, q));
     JCH_TRY(d2h(io.xscales, s.scl, p)); JCH_TRY(d2h(io.yscales, s.scl + p, q));
     if (host) {
@@ -269,10 +290,10 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         double sw = 0.0; int cnt = 0;
         for (size_t i = sweep_ev0; i + 1 < sweep_ev1; i += 2) { sw += ev_ms(ctx->ev_pool[i], ctx->ev_pool[i + 1]); ++cnt; }
         pr.sweep_ms = sw;
-        pr.sweep_launches = variant2 ? 1 : (algo == 0 ? cnt : nlv);
+        pr.sweep_launches = variant2 ? 1 : (kern_like ? cnt : nlv);
         pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
         const double per_x = (double)n * ldr * 8.0;
-        pr.sweep_bytes = algo == 0 ? per_x + 16.0 * (double)n : 3.0 * per_x;
+        pr.sweep_bytes = kern_like ? per_x + 16.0 * (double)n : 3.0 * per_x;
     }
     return JCH_OK;
 }
@@ -295,4 +316,32 @@ extern "C" int32_t jch_plsnipals_fit(jch_ctx *ctx, const jch_pls_desc *desc, voi
 {
     fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
     return fit_impl(ctx, io, 1);
+}
+
+extern "C" int32_t jch_plssimp_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                                   const double *weights, double *T, double *P, double *R, double *W, double *C, double *TT,
+                                   double *xmeans, double *xscales, double *ymeans, double *yscales, double *weights_norm,
+                                   int32_t *nlv_out)
+{
+    fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
+    return fit_impl(ctx, io, ALGO_SIMP);
+}
+
+extern "C" int32_t jch_plsrosa_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                                   const double *weights, double *T, double *P, double *R, double *W, double *C, double *TT,
+                                   double *xmeans, double *xscales, double *ymeans, double *yscales, double *weights_norm,
+                                   int32_t *nlv_out)
+{
+    fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
+    return fit_impl(ctx, io, ALGO_ROSA);
+}
+
+extern "C" int32_t jch_plswold_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                                   const double *weights, double tol, int32_t maxit, double *T, double *P, double *R, double *W,
+                                   double *C, double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
+                                   double *weights_norm, double *niter, int32_t *nlv_out)
+{
+    fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
+    io.tol = tol; io.maxit = maxit; io.niter = niter;
+    return fit_impl(ctx, io, ALGO_WOLD);
 }

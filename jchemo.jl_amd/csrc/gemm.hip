@@ -241,3 +241,49 @@ extern "C" int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, i
     *sstot = s;
     return JCH_OK;
 }
+
+// ---- named accessors of the §8b export list: thin host arithmetic over jch_affine_gemm --------------------------
+// transform(object::Plsr, X; nlv) = cscale(X, xmeans, xscales) * R[:, 1:nlv]      (src/plskern.jl:187-195)
+extern "C" int32_t jch_transform(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx,
+                                 const double *xmeans, const double *xscales, const double *R, int32_t nlv, double *T, int64_t ldt)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!R || nlv < 1) return jch_fail(ctx, JCH_EINVAL, "jch_transform: R is NULL or nlv < 1");
+    return jch_affine_gemm(ctx, loc, X, m, p, ldx, xmeans, xscales, R, nlv, nullptr, T, ldt);
+}
+
+// predict(object::Plsr, X; nlv) for every nlv in [nlv_lo, nlv_hi] (0 allowed: intercept only), via coef
+// (src/plskern.jl:207-217: B = diag(1/xscales) R_k C_k' diag(yscales), int = ymeans' - xmeans' B) and
+// pred = int .+ X B (src/plskern.jl:226-238).  The coefficient blocks of the whole range are concatenated
+// [B_lo | ... | B_hi] so X is read ONCE; block b of `pred` (columns b*q .. b*q+q-1) is the prediction at nlv_lo + b.
+extern "C" int32_t jch_predict(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx, const double *xmeans,
+                               const double *xscales, const double *ymeans, const double *yscales, const double *R,
+                               const double *C, int64_t q, int32_t nlv_lo, int32_t nlv_hi, double *pred, int64_t ldo)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!R || !C || q < 1 || nlv_lo < 0 || nlv_hi < nlv_lo) return jch_fail(ctx, JCH_EINVAL, "jch_predict: bad model arguments");
+    const int64_t le = (int64_t)nlv_hi - nlv_lo + 1, kcols = le * q;
+    std::vector<double> B((size_t)p * kcols, 0.0), b0((size_t)kcols, 0.0), cur((size_t)p * q, 0.0);
+    for (int a = 0; a <= nlv_hi; ++a) {
+        if (a > 0) {   // B_a = B_{a-1} + (r_a / xscales) (c_a * yscales)'
+            const double *r = R + (size_t)(a - 1) * p, *c = C + (size_t)(a - 1) * q;
+            for (int64_t k = 0; k < q; ++k) {
+                const double ck = c[k] * (yscales ? yscales[k] : 1.0);
+                for (int64_t j = 0; j < p; ++j) cur[j + k * p] += r[j] / (xscales ? xscales[j] : 1.0) * ck;
+            }
+        }
+        if (a >= nlv_lo) {
+            const int64_t blk = a - nlv_lo;
+            for (int64_t k = 0; k < q; ++k) {
+                double acc = ymeans ? ymeans[k] : 0.0;
+                for (int64_t j = 0; j < p; ++j) {
+                    const double v = cur[j + k * p];
+                    B[j + (blk * q + k) * p] = v;
+                    if (xmeans) acc -= xmeans[j] * v;
+                }
+                b0[blk * q + k] = acc;
+            }
+        }
+    }
+    return jch_affine_gemm(ctx, loc, X, m, p, ldx, nullptr, nullptr, B.data(), kcols, b0.data(), pred, ldo);
+}

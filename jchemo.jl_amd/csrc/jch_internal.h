@@ -87,7 +87,8 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                               int64_t n, int p, int q, const double *mom, const double *scl, bool writeback,
                               double *Xr, int ldr, double *Yr, int qpad, double *K /*[p][qpad] device*/, bool scal);
 int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n,
-                                   int p, int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy);
+                                   int p, int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy,
+                                   const double *sqrt_rowscale = nullptr /*rows scaled by sqrt(d_i): plswold! row metric*/);
 // sweep.hip
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra /*0: plskern; q: also c_raw (plsnipals)*/,
@@ -113,6 +114,7 @@ struct jch_small {  // device-resident replicated small state of one fit
     double *hdr;        // [4]
     int variant;        // 0: algorithm #1 (zt holds [zp, tt] from the sweep); 1: algorithm #2 (zt = G r, tt = r'zp computed here)
     double *dbg;        // [nlv + 1] diagnostics (JCH_LV_DEBUG): Jacobi sweeps per LV; may be null
+    double *niter;      // [nlv] plswold: inner iterations per LV (src/plswold.jl:93); null otherwise
 };
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a /*-1: init*/,
                              int nlv, int algo /*0 plskern, 1 plsnipals*/, int nslice, int ldz, bool fast);
@@ -120,6 +122,12 @@ size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv);
 int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
                                   int do_a, int do_b, int nslice, int ldz);
 int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv);
+// siblings.hip (plssimp / plsrosa / plswold small-state kernels)
+bool jch_sibling_supported(int p, int q, int ldr, int nlv);
+int32_t jch_launch_lv_update_simp(jch_ctx *ctx, const jch_small &s, int p, int q, int ldr, int a /*-1: init*/, int nlv, int nslice, int ldz);
+int32_t jch_launch_wold_b(jch_ctx *ctx, const jch_small &s, int p, int q, int ldr, int a, int nlv, double tol, int maxit);
+int32_t jch_launch_rosa_orthw(jch_ctx *ctx, double *W, int p, int nlv);
+int32_t jch_launch_ydeflate_all(jch_ctx *ctx, double *Yc, int64_t ldy, const double *T, int64_t n, const double *C, int q, int nlv);
 // gemm.hip
 int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p, int64_t ldx, const double *Bs /*[p][kpad] scaled*/,
                                int k, int kpad, const double *bias /*[kpad]*/, double *out, int64_t ldo);

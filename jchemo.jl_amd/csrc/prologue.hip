@@ -475,7 +475,8 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
 // (plsnipals! hands back the deflated X, Y: src/plsnipals.jl:86-87)
 __global__ __launch_bounds__(256) void k_export_colmajor(const double *__restrict__ Xr, int ldr, const double *__restrict__ Yr,
                                                           int qpad, int64_t n, int p, int q, double *__restrict__ Xc,
-                                                          int64_t ldx, double *__restrict__ Yc, int64_t ldy)
+                                                          int64_t ldx, double *__restrict__ Yc, int64_t ldy,
+                                                          const double *__restrict__ dsc)
 {
     __shared__ double xt[64 * XT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -495,14 +496,14 @@ __global__ __launch_bounds__(256) void k_export_colmajor(const double *__restric
             for (int k = 0; k < 16; ++k) {
                 const int col = wv + 4 * k, j = j0 + col;
                 const int64_t i = i0 + lane;
-                if (i < n && j < p) Xc[(size_t)i + (size_t)j * (size_t)ldx] = xt[lane * XT_LD + col];
+                if (i < n && j < p) Xc[(size_t)i + (size_t)j * (size_t)ldx] = xt[lane * XT_LD + col] * (dsc ? sqrt(dsc[i]) : 1.0);
             }
         }
         if (blockIdx.y == 0 && Yc) {
             for (int e = tid; e < 64 * q; e += 256) {
                 const int row = e & 63, yc = e >> 6;
                 const int64_t i = i0 + row;
-                if (i < n) Yc[(size_t)i + (size_t)yc * (size_t)ldy] = Yr[(size_t)i * qpad + yc];
+                if (i < n) Yc[(size_t)i + (size_t)yc * (size_t)ldy] = Yr[(size_t)i * qpad + yc] * (dsc ? sqrt(dsc[i]) : 1.0);
             }
         }
         __syncthreads();
@@ -510,14 +511,14 @@ __global__ __launch_bounds__(256) void k_export_colmajor(const double *__restric
 }
 
 int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n, int p,
-                                   int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy)
+                                   int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *sqrt_rowscale)
 {
     const int ptiles = Xr ? (p + 63) / 64 : 1;
     const int64_t nchunks = (n + 63) / 64;
     int nbx = (ctx->cus * 4 + ptiles - 1) / ptiles;
     if (nbx > nchunks) nbx = (int)(nchunks > 0 ? nchunks : 1);
     hipLaunchKernelGGL(k_export_colmajor, dim3(nbx, ptiles), dim3(256), 0, ctx->stream, Xr, ldr, Yr, qpad, n, p, q, Xc, ldx,
-                       Yc, ldy);
+                       Yc, ldy, sqrt_rowscale);
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }

@@ -24,7 +24,8 @@ SYMBOLS = (
     "jch_version", "jch_ctx_create", "jch_ctx_destroy", "jch_last_error", "jch_comm_unique_id",
     "jch_ctx_comm_init", "jch_ctx_comm_info", "jch_plskern_fit", "jch_plsnipals_fit", "jch_affine_gemm",
     "jch_weighted_ss", "jch_fill_uniform", "jch_ctx_set_profiling", "jch_ctx_get_profile", "jch_lwplsr_predict",
-    "jch_weighted_cov", "jch_score_sums",
+    "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
+    "jch_predict",
 )
 
 
@@ -68,6 +69,11 @@ def load():
     fit = [vp, C.POINTER(PlsDesc), dp, i64, dp, i64, dp] + [dp] * 11 + [C.POINTER(i32)]
     L.jch_plskern_fit.argtypes = fit
     L.jch_plsnipals_fit.argtypes = fit
+    L.jch_plssimp_fit.argtypes = fit
+    L.jch_plsrosa_fit.argtypes = fit
+    L.jch_plswold_fit.argtypes = ([vp, C.POINTER(PlsDesc), dp, i64, dp, i64, dp, C.c_double, i32] + [dp] * 11 + [dp, C.POINTER(i32)])
+    L.jch_transform.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, i32, dp, i64]
+    L.jch_predict.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, dp, dp, dp, i64, i32, i32, dp, i64]
     L.jch_affine_gemm.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, i64, dp, dp, i64]
     L.jch_weighted_ss.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, C.POINTER(C.c_double)]
     L.jch_lwplsr_predict.argtypes = [vp, i32, dp, i64, i64, i64, dp, i64, i64, dp, i64, dp, i64, i64, dp, i64, i64, i32,

@@ -120,7 +120,8 @@ def _np(a):
 
 
 # ---------------------------------------------------------------------------------- fits
-def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Optional[Context], variant: int = 0):
+def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Optional[Context], variant: int = 0,
+         wold: Optional[tuple] = None):
     dev = _is_torch(X)
     if dev != _is_torch(Y):
         raise TypeError("X and Y must both be host arrays or both device tensors")
@@ -165,11 +166,19 @@ def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Op
     got = C.c_int32(0)
     if dev:
         torch.cuda.current_stream(X.device).synchronize()  # inputs produced on other streams are complete
-    st = getattr(_lib.load(), entry)(ctx._h, C.byref(desc), xa, ldx, ya, ldy, w_addr, t_addr, _np(P), _np(R), _np(W),
-                                      _np(Cm), _np(TT), _np(xm), _np(xs), _np(ym), _np(ys), wn_addr, C.byref(got))
+    niter = None
+    if wold is not None:   # jch_plswold_fit: tol, maxit after weights; niter before nlv_out
+        niter = np.zeros(kmax)
+        st = _lib.load().jch_plswold_fit(ctx._h, C.byref(desc), xa, ldx, ya, ldy, w_addr, float(wold[0]), int(wold[1]), t_addr,
+                                         _np(P), _np(R), _np(W), _np(Cm), _np(TT), _np(xm), _np(xs), _np(ym), _np(ys), wn_addr,
+                                         _np(niter), C.byref(got))
+    else:
+        st = getattr(_lib.load(), entry)(ctx._h, C.byref(desc), xa, ldx, ya, ldy, w_addr, t_addr, _np(P), _np(R), _np(W),
+                                          _np(Cm), _np(TT), _np(xm), _np(xs), _np(ym), _np(ys), wn_addr, C.byref(got))
     ctx.check(st)
     k = got.value
-    return Plsr(T[:, :k], P[:, :k], R[:, :k], W[:, :k], Cm[:, :k], TT[:k], xm, xs, ym, ys, wn, None)
+    return Plsr(T[:, :k], P[:, :k], R[:, :k], W[:, :k], Cm[:, :k], TT[:k], xm, xs, ym, ys, wn,
+                None if niter is None else niter[:k])
 
 
 def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, variant: int = 0) -> Plsr:
@@ -203,6 +212,50 @@ def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional
 def plsnipals_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
     """`plsnipals!` — src/plsnipals.jl:37-97: X, Y end up centred/scaled AND deflated."""
     return _fit("jch_plsnipals_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
+
+
+def _copy_fit(entry, X, Y, weights, nlv, scal, ctx, wold=None):
+    X = ensure_mat(X); Y = ensure_mat(Y)
+    try:
+        _addr_ld(X); _addr_ld(Y)
+    except (ValueError, TypeError):
+        X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
+    return _fit(entry, X, Y, weights, nlv, scal, False, ctx, wold=wold)
+
+
+def plssimp(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plssimp` — src/plssimp.jl:22-26 (SIMPLS, scores not normed; `W` is returned equal to `R`, :85-87)."""
+    return _copy_fit("jch_plssimp_fit", X, Y, weights, nlv, scal, ctx)
+
+
+def plssimp_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plssimp!` — src/plssimp.jl:28-88: X, Y overwritten with their centred/scaled versions."""
+    return _fit("jch_plssimp_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
+
+
+def plsrosa(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plsrosa` — src/plsrosa.jl:26-30."""
+    return _copy_fit("jch_plsrosa_fit", X, Y, weights, nlv, scal, ctx)
+
+
+def plsrosa_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plsrosa!` — src/plsrosa.jl:32-96: X ends up centred/scaled, Y centred/scaled AND deflated (:87)."""
+    return _fit("jch_plsrosa_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
+
+
+_SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
+
+
+def plswold(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,
+            ctx: Optional[Context] = None) -> Plsr:
+    """`plswold` — src/plswold.jl:30-34; `niter` (inner passes per LV) as :93."""
+    return _copy_fit("jch_plswold_fit", X, Y, weights, nlv, scal, ctx, wold=(tol, maxit))
+
+
+def plswold_(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,
+             ctx: Optional[Context] = None) -> Plsr:
+    """`plswold!` — src/plswold.jl:36-111: X, Y end up centred/scaled, carrying the row metric sqrt(w) and deflated."""
+    return _fit("jch_plswold_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx, wold=(tol, maxit))
 
 
 # ---------------------------------------------------------------------------------- accessors
@@ -240,10 +293,59 @@ def _affine(X, shift, scale, B, bias, ctx):
     return out
 
 
+def _x_out(X, k, ctx):
+    """Common plumbing of the accessors: column-major X, an m x k output next to it, the ctx."""
+    X = ensure_mat(X)
+    try:
+        _addr_ld(X)
+    except (ValueError, TypeError):
+        X = _as_colmajor_copy(X)
+    dev = _is_torch(X)
+    m = X.shape[0]
+    ctx = ctx or default_context((X.device.index or 0) if dev else 0)
+    if dev:
+        out = colmajor_empty(m, k, X.device)
+        torch.cuda.current_stream(X.device).synchronize()
+        oa = out.data_ptr()
+    else:
+        out = np.empty((m, k), dtype=np.float64, order="F")
+        oa = out.ctypes.data
+    return X, out, oa, ctx, (_lib.LOC_DEVICE if dev else _lib.LOC_HOST)
+
+
+def _model_vec(v):
+    return np.ascontiguousarray(v, dtype=np.float64)
+
+
 def transform(fm: Plsr, X, *, nlv: Optional[int] = None, ctx: Optional[Context] = None):
-    """src/plskern.jl:187-195: `cscale(X, xmeans, xscales) * R[:, 1:nlv]` (nlv clamped to the model's)."""
+    """src/plskern.jl:187-195: `cscale(X, xmeans, xscales) * R[:, 1:nlv]` (nlv clamped to the model's) — jch_transform."""
     k = _nlv_arg(fm, nlv)
-    return _affine(X, fm.xmeans, fm.xscales, fm.R[:, :k], None, ctx)
+    if k < 1:
+        raise ValueError("transform needs nlv >= 1")
+    X, out, oa, ctx, loc = _x_out(X, k, ctx)
+    m, p = X.shape
+    if fm.R.shape[0] != p:
+        raise ValueError(f"DimensionMismatch: X has {p} columns, the model has {fm.R.shape[0]}")
+    R = np.asfortranarray(fm.R[:, :k], dtype=np.float64)
+    xm, xs = _model_vec(fm.xmeans), _model_vec(fm.xscales)
+    xa, ldx = _addr_ld(X)
+    ctx.check(_lib.load().jch_transform(ctx._h, loc, xa, m, p, ldx, _np(xm), _np(xs), R.ctypes.data, k, oa, max(m, 1)))
+    return out
+
+
+def _predict_range(fm: Plsr, X, lo: int, hi: int, ctx):
+    """jch_predict: predictions for every nlv in lo..hi, one pass over X; m x (q * (hi - lo + 1))."""
+    q = fm.C.shape[0]
+    X, out, oa, ctx, loc = _x_out(X, q * (hi - lo + 1), ctx)
+    m, p = X.shape
+    if fm.R.shape[0] != p:
+        raise ValueError(f"DimensionMismatch: X has {p} columns, the model has {fm.R.shape[0]}")
+    R = np.asfortranarray(fm.R, dtype=np.float64); Cm = np.asfortranarray(fm.C, dtype=np.float64)
+    xm, xs, ym, ys = (_model_vec(v) for v in (fm.xmeans, fm.xscales, fm.ymeans, fm.yscales))
+    xa, ldx = _addr_ld(X)
+    ctx.check(_lib.load().jch_predict(ctx._h, loc, xa, m, p, ldx, _np(xm), _np(xs), _np(ym), _np(ys), R.ctypes.data,
+                                      Cm.ctypes.data, q, lo, hi, oa, max(m, 1)))
+    return out
 
 
 def coef(fm: Plsr, *, nlv: Optional[int] = None):
@@ -267,8 +369,7 @@ def _pred_matrix(fm: "Plsr", X, rng, ctx):
         for ai, a_ in enumerate(rng):
             Bc[:a_, ai * q:(ai + 1) * q] = (fm.C[:, :a_] * fm.yscales[:, None]).T
         return _affine(Tq, None, None, Bc, np.tile(fm.ymeans, len(rng)), ctx)
-    Bs, ints = zip(*(coef(fm, nlv=k) for k in rng))
-    return _affine(X, None, None, np.concatenate(Bs, axis=1), np.concatenate([i.reshape(-1) for i in ints]), ctx)
+    return _predict_range(fm, X, rng[0], rng[-1], ctx)   # rng is contiguous (src/plskern.jl:228)
 
 
 def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Optional[Context] = None):

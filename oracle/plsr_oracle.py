@@ -223,6 +223,131 @@ def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
 
 
 # --------------------------------------------------------------------------
+# Sibling algorithms: SIMPLS, ROSA, Wold's NIPALS
+# --------------------------------------------------------------------------
+def plssimp_(X: np.ndarray, Y: np.ndarray, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plssimp!` — src/plssimp.jl:28-88 (de Jong 1993, scores not normed).  XtY is never deflated: each LV
+    projects it on the orthogonal complement of the loadings found so far (:65-70); W does not exist in SIMPLS and
+    is returned as R (:85-87)."""
+    assert X.dtype == np.float64 and Y.dtype == np.float64 and X.ndim == 2 and Y.ndim == 2
+    if weights is None:
+        weights = np.ones(X.shape[0])
+    n, p, q, nlv, weights, xmeans, ymeans, xscales, yscales = _preamble(X, Y, weights, nlv, scal)
+    XtY = X.T @ (weights[:, None] * Y)                      # :47-48
+    T = np.empty((n, nlv)); P = np.empty((p, nlv)); R = np.empty((p, nlv))
+    C = np.empty((q, nlv)); TT = np.empty(nlv)
+    for a in range(nlv):                                    # :64-83
+        if a == 0:
+            tmp = XtY.copy()
+        else:
+            zP = P[:, :a]
+            tmp = XtY - zP @ np.linalg.inv(zP.T @ zP) @ (zP.T @ XtY)   # :69
+        U, _, _ = np.linalg.svd(tmp, full_matrices=False)   # :71 (also for q == 1)
+        r = U[:, 0].copy()
+        t = X @ r
+        dt = weights * t
+        tt = np.dot(t, dt)
+        c = (XtY.T @ r) / tt                                # :75-76
+        zp = X.T @ dt                                       # :77
+        P[:, a] = zp / tt; T[:, a] = t; R[:, a] = r; C[:, a] = c; TT[a] = tt
+    return Plsr(T, P, R, R.copy(), C, TT, xmeans, xscales, ymeans, yscales, weights, None)
+
+
+def plssimp(X, Y, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plssimp` — src/plssimp.jl:22-26."""
+    Xc = np.array(ensure_mat(X), dtype=np.float64, copy=True)
+    Yc = np.array(ensure_mat(Y), dtype=np.float64, copy=True)
+    return plssimp_(Xc, Yc, weights, nlv=nlv, scal=scal)
+
+
+def plsrosa_(X: np.ndarray, Y: np.ndarray, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plsrosa!` — src/plsrosa.jl:32-96 (Liland et al. 2016).  X stays centred (never deflated); Y is deflated in
+    place (:87); scores are orthogonalised against the previous ones in the D metric (:75-76), weights against the
+    previous weights (:77-79); R = W inv(P'W) (:94)."""
+    assert X.dtype == np.float64 and Y.dtype == np.float64 and X.ndim == 2 and Y.ndim == 2
+    if weights is None:
+        weights = np.ones(X.shape[0])
+    n, p, q, nlv, weights, xmeans, ymeans, xscales, yscales = _preamble(X, Y, weights, nlv, scal)
+    T = np.empty((n, nlv)); W = np.empty((p, nlv)); P = np.empty((p, nlv))
+    C = np.empty((q, nlv)); TT = np.empty(nlv)
+    for a in range(nlv):                                    # :65-93
+        XtY = X.T @ (weights[:, None] * Y)                  # :66
+        w = dominant_left_sv(XtY)                           # :67-72
+        t = X @ w                                           # :73
+        if a > 0:
+            z = T[:, :a]
+            t = t - z @ (np.linalg.inv(z.T @ (weights[:, None] * z)) @ (z.T @ (weights * t)))   # :76
+            z = W[:, :a]
+            w = w - z @ (z.T @ w)                           # :78
+            w = w / np.sqrt(np.dot(w, w))                   # :79
+        dt = weights * t
+        tt = np.dot(t, dt)
+        c = (Y.T @ dt) / tt                                 # :83-84
+        zp = (X.T @ dt) / tt                                # :85-86
+        Y -= np.outer(t, c)                                 # :87
+        P[:, a] = zp; T[:, a] = t; W[:, a] = w; C[:, a] = c; TT[a] = tt
+    R = W @ np.linalg.inv(P.T @ W)                          # :94
+    return Plsr(T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights, None)
+
+
+def plsrosa(X, Y, weights=None, *, nlv: int, scal: bool = False) -> Plsr:
+    """`plsrosa` — src/plsrosa.jl:26-30."""
+    Xc = np.array(ensure_mat(X), dtype=np.float64, copy=True)
+    Yc = np.array(ensure_mat(Y), dtype=np.float64, copy=True)
+    return plsrosa_(Xc, Yc, weights, nlv=nlv, scal=scal)
+
+
+def plswold_(X: np.ndarray, Y: np.ndarray, weights=None, *, nlv: int, tol: float = float(np.sqrt(np.finfo(float).eps)),
+             maxit: int = 200, scal: bool = False) -> Plsr:
+    """`plswold!` — src/plswold.jl:36-111 (Wold's NIPALS with the inner power iteration; X, Y carry the row metric
+    sqrt(w) (:57-58) and are deflated in place).  The reference starts every LV from `wx .= rand(p)` (:78): that random
+    vector is only ever used as the `w0` of the FIRST convergence check, which therefore never passes (dif ~ p/3);
+    here the first check is skipped outright, which is the same thing without the generator.  `niter` as :93."""
+    assert X.dtype == np.float64 and Y.dtype == np.float64 and X.ndim == 2 and Y.ndim == 2
+    if weights is None:
+        weights = np.ones(X.shape[0])
+    n, p, q, nlv, weights, xmeans, ymeans, xscales, yscales = _preamble(X, Y, weights, nlv, scal)
+    sqrtw = np.sqrt(weights)
+    X *= sqrtw[:, None]                                     # :57
+    Y *= sqrtw[:, None]                                     # :58
+    Tx = np.empty((n, nlv)); Wx = np.empty((p, nlv)); Px = np.empty((p, nlv))
+    Wyt = np.empty((q, nlv)); TTx = np.empty(nlv); niter = np.zeros(nlv)
+    for a in range(nlv):                                    # :73-106
+        ty = Y[:, 0].copy()                                 # :75
+        it = 1
+        wx = None
+        while True:                                         # :79-92
+            w0 = wx
+            wx = X.T @ ty / np.dot(ty, ty)                  # :81
+            wx = wx / np.linalg.norm(wx)                    # :82
+            tx = X @ wx                                     # :83
+            wytild = Y.T @ tx / np.dot(tx, tx)              # :84
+            wy = wytild / np.linalg.norm(wytild)            # :85
+            ty = Y @ wy                                     # :86
+            dif = np.inf if w0 is None else float(np.sum((wx - w0) ** 2))   # :87
+            it += 1
+            if dif < tol or it > maxit:                     # :89-91
+                break
+        niter[a] = it - 1                                   # :93
+        ttx = np.dot(tx, tx)
+        px = (X.T @ tx) / ttx                               # :95-96
+        X -= np.outer(tx, px)                               # :98
+        Y -= np.outer(tx, wytild)                           # :99
+        Tx[:, a] = tx; Wx[:, a] = wx; Px[:, a] = px; Wyt[:, a] = wytild; TTx[a] = ttx
+    Tx = Tx / sqrtw[:, None]                                # :107
+    Rx = Wx @ np.linalg.inv(Px.T @ Wx)                      # :108
+    return Plsr(Tx, Px, Rx, Wx, Wyt, TTx, xmeans, xscales, ymeans, yscales, weights, niter)
+
+
+def plswold(X, Y, weights=None, *, nlv: int, tol: float = float(np.sqrt(np.finfo(float).eps)), maxit: int = 200,
+            scal: bool = False) -> Plsr:
+    """`plswold` — src/plswold.jl:30-34."""
+    Xc = np.array(ensure_mat(X), dtype=np.float64, copy=True)
+    Yc = np.array(ensure_mat(Y), dtype=np.float64, copy=True)
+    return plswold_(Xc, Yc, weights, nlv=nlv, tol=tol, maxit=maxit, scal=scal)
+
+
+# --------------------------------------------------------------------------
 # Accessors  (src/plskern.jl:187-260)
 # --------------------------------------------------------------------------
 def transform(fm: Plsr, X, *, nlv: Optional[int] = None) -> np.ndarray:

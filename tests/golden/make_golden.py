@@ -31,6 +31,7 @@ CASES = {
     "wide_q": dict(n=300, p=70, q=10, nlv=12, scal=False, weighted=True, m=7),         # q = 10 as in cfg2
 }
 SEED_X, SEED_Y, SEED_T, SEED_W = 20250112, 20250113, 20250114, 20250116
+SIB_NLV = 8   # LVs of the sibling-algorithm fixtures (the late LVs of `ragged` are rank-exhausted noise)
 
 
 def inputs(c):
@@ -64,6 +65,19 @@ def main():
         out["nipals_Xinplace_fro"] = np.array([np.linalg.norm(Xn)])
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, {k: v.shape for k, v in list(out.items())[:4]}, "...")
+        # sibling algorithms, separate file so the fixtures above stay byte-identical
+        sib = {}
+        ks = min(c["nlv"], SIB_NLV)
+        for alg, fn in (("simp", O.plssimp), ("rosa", O.plsrosa), ("wold", O.plswold)):
+            fm = fn(X, Y, w, nlv=ks, scal=c["scal"])
+            for f in ("T", "P", "R", "W", "C", "TT"):
+                sib[f"{alg}_{f}"] = getattr(fm, f)
+            if fm.niter is not None:
+                sib[f"{alg}_niter"] = fm.niter
+        Xr_, Yr_ = X.copy(), Y.copy(); O.plsrosa_(Xr_, Yr_, w, nlv=ks, scal=c["scal"])
+        Xw_, Yw_ = X.copy(), Y.copy(); O.plswold_(Xw_, Yw_, w, nlv=ks, scal=c["scal"])
+        sib["rosa_Yinplace"] = Yr_; sib["wold_Yinplace"] = Yw_; sib["wold_Xinplace_fro"] = np.array([np.linalg.norm(Xw_)])
+        np.savez_compressed(os.path.join(HERE, name + "_siblings.npz"), **sib)
 
 
 if __name__ == "__main__":

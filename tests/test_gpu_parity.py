@@ -460,3 +460,124 @@ def test_plsrda(J, ctx):
         assert np.array_equal(rp[a], gp[a])
     one_pred, one_post = J.predict(fm, Xq, ctx=ctx)
     assert one_pred.shape == (50, 1) and np.array_equal(one_pred, O.plsrda_predict(ref, Xq)[0])
+
+
+# ------------------------------------------------------------------ sibling algorithms
+def _sib_cmp(ref, fm, tol=TIGHT):
+    s = O.sign_align(ref.R, fm.R)
+    for f in FIELDS:
+        e = O.rel_fro(getattr(ref, f), np.asarray(getattr(fm, f)) * s)
+        assert e < tol, (f, e)
+    for f in ("TT", "xmeans", "xscales", "ymeans", "yscales", "weights"):
+        assert O.rel_fro(getattr(ref, f), getattr(fm, f)) < tol, f
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg1_scal_w", "q1", "ragged", "wide_q"])
+@pytest.mark.parametrize("alg", ["simp", "rosa", "wold"])
+def test_sibling_golden(name, alg, golden_cases, J, ctx):
+    """plssimp / plsrosa / plswold through the C ABI vs the committed fixtures (oracle restatements of
+    src/plssimp.jl:28-88, src/plsrosa.jl:32-96, src/plswold.jl:36-111)."""
+    g = load_golden(name + "_siblings")
+    c = golden_cases.CASES[name]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    ks = min(c["nlv"], golden_cases.SIB_NLV)
+    X0, Y0 = X.copy(), Y.copy()
+    fm = getattr(J, "pls" + alg)(X, Y, w, nlv=ks, scal=c["scal"], ctx=ctx)
+    assert np.array_equal(X, X0) and np.array_equal(Y, Y0)
+    s = O.sign_align(g[f"{alg}_R"], fm.R)
+    for f in FIELDS:
+        assert O.rel_fro(g[f"{alg}_{f}"], getattr(fm, f) * s) < TIGHT, f
+    assert O.rel_fro(g[f"{alg}_TT"], fm.TT) < TIGHT
+    if alg == "wold":
+        assert np.array_equal(g["wold_niter"], fm.niter)       # same number of inner passes, LV by LV
+        assert np.all(s == 1.0)                                # the power iteration fixes the sign: no alignment needed
+    else:
+        assert fm.niter is None
+    if alg == "simp":
+        assert np.array_equal(fm.W, fm.R)                      # src/plssimp.jl:85-87
+    # `!` variants
+    Xi, Yi = np.asfortranarray(X.copy()), np.asfortranarray(Y.copy())
+    getattr(J, "pls" + alg + "_")(Xi, Yi, w, nlv=ks, scal=c["scal"], ctx=ctx)
+    if alg == "simp":
+        ref = O.plskern(X, Y, w, nlv=1, scal=c["scal"])
+        assert O.rel_fro((X - ref.xmeans) / ref.xscales, Xi) < TIGHT and O.rel_fro((Y - ref.ymeans) / ref.yscales, Yi) < TIGHT
+    elif alg == "rosa":
+        ref = O.plskern(X, Y, w, nlv=1, scal=c["scal"])
+        assert O.rel_fro((X - ref.xmeans) / ref.xscales, Xi) < TIGHT
+        assert O.rel_fro(g["rosa_Yinplace"], Yi) < 1e-8
+    else:
+        assert O.rel_fro(g["wold_Yinplace"], Yi) < 1e-8
+        assert abs(np.linalg.norm(Xi) - g["wold_Xinplace_fro"][0]) < 1e-8 * g["wold_Xinplace_fro"][0]
+
+
+@pytest.mark.parametrize("shape", [(6000, 500, 10, 12), (4099, 129, 3, 9), (3000, 1000, 1, 8), (2500, 2047, 2, 5), (5000, 300, 16, 6)])
+@pytest.mark.parametrize("alg", ["simp", "rosa", "wold"])
+def test_sibling_seeded_shapes(shape, alg, J, ctx):
+    """Seeded structured data (latent sources + noise) so that every LV is well defined; weighted, scaled."""
+    n, p, q, nlv = shape
+    rng = np.random.default_rng(n + p)
+    L = rng.standard_normal((n, 2 * nlv))
+    X = np.asfortranarray(L @ rng.standard_normal((2 * nlv, p)) + 0.5 * rng.standard_normal((n, p)))
+    ky = min(max(q, 4), 2 * nlv)
+    Y = np.asfortranarray(L[:, :ky] @ rng.standard_normal((ky, q)) + 0.3 * rng.standard_normal((n, q)))
+    w = rng.uniform(0.5, 1.5, n)
+    scal = (n % 2 == 1)
+    ref = getattr(O, "pls" + alg)(X, Y, w, nlv=nlv, scal=scal)
+    fm = getattr(J, "pls" + alg)(X, Y, w, nlv=nlv, scal=scal, ctx=ctx)
+    _sib_cmp(ref, fm, tol=1e-8)
+    if alg == "wold":
+        assert np.array_equal(ref.niter, fm.niter)
+    # device-resident inputs give the same bits as host inputs
+    import torch
+    Xd = J.colmajor_empty(n, p); Xd.copy_(torch.from_numpy(X))
+    Yd = J.colmajor_empty(n, q); Yd.copy_(torch.from_numpy(Y))
+    fd = getattr(J, "pls" + alg)(Xd, Yd, torch.from_numpy(w).cuda(), nlv=nlv, scal=scal, ctx=ctx)
+    assert np.array_equal(fd.P, fm.P) and np.array_equal(fd.T.cpu().numpy(), fm.T)
+
+
+def test_sibling_limits_and_wold_options(J, ctx):
+    rng = np.random.default_rng(3)
+    X = np.asfortranarray(rng.standard_normal((400, 30))); Y = np.asfortranarray(rng.standard_normal((400, 20)))
+    for fn in (J.plssimp, J.plswold):                       # q > 16: outside the LDS-resident envelope -> loud error
+        with pytest.raises(J.JchError):
+            fn(X, Y, nlv=3, ctx=ctx)
+    fr = J.plsrosa(X, Y, nlv=3, ctx=ctx)                    # plsrosa is plskern-shaped: any q <= 64
+    _sib_cmp(O.plsrosa(X, Y, nlv=3), fr, tol=1e-8)
+    Y4 = np.asfortranarray(Y[:, :4])
+    for maxit in (1, 2, 5):
+        ref = O.plswold(X, Y4, nlv=3, maxit=maxit)
+        fm = J.plswold(X, Y4, nlv=3, maxit=maxit, ctx=ctx)
+        assert np.array_equal(ref.niter, fm.niter) and np.all(fm.niter <= maxit)
+        _sib_cmp(ref, fm, tol=1e-8)
+    ref = O.plswold(X, Y4, nlv=3, tol=1e-3)
+    fm = J.plswold(X, Y4, nlv=3, tol=1e-3, ctx=ctx)
+    assert np.array_equal(ref.niter, fm.niter)
+    _sib_cmp(ref, fm, tol=1e-8)
+
+
+def test_named_transform_predict_entry_points(golden_cases, J, ctx):
+    """jch_transform / jch_predict (the §8b export list) called directly through ctypes."""
+    import ctypes as C
+    c = golden_cases.CASES["wide_q"]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    ref = O.plskern(X, Y, w, nlv=c["nlv"])
+    fm = J.plskern(X, Y, w, nlv=c["nlv"], ctx=ctx)
+    s = O.sign_align(ref.W, fm.W)
+    L = J.load()
+    m, p = Xt.shape
+    q, k = c["q"], fm.P.shape[1]
+    Xf = np.asfortranarray(Xt)
+    T = np.empty((m, 5), order="F")
+    ctx.check(L.jch_transform(ctx._h, 0, Xf.ctypes.data, m, p, m, fm.xmeans.ctypes.data, fm.xscales.ctypes.data,
+                              np.asfortranarray(fm.R).ctypes.data, 5, T.ctypes.data, m))
+    assert O.rel_fro(O.transform(ref, Xt, nlv=5), T * s[:5]) < TIGHT
+    lo, hi = 2, k
+    pred = np.empty((m, q * (hi - lo + 1)), order="F")
+    R, Cm = np.asfortranarray(fm.R), np.asfortranarray(fm.C)
+    ctx.check(L.jch_predict(ctx._h, 0, Xf.ctypes.data, m, p, m, fm.xmeans.ctypes.data, fm.xscales.ctypes.data,
+                            fm.ymeans.ctypes.data, fm.yscales.ctypes.data, R.ctypes.data, Cm.ctypes.data, q, lo, hi,
+                            pred.ctypes.data, m))
+    want = np.concatenate(O.predict(ref, Xt, nlv=range(lo, hi + 1)), axis=1)
+    assert O.rel_fro(want, pred) < TIGHT
+    assert L.jch_predict(ctx._h, 0, Xf.ctypes.data, m, p, m, None, None, None, None, R.ctypes.data, Cm.ctypes.data, q, 3, 2,
+                         pred.ctypes.data, m) == -1

@@ -201,3 +201,39 @@ def test_scores_and_grid_oracle():
     s = segm[0][1]
     _, one = O.gridscorelv(O.rmrow(X, s), O.rmrow(Y, s), X[s], Y[s], score=O.msep, fun=O.plskern, nlv=range(0, 6))
     assert np.allclose(rep[0, 1], one)
+
+
+# ------------------------------------------------------------------ sibling algorithms
+@pytest.mark.parametrize("name", ["cfg1", "cfg1_scal_w", "q1", "ragged", "wide_q"])
+def test_sibling_oracles(name, golden_cases):
+    """plsrosa == plskern and a fully converged plswold == plsnipals (all four are the same PLS2 up to rounding /
+    inner convergence); plssimp: invariants, and the PLS1 identity for q == 1.  Fixtures pin the committed values."""
+    c = golden_cases.CASES[name]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    ks = min(c["nlv"], golden_cases.SIB_NLV)
+    fk = O.plskern(X, Y, w, nlv=ks, scal=c["scal"])
+    fr = O.plsrosa(X, Y, w, nlv=ks, scal=c["scal"])
+    fs = O.plssimp(X, Y, w, nlv=ks, scal=c["scal"])
+    fw = O.plswold(X, Y, w, nlv=ks, scal=c["scal"])
+    g = load_golden(name + "_siblings")
+    for alg, fm in (("simp", fs), ("rosa", fr), ("wold", fw)):
+        for f in ("T", "P", "R", "W", "C", "TT"):
+            assert O.rel_fro(g[f"{alg}_{f}"], getattr(fm, f)) < 1e-9, (alg, f)
+    assert np.array_equal(g["wold_niter"], fw.niter)
+    assert _aligned_err(fk, fr) < 1e-9
+    if name != "ragged":      # (its first LV needs > 20000 passes: two nearly equal singular values)
+        fwc = O.plswold(X, Y, w, nlv=ks, scal=c["scal"], tol=1e-30, maxit=20000)
+        assert _aligned_err(O.plsnipals(X, Y, w, nlv=ks, scal=c["scal"]), fwc) < 1e-6
+    # SIMPLS invariants: D-orthogonal scores, T = Xs R, unit r, P'R = I, W == R
+    D = np.diag(fs.weights)
+    Xs = (X - fs.xmeans) / fs.xscales
+    assert np.abs(fs.T.T @ D @ fs.T - np.diag(fs.TT)).max() < 1e-11 * fs.TT.max()
+    assert O.rel_fro(fs.T, Xs @ fs.R) < 1e-12
+    assert np.abs(np.linalg.norm(fs.R, axis=0) - 1).max() < 1e-12
+    assert np.array_equal(fs.W, fs.R)
+    if c["q"] == 1:           # PLS1: SIMPLS and the kernel algorithm give the same regression
+        for a in range(ks + 1):
+            assert O.rel_fro(O.coef(fk, nlv=a)[0], O.coef(fs, nlv=a)[0]) < 1e-8 or a == 0
+    assert fw.niter.min() >= 1 and fw.niter.max() <= 200
+    # maxit caps the inner loop (src/plswold.jl:89)
+    assert np.all(O.plswold(X, Y, w, nlv=2, scal=c["scal"], maxit=3).niter <= 3)
