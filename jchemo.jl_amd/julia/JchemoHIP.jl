@@ -14,8 +14,9 @@ behaviour below is exercised through the identical C entry points by the ctypes 
 module JchemoHIP
 
 using LinearAlgebra
+using Libdl
 
-export Plsr, Lwplsr, plskern, plskern!, plsnipals, plsnipals!, lwplsr, transform, coef, predict, summary_plsr, JchCtx
+export Plsr, Lwplsr, plskern, plskern!, plsnipals, plsnipals!, plssimp, plssimp!, plsrosa, plsrosa!, plswold, plswold!, lwplsr, transform, coef, predict, summary_plsr, JchCtx
 
 const LIB = get(ENV, "JCHEMO_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libjchemo_hip.so"))
 
@@ -75,36 +76,40 @@ _loc(A) = Int32(1)                                      # any other strided colu
 _similar(A::Array, dims...) = Array{Float64}(undef, dims...)
 _similar(A, dims...) = similar(A, Float64, dims...)
 
-function _fit(sym::Symbol, X, Y, weights, nlv, scal, inplace, ctx::JchCtx)
+const _FIT_SIG = (Ptr{Cvoid}, Ref{PlsDesc}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64},
+                  Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                  Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32})
+_entry(name::Symbol) = Libdl.dlsym(Libdl.dlopen(LIB), name)     # jch_plskern_fit and its same-signature siblings
+
+# sym: :plskern | :plsnipals | :plssimp | :plsrosa (one C signature) or :plswold (tol, maxit, niter in addition)
+function _fit(sym::Symbol, X, Y, weights, nlv, scal, inplace, ctx::JchCtx; tol = sqrt(eps(1.)), maxit = 200)
     n, p = size(X); q = size(Y, 2)
     size(Y, 1) == n || throw(DimensionMismatch("X has $n rows, Y has $(size(Y, 1))"))
     kmax = max(1, min(p, nlv))
     T = _similar(X, n, kmax); wn = _similar(X, n)
     P = zeros(p, kmax); R = zeros(p, kmax); W = zeros(p, kmax); C = zeros(q, kmax); TT = zeros(kmax)
-    xm = zeros(p); xs = zeros(p); ym = zeros(q); ys = zeros(q)
+    xm = zeros(p); xs = zeros(p); ym = zeros(q); ys = zeros(q); niter = zeros(kmax)
     desc = Ref(PlsDesc(n, p, q, nlv, scal ? 1 : 0, 0, _loc(X), inplace ? 1 : 0, 0))
     got = Ref{Int32}(0)
     w = weights === nothing ? C_NULL : pointer(weights)
     GC.@preserve X Y weights T wn begin
-        st = if sym === :plskern
-            ccall((:jch_plskern_fit, LIB), Int32,
-                  (Ptr{Cvoid}, Ref{PlsDesc}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64},
+        st = if sym === :plswold
+            ccall((:jch_plswold_fit, LIB), Int32,
+                  (Ptr{Cvoid}, Ref{PlsDesc}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Int32, Ptr{Float64},
                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
-                  ctx.h, desc, pointer(X), stride(X, 2), pointer(Y), max(stride(Y, 2), n), w, pointer(T),
-                  P, R, W, C, TT, xm, xs, ym, ys, pointer(wn), got)
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+                  ctx.h, desc, pointer(X), stride(X, 2), pointer(Y), max(stride(Y, 2), n), w, tol, maxit, pointer(T),
+                  P, R, W, C, TT, xm, xs, ym, ys, pointer(wn), niter, got)
         else
-            ccall((:jch_plsnipals_fit, LIB), Int32,
-                  (Ptr{Cvoid}, Ref{PlsDesc}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64},
-                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+            ccall(_entry(Symbol(:jch_, sym, :_fit)), Int32, _FIT_SIG,
                   ctx.h, desc, pointer(X), stride(X, 2), pointer(Y), max(stride(Y, 2), n), w, pointer(T),
                   P, R, W, C, TT, xm, xs, ym, ys, pointer(wn), got)
         end
         check(ctx, st)
     end
     k = Int(got[])
-    Plsr(T[:, 1:k], P[:, 1:k], R[:, 1:k], W[:, 1:k], C[:, 1:k], TT[1:k], xm, xs, ym, ys, wn, nothing)
+    Plsr(T[:, 1:k], P[:, 1:k], R[:, 1:k], W[:, 1:k], C[:, 1:k], TT[1:k], xm, xs, ym, ys, wn,
+         sym === :plswold ? niter[1:k] : nothing)
 end
 
 _w(weights, X) = weights === nothing ? nothing : convert(typeof(_similar(X, 0)), vec(Float64.(weights)))
@@ -121,6 +126,26 @@ plsnipals(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
 "`plsnipals!` — src/plsnipals.jl:37-97: X, Y end up centred/scaled and deflated."
 plsnipals!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plsnipals, X, Y, _w(weights, X), nlv, scal, true, ctx)
+
+# Sibling algorithms (same row kernels, different small state; include/jchemo_hip.h)
+"`plssimp` — src/plssimp.jl:22-26 (`W` is returned equal to `R`, :85-87)."
+plssimp(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plssimp, ensure_mat(X), ensure_mat(Y), _w(weights, ensure_mat(X)), nlv, scal, false, ctx)
+"`plssimp!` — src/plssimp.jl:28-88."
+plssimp!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plssimp, X, Y, _w(weights, X), nlv, scal, true, ctx)
+"`plsrosa` — src/plsrosa.jl:26-30."
+plsrosa(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plsrosa, ensure_mat(X), ensure_mat(Y), _w(weights, ensure_mat(X)), nlv, scal, false, ctx)
+"`plsrosa!` — src/plsrosa.jl:32-96: X centred/scaled, Y centred/scaled and deflated."
+plsrosa!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
+    _fit(:plsrosa, X, Y, _w(weights, X), nlv, scal, true, ctx)
+"`plswold` — src/plswold.jl:30-34; `niter` filled as :93."
+plswold(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
+    _fit(:plswold, ensure_mat(X), ensure_mat(Y), _w(weights, ensure_mat(X)), nlv, scal, false, ctx; tol = tol, maxit = maxit)
+"`plswold!` — src/plswold.jl:36-111."
+plswold!(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
+    _fit(:plswold, X, Y, _w(weights, X), nlv, scal, true, ctx; tol = tol, maxit = maxit)
 
 function _affine(X, shift, scale, B::Matrix{Float64}, bias, ctx)
     X = ensure_mat(X); m, p = size(X); k = size(B, 2)
