@@ -72,6 +72,14 @@ JCH_API int32_t jch_comm_unique_id(void *uid128);
 JCH_API int32_t jch_ctx_comm_init(jch_ctx *ctx, const void *uid128, int32_t rank, int32_t nranks);
 JCH_API int32_t jch_ctx_comm_info(const jch_ctx *ctx, int32_t *rank, int32_t *nranks);
 
+/* Loopback communicator — TEST HARNESS for the row-sharded path on a one-GPU box (RCCL refuses two ranks on one device):
+ * the "ranks" are host threads of ONE process, each with its own ctx on the same GPU; all-reduces are staged through
+ * host memory in rank order (bit-identical sums on every rank, like the RCCL path).  Every rank thread must make the
+ * same sequence of library calls.  Not a production transport. */
+JCH_API int32_t jch_loopback_group_create(int32_t nranks, void **group_out);
+JCH_API int32_t jch_loopback_group_destroy(void *group);
+JCH_API int32_t jch_ctx_comm_init_loopback(jch_ctx *ctx, void *group, int32_t rank);
+
 typedef struct jch_pls_desc {
     int64_t n;       /* rows held by THIS rank (all rows when single-GPU) */
     int64_t p;       /* columns of X */

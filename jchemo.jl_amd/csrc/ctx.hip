@@ -1,5 +1,6 @@
 // Context, error plumbing, workspace, RCCL binding, profiling events.  Public ABI: include/jchemo_hip.h.
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -167,8 +168,77 @@ extern "C" int32_t jch_ctx_comm_info(const jch_ctx *ctx, int32_t *rank, int32_t 
     return JCH_OK;
 }
 
+// ---- loopback communicator (tests): the ranks are host THREADS of one process, each with its own ctx (and stream) on
+// the same GPU.  It exists so that the row-sharded code path of the library (global weight sum, all-reduced moments,
+// XtY, per-LV [zp, tt]) can be executed and checked on a one-GPU box, where RCCL refuses two ranks on one device.
+// The all-reduce is staged through host memory in rank order, so every rank ends with bit-identical sums — the same
+// property the RCCL path has.
+struct jch_loop_group {
+    int nranks = 0;
+    pthread_barrier_t bar;
+    std::vector<double> stage;
+};
+
+extern "C" int32_t jch_loopback_group_create(int32_t nranks, void **out)
+{
+    if (!out || nranks < 1 || nranks > 64) return jch_fail(nullptr, JCH_EINVAL, "jch_loopback_group_create: bad arguments");
+    jch_loop_group *g = new (std::nothrow) jch_loop_group();
+    if (!g) return jch_fail(nullptr, JCH_ENOMEM, "jch_loopback_group_create: host allocation failed");
+    g->nranks = nranks;
+    if (pthread_barrier_init(&g->bar, nullptr, (unsigned)nranks) != 0) {
+        delete g;
+        return jch_fail(nullptr, JCH_EINVAL, "pthread_barrier_init failed");
+    }
+    *out = g;
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_loopback_group_destroy(void *grp)
+{
+    jch_loop_group *g = (jch_loop_group *)grp;
+    if (!g) return JCH_OK;
+    pthread_barrier_destroy(&g->bar);
+    delete g;
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_ctx_comm_init_loopback(jch_ctx *ctx, void *grp, int32_t rank)
+{
+    if (!ctx) return JCH_EINVAL;
+    jch_loop_group *g = (jch_loop_group *)grp;
+    if (!g || rank < 0 || rank >= g->nranks) return jch_fail(ctx, JCH_EINVAL, "jch_ctx_comm_init_loopback: bad group / rank");
+    if (ctx->comm || ctx->loop) return jch_fail(ctx, JCH_EINVAL, "jch_ctx_comm_init_loopback: ctx already has a communicator");
+    ctx->loop = g;
+    ctx->rank = rank;
+    ctx->nranks = g->nranks;
+    return JCH_OK;
+}
+
+static int32_t loopback_allreduce(jch_ctx *ctx, double *dev_buf, size_t count)
+{
+    jch_loop_group *g = (jch_loop_group *)ctx->loop;
+    const size_t need = count * (size_t)g->nranks;
+    pthread_barrier_wait(&g->bar);                       // everybody is done with the previous round's stage
+    if (ctx->rank == 0 && g->stage.size() < need) g->stage.resize(need);
+    pthread_barrier_wait(&g->bar);
+    hipError_t e = hipMemcpyAsync(g->stage.data() + (size_t)ctx->rank * count, dev_buf, sizeof(double) * count,
+                                  hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    pthread_barrier_wait(&g->bar);                       // (always reached, also on error: no rank may be left waiting)
+    if (e != hipSuccess) return jch_fail(ctx, JCH_EHIP, "loopback all-reduce: %s", hipGetErrorString(e));
+    ctx->loop_sum.assign(count, 0.0);
+    for (int r = 0; r < g->nranks; ++r) {
+        const double *src = g->stage.data() + (size_t)r * count;
+        for (size_t i = 0; i < count; ++i) ctx->loop_sum[i] += src[i];
+    }
+    JCH_HIP(ctx, hipMemcpyAsync(dev_buf, ctx->loop_sum.data(), sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JCH_OK;
+}
+
 int32_t jch_allreduce_f64(jch_ctx *ctx, double *dev_buf, size_t count)
 {
+    if (ctx->loop && count > 0) return loopback_allreduce(ctx, dev_buf, count);
     if (!ctx->comm || count == 0) return JCH_OK;  // single rank: the local sum is the global sum
     int r = g_rccl.AllReduce(dev_buf, dev_buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
     if (r != 0) return jch_fail(ctx, JCH_ERCCL, "ncclAllReduce(%zu f64): %s", count, g_rccl.GetErrorString(r));

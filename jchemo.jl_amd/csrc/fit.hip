@@ -216,11 +216,13 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (kern_like) {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
+            if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;   // rank-independent message size (a small shard may use 1 slice; the rest hold zeros)
             JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1));  // ONE collective per LV: [zp (p), tt]
             if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
             else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
         } else {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
+            if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;
             JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1 + qpad));  // [zp_raw, tt, c_raw]
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast));
             const bool last = a + 1 == nlv;

@@ -40,6 +40,8 @@ struct jch_ctx {
     // communicator
     void *comm = nullptr;
     int rank = 0, nranks = 1;
+    void *loop = nullptr;            // loopback group (tests; ctx.hip)
+    std::vector<double> loop_sum;
     // workspace (grow-only)
     jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq;
     // profiling

@@ -25,7 +25,7 @@ SYMBOLS = (
     "jch_ctx_comm_init", "jch_ctx_comm_info", "jch_plskern_fit", "jch_plsnipals_fit", "jch_affine_gemm",
     "jch_weighted_ss", "jch_fill_uniform", "jch_ctx_set_profiling", "jch_ctx_get_profile", "jch_lwplsr_predict",
     "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
-    "jch_predict",
+    "jch_predict", "jch_loopback_group_create", "jch_loopback_group_destroy", "jch_ctx_comm_init_loopback",
 )
 
 
@@ -66,6 +66,9 @@ def load():
     L.jch_comm_unique_id.argtypes = [vp]
     L.jch_ctx_comm_init.argtypes = [vp, vp, i32, i32]
     L.jch_ctx_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.jch_loopback_group_create.argtypes = [i32, C.POINTER(vp)]
+    L.jch_loopback_group_destroy.argtypes = [vp]
+    L.jch_ctx_comm_init_loopback.argtypes = [vp, vp, i32]
     fit = [vp, C.POINTER(PlsDesc), dp, i64, dp, i64, dp] + [dp] * 11 + [C.POINTER(i32)]
     L.jch_plskern_fit.argtypes = fit
     L.jch_plsnipals_fit.argtypes = fit
@@ -127,6 +130,11 @@ class Context:
     def comm_init(self, uid: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(uid, 128)
         self.check(load().jch_ctx_comm_init(self._h, buf, rank, nranks))
+        self.rank, self.nranks = rank, nranks
+
+    def comm_init_loopback(self, group, rank: int, nranks: int):
+        """Test harness: ranks = threads of this process on one GPU (include/jchemo_hip.h, loopback communicator)."""
+        self.check(load().jch_ctx_comm_init_loopback(self._h, group, rank))
         self.rank, self.nranks = rank, nranks
 
     def set_profiling(self, on: bool):

@@ -581,3 +581,73 @@ def test_named_transform_predict_entry_points(golden_cases, J, ctx):
     assert O.rel_fro(want, pred) < TIGHT
     assert L.jch_predict(ctx._h, 0, Xf.ctypes.data, m, p, m, None, None, None, None, R.ctypes.data, Cm.ctypes.data, q, 3, 2,
                          pred.ctypes.data, m) == -1
+
+
+# ------------------------------------------------------------------ row-sharded path on ONE GPU (loopback communicator)
+def _run_sharded(J, fn_name, shards, nlv, scal, **kw):
+    """One thread per rank, each with its own ctx (private stream) joined to a loopback group (include/jchemo_hip.h):
+    executes exactly the library code of a multi-GPU fit — global weight sum and row count, all-reduced moments and
+    XtY, one all-reduce per LV — with the transport replaced by a host-staged sum."""
+    import ctypes as C
+    import threading
+    nr = len(shards)
+    L = J.load()
+    grp = C.c_void_p()
+    assert L.jch_loopback_group_create(nr, C.byref(grp)) == 0
+    ctxs = [J.Context(0) for _ in range(nr)]
+    out, err = [None] * nr, [None] * nr
+
+    def work(r):
+        try:
+            ctxs[r].comm_init_loopback(grp, r, nr)
+            Xs, Ys, ws = shards[r]
+            out[r] = getattr(J, fn_name)(Xs, Ys, ws, nlv=nlv, scal=scal, ctx=ctxs[r], **kw)
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(nr)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank thread is stuck in a collective"
+    assert err == [None] * nr, err
+    for c in ctxs:
+        c.close()
+    L.jch_loopback_group_destroy(grp)
+    return out
+
+
+@pytest.mark.parametrize("alg", ["plskern", "plsnipals", "plssimp", "plsrosa", "plswold", "plskern_v2"])
+@pytest.mark.parametrize("cuts", [(0.5,), (0.3, 0.7), (0.002, 0.4, 0.75)])
+def test_row_sharded_fit_matches_unsharded(alg, cuts, J):
+    """rows sharded over 2-4 ranks (uneven shards, one of them smaller than nlv) must give the unsharded
+    result; every replicated output must be bit-identical on all ranks."""
+    n, p, q, nlv = 6000, 140, 4, 7
+    rng = np.random.default_rng(11)
+    Lt = rng.standard_normal((n, 2 * nlv))
+    X = Lt @ rng.standard_normal((2 * nlv, p)) + 0.5 * rng.standard_normal((n, p))
+    Y = Lt[:, :q] @ rng.standard_normal((q, q)) + 0.3 * rng.standard_normal((n, q))
+    w = rng.uniform(0.5, 1.5, n)
+    edges = [0] + [int(c * n) for c in cuts] + [n]
+    shards = [(np.asfortranarray(X[a:b]), np.asfortranarray(Y[a:b]), w[a:b].copy()) for a, b in zip(edges[:-1], edges[1:])]
+    assert min(b - a for a, b in zip(edges[:-1], edges[1:])) >= 1
+    scal = len(cuts) == 2
+    kw = {"variant": 1} if alg == "plskern_v2" else {}
+    name = "plskern" if alg == "plskern_v2" else alg
+    ref = getattr(O, name)(X, Y, w, nlv=nlv, scal=scal)
+    fms = _run_sharded(J, name, shards, nlv, scal, **kw)
+    for f in ("P", "R", "W", "C", "TT", "xmeans", "xscales", "ymeans", "yscales"):
+        for fm in fms[1:]:
+            assert np.array_equal(getattr(fms[0], f), getattr(fm, f)), f      # replicated state: bit-identical
+    T = np.concatenate([fm.T for fm in fms], axis=0)
+    wn = np.concatenate([fm.weights for fm in fms])
+    s = O.sign_align(ref.R, fms[0].R)
+    tol = 1e-8
+    assert O.rel_fro(ref.T, T * s) < tol and O.rel_fro(ref.weights, wn) < tol
+    for f in ("P", "R", "W", "C"):
+        assert O.rel_fro(getattr(ref, f), getattr(fms[0], f) * s) < tol, f
+    for f in ("TT", "xmeans", "xscales", "ymeans", "yscales"):
+        assert O.rel_fro(getattr(ref, f), getattr(fms[0], f)) < tol, f
+    if alg == "plswold":
+        assert np.array_equal(ref.niter, fms[0].niter)
