@@ -646,34 +646,72 @@ def _nlv_range(nlv, p):
     return list(range(max(0, int(vals.min())), min(p, int(vals.max())) + 1))
 
 
-def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, ctx: Optional[Context] = None, **kwargs):
-    """`gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv)` — src/gridscore.jl:167-221 (pars = nothing): one fit at
-    max(nlv), predictions for the whole range in ONE pass over X, scores from device-side sums.
-    Returns dict(nlv=[...], res=(le_nlv, q))."""
+def mpar(**kwargs):
+    """`mpar(; kwargs...)` — src/mpar.jl:15-24: every combination of the parameter values (first keyword fastest,
+    `Base.product` order) as {name: list of ncomb values}."""
+    import itertools
+    names = list(kwargs)
+    vals = [list(v) if isinstance(v, (list, tuple, np.ndarray, range)) else [v] for v in kwargs.values()]
+    out = {nm: [] for nm in names}
+    for c in itertools.product(*reversed(vals)):
+        for nm, x in zip(names, reversed(c)):
+            out[nm].append(x)
+    return out
+
+
+def _pars_rows(pars):
+    """Element-wise combinations of the `pars` vectors (src/gridscore.jl:192-195); one empty combination for None."""
+    if pars is None:
+        return [dict()]
+    names = list(pars)
+    if "nlv" in names:
+        raise ValueError("Argument `pars` must not contain `nlv` (src/gridscore.jl:163)")
+    ncomb = len(pars[names[0]])
+    return [{nm: pars[nm][i] for nm in names} for i in range(ncomb)]
+
+
+def _grid_table(pars, rng, res):
+    """Column layout of the reference's result DataFrame (src/gridscore.jl:204-216): combination-major rows."""
+    rows = _pars_rows(pars)
+    out = dict(nlv=list(rng) * len(rows), res=res)
     if pars is not None:
-        raise NotImplementedError("pars grids are not wired yet")
+        for nm in pars:
+            out[nm] = [r[nm] for r in rows for _ in rng]
+    return out
+
+
+def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, ctx: Optional[Context] = None, **kwargs):
+    """`gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars)` — src/gridscore.jl:167-221: per parameter combination
+    one fit at max(nlv), predictions for the whole range in ONE pass over X, scores from device-side sums.
+    Returns dict(nlv=[...], <one list per pars key>, res=(ncomb * le_nlv, q)), rows combination-major."""
     rng = _nlv_range(nlv, ensure_mat(Xtrain).shape[1])
-    fm = fun(Xtrain, Ytrain, nlv=max(rng), ctx=ctx, **kwargs)
     name = getattr(score, "_jch_name", None)
-    if name is None:   # arbitrary user score(pred, Y): evaluated on what predict returns
-        pred = predict(fm, X, nlv=rng, ctx=ctx)
-        pred = [pred] if len(rng) == 1 else pred
-        return dict(nlv=rng, res=np.vstack([np.asarray(score(pr, Y)).reshape(1, -1) for pr in pred]))
-    P = _pred_matrix(fm, X, rng, ctx)
-    return dict(nlv=rng, res=_score_from_sums(name, _score_sums(P, Y, None, ctx)))
+    blocks = []
+    for kw in _pars_rows(pars):
+        fm = fun(Xtrain, Ytrain, nlv=max(rng), ctx=ctx, **kwargs, **kw)
+        if name is None or not isinstance(fm, Plsr):   # arbitrary score(pred, Y) or a non-Plsr model: what predict returns
+            pred = predict(fm, X, nlv=rng, ctx=ctx)
+            if isinstance(pred, LwplsrPred):
+                pred = pred.pred
+            pred = [pred] if len(rng) == 1 else pred
+            blocks.append(np.vstack([np.asarray(score(pr, Y)).reshape(1, -1) for pr in pred]))
+        else:
+            blocks.append(_score_from_sums(name, _score_sums(_pred_matrix(fm, X, rng, ctx), Y, None, ctx)))
+    return _grid_table(pars, rng, np.vstack(blocks))
+
+
+_CV_FUNS = None
 
 
 def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] = None, **kwargs):
-    """`gridcvlv(X, Y; segm, score, fun, nlv)` — src/gridcv.jl:187-228 (pars = nothing).  The reference copies
-    rmrow(X, s) for every segment; here X stays where it is and each fold is ONE weighted fit with weight 0 on the
-    held-out rows (identical means / XtY / loadings), whose scores T on the held-out rows already are their
-    transformed rows: predictions for every nlv are T[:, :a] * C[:, :a]' — a GEMM on the n x nlv scores, no second
-    pass over X.  Returns dict(nlv, res (le, q) mean over folds, res_rep (nrep, nsegm, le, q))."""
-    if pars is not None:
-        raise NotImplementedError("pars grids are not wired yet")
+    """`gridcvlv(X, Y; segm, score, fun, nlv, pars)` — src/gridcv.jl:187-228.  The reference copies rmrow(X, s) for
+    every segment; here X stays where it is and each fold is ONE weighted fit with weight 0 on the held-out rows
+    (identical means / XtY / loadings), whose scores T on the held-out rows already are their transformed rows:
+    predictions for every nlv are T[:, :a] * C[:, :a]' — a GEMM on the n x nlv scores, no second pass over X.
+    Returns dict(nlv, <pars columns>, res (ncomb * le, q) mean over folds, res_rep (nrep, nsegm, ncomb * le, q))."""
     name = getattr(score, "_jch_name", None)
-    if name is None or fun not in (plskern, plsnipals):
-        raise NotImplementedError("gridcvlv: score must be one of msep/rmsep/ssr/bias/r2/cor2 and fun plskern/plsnipals")
+    if name is None or fun not in (plskern, plsnipals, plssimp, plsrosa, plswold):
+        raise NotImplementedError("gridcvlv: score must be one of msep/rmsep/ssr/bias/r2/cor2 and fun a PLS fit of this module")
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
         _addr_ld(X); _addr_ld(Y)
@@ -683,6 +721,7 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] =
     n, p = X.shape
     q = Y.shape[1]
     rng = _nlv_range(nlv, p)
+    combos = _pars_rows(pars)
     rep_out = []
     for listsegm in segm:
         zres = []
@@ -693,18 +732,23 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] =
             if dev:
                 held = torch.as_tensor(held, device=X.device); w = torch.as_tensor(w, device=X.device)
             kfit = min(max(rng), n - len(s))                                   # the reference clamps with the TRAINING rows
-            fm = fun(X, Y, w, nlv=kfit, ctx=ctx, **kwargs)
-            k = fm.P.shape[1]
-            # B_c[l, a*q + j] = C[j, l] * yscale_j for l < min(a, k); bias = ymeans
-            Bc = np.zeros((k, len(rng) * q))
-            for ai, a in enumerate(rng):
-                kk = min(a, k)
-                Bc[:kk, ai * q:(ai + 1) * q] = (fm.C[:, :kk] * fm.yscales[:, None]).T
-            Pm = _affine(fm.T, None, None, Bc, np.tile(fm.ymeans, len(rng)), ctx)
-            zres.append(_score_from_sums(name, _score_sums(Pm, Y, held, ctx)))
+            blocks = []
+            for kw in combos:
+                fm = fun(X, Y, w, nlv=kfit, ctx=ctx, **kwargs, **kw)
+                k = fm.P.shape[1]
+                # B_c[l, a*q + j] = C[j, l] * yscale_j for l < min(a, k); bias = ymeans
+                Bc = np.zeros((k, len(rng) * q))
+                for ai, a in enumerate(rng):
+                    kk = min(a, k)
+                    Bc[:kk, ai * q:(ai + 1) * q] = (fm.C[:, :kk] * fm.yscales[:, None]).T
+                Pm = _affine(fm.T, None, None, Bc, np.tile(fm.ymeans, len(rng)), ctx)
+                blocks.append(_score_from_sums(name, _score_sums(Pm, Y, held, ctx)))
+            zres.append(np.vstack(blocks))
         rep_out.append(np.stack(zres))
     res_rep = np.stack(rep_out)
-    return dict(nlv=rng, res=res_rep.mean(axis=(0, 1)), res_rep=res_rep)
+    out = _grid_table(pars, rng, res_rep.mean(axis=(0, 1)))
+    out["res_rep"] = res_rep
+    return out
 
 
 # ---------------------------------------------------------------------------------- PLSR-DA (§8f rank 4)

@@ -630,24 +630,51 @@ def rmrow(X, s):
     return np.asarray(X)[keep]
 
 
+def mpar(**kwargs):
+    """src/mpar.jl:15-24 — all combinations of the parameter values; `Base.product` order: the FIRST keyword varies
+    fastest.  Returns {name: list of ncomb values}."""
+    import itertools
+    names = list(kwargs)
+    vals = [list(v) if isinstance(v, (list, tuple, np.ndarray, range)) else [v] for v in kwargs.values()]
+    out = {nm: [] for nm in names}
+    for c in itertools.product(*reversed(vals)):          # last factor fastest == first keyword fastest
+        for nm, x in zip(names, reversed(c)):
+            out[nm].append(x)
+    return out
+
+
+def _pars_rows(pars):
+    if pars is None:
+        return [dict()]
+    names = list(pars)
+    ncomb = len(pars[names[0]])       # src/gridscore.jl:192 `length(pars[1])`
+    return [{nm: pars[nm][i] for nm in names} for i in range(ncomb)]
+
+
 def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None):
-    """src/gridscore.jl:167-221 with pars = nothing: fit once at max(nlv), predict for the whole (clamped) range,
-    score each.  Returns (nlv values, res (le_nlv, q))."""
-    assert pars is None
+    """src/gridscore.jl:167-221: per parameter combination (element-wise over the `pars` vectors, :192-195; one
+    implicit combination when pars = nothing) fit once at max(nlv), predict for the whole (clamped) range, score each.
+    Returns (nlv values, res (ncomb * le_nlv, q)) — rows ordered combination-major like :204-216."""
     Xtrain = ensure_mat(Xtrain); Ytrain = ensure_mat(Ytrain)
     p = Xtrain.shape[1]
     vals = np.atleast_1d(np.asarray(nlv))
     rng = list(range(max(0, int(vals.min())), min(p, int(vals.max())) + 1))
-    fm = fun(Xtrain, Ytrain, nlv=max(rng))
-    pred = predict(fm, X, nlv=rng)
-    pred = [pred] if len(rng) == 1 else pred
-    res = np.vstack([score(pr, Y) for pr in pred])
-    return rng, res
+    blocks = []
+    for kw in _pars_rows(pars):
+        fm = fun(Xtrain, Ytrain, nlv=max(rng), **kw)
+        if isinstance(fm, Plsr):
+            pred = predict(fm, X, nlv=rng)
+            pred = [pred] if len(rng) == 1 else pred
+        else:                                   # Lwplsr: pred (m, q, le) over its own clamped range
+            out = lwplsr_predict(fm, X, nlv=rng)
+            pred = [out["pred"][:, :, i] for i in range(out["pred"].shape[2])]
+        blocks.append(np.vstack([score(pr, Y) for pr in pred]))
+    return rng, np.vstack(blocks)
 
 
 def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None):
-    """src/gridcv.jl:187-228 with pars = nothing.  segm: list (replications) of lists (segments) of 0-based row
-    indices.  Returns (nlv values, res = mean over all (repl, segm) (le_nlv, q), res_rep (nrep, nsegm, le_nlv, q))."""
+    """src/gridcv.jl:187-228.  segm: list (replications) of lists (segments) of 0-based row indices.  Returns
+    (nlv values, res = mean over all (repl, segm) (ncomb * le_nlv, q), res_rep (nrep, nsegm, ncomb * le_nlv, q))."""
     X = ensure_mat(X); Y = ensure_mat(Y)
     p = X.shape[1]
     vals = np.atleast_1d(np.asarray(nlv))
@@ -657,7 +684,7 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None):
         zres = []
         for s in listsegm:
             s = np.asarray(s)
-            _, r = gridscorelv(rmrow(X, s), rmrow(Y, s), X[s, :], Y[s, :], score=score, fun=fun, nlv=rng)
+            _, r = gridscorelv(rmrow(X, s), rmrow(Y, s), X[s, :], Y[s, :], score=score, fun=fun, nlv=rng, pars=pars)
             zres.append(r)
         rep.append(np.stack(zres))
     res_rep = np.stack(rep)

@@ -651,3 +651,35 @@ def test_row_sharded_fit_matches_unsharded(alg, cuts, J):
         assert O.rel_fro(getattr(ref, f), getattr(fms[0], f)) < tol, f
     if alg == "plswold":
         assert np.array_equal(ref.niter, fms[0].niter)
+
+
+def test_pars_grids(J, ctx):
+    """`pars` grids of gridscorelv / gridcvlv (src/gridscore.jl:191-216, src/gridcv.jl:206-224) and `mpar`
+    (src/mpar.jl:15-24): PLS fits over scal, kNN-LWPLSR over (nlvdis, metric, h, k)."""
+    assert J.mpar(scal=[False, True], k=[3, 4, 5]) == O.mpar(scal=[False, True], k=[3, 4, 5])
+    rng_ = np.random.default_rng(5)
+    n, p, q = 900, 40, 2
+    Lt = rng_.standard_normal((n, 6))
+    X = Lt @ rng_.standard_normal((6, p)) + 0.3 * rng_.standard_normal((n, p))
+    Y = Lt[:, :3] @ rng_.standard_normal((3, q)) + 0.2 * rng_.standard_normal((n, q))
+    Xt, Yt, X, Y = X[:100], Y[:100], X[100:], Y[100:]
+    pars = J.mpar(scal=[False, True])
+    for jf, of in ((J.plskern, O.plskern), (J.plssimp, O.plssimp), (J.plswold, O.plswold)):
+        _, ref = O.gridscorelv(X, Y, Xt, Yt, score=O.rmsep, fun=of, nlv=range(0, 6), pars=pars)
+        res = J.gridscorelv(X, Y, Xt, Yt, score=J.rmsep, fun=jf, nlv=range(0, 6), pars=pars, ctx=ctx)
+        assert res["nlv"] == list(range(6)) * 2 and res["scal"] == [False] * 6 + [True] * 6
+        assert np.allclose(res["res"], ref, rtol=1e-7, atol=1e-12)
+    segm = J.segmkf(X.shape[0], 3, rep=1, seed=1)
+    _, ref, ref_rep = O.gridcvlv(X, Y, segm=segm, score=O.msep, fun=O.plskern, nlv=range(0, 5), pars=pars)
+    res = J.gridcvlv(X, Y, segm=segm, score=J.msep, fun=J.plskern, nlv=range(0, 5), pars=pars, ctx=ctx)
+    assert np.allclose(res["res"], ref, rtol=1e-6) and np.allclose(res["res_rep"], ref_rep, rtol=1e-6)
+    assert res["scal"] == [False] * 5 + [True] * 5
+    with pytest.raises(ValueError):
+        J.gridscorelv(X, Y, Xt, Yt, score=J.rmsep, fun=J.plskern, nlv=3, pars=dict(nlv=[1]), ctx=ctx)
+    # kNN-LWPLSR grid (the reference's own example, src/gridcv.jl:47-57, at a small size); y univariate
+    y = Y[:, :1]; yt = Yt[:, :1]
+    lp = J.mpar(nlvdis=[4], metric=["mahal"], h=[1.0, 3.0], k=[40, 80])
+    _, ref = O.gridscorelv(X, y, Xt, yt, score=O.rmsep, fun=O.lwplsr, nlv=range(0, 4), pars=lp)
+    res = J.gridscorelv(X, y, Xt, yt, score=J.rmsep, fun=J.lwplsr, nlv=range(0, 4), pars=lp, ctx=ctx)
+    assert res["h"] == [1.0] * 4 + [3.0] * 4 + [1.0] * 4 + [3.0] * 4 and res["k"] == [40] * 8 + [80] * 8
+    assert np.allclose(res["res"], ref, rtol=1e-6)

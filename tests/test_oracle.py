@@ -237,3 +237,21 @@ def test_sibling_oracles(name, golden_cases):
     assert fw.niter.min() >= 1 and fw.niter.max() <= 200
     # maxit caps the inner loop (src/plswold.jl:89)
     assert np.all(O.plswold(X, Y, w, nlv=2, scal=c["scal"], maxit=3).niter <= 3)
+
+
+def test_mpar_and_pars_grids():
+    """src/mpar.jl:15-24 (first keyword fastest) and the `pars` branch of gridscorelv / gridcvlv
+    (src/gridscore.jl:191-216, src/gridcv.jl:206-224): element-wise combinations, combination-major rows."""
+    pars = O.mpar(scal=[False, True], k=[3, 4, 5])
+    assert pars == {"scal": [False, True] * 3, "k": [3, 3, 4, 4, 5, 5]}
+    assert O.mpar(a=7, b="m") == {"a": [7], "b": ["m"]}
+    X = O.rand_matrix(1, 60, 12); Y = O.rand_matrix(2, 60, 2); Xt = O.rand_matrix(3, 9, 12); Yt = O.rand_matrix(4, 9, 2)
+    pars = O.mpar(scal=[False, True])
+    rng, res = O.gridscorelv(X, Y, Xt, Yt, score=O.rmsep, fun=O.plskern, nlv=range(0, 4), pars=pars)
+    assert res.shape == (2 * 4, 2)
+    for i, sc in enumerate(pars["scal"]):
+        _, one = O.gridscorelv(X, Y, Xt, Yt, score=O.rmsep, fun=lambda a, b, nlv: O.plskern(a, b, nlv=nlv, scal=sc), nlv=range(0, 4))
+        assert np.array_equal(res[4 * i:4 * i + 4], one)
+    segm = [[np.arange(0, 20), np.arange(20, 60)]]
+    _, cv, rep = O.gridcvlv(X, Y, segm=segm, score=O.msep, fun=O.plskern, nlv=range(0, 4), pars=pars)
+    assert cv.shape == (8, 2) and rep.shape == (1, 2, 8, 2) and np.allclose(cv, rep.mean(axis=(0, 1)))
