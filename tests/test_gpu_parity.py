@@ -584,7 +584,7 @@ def test_named_transform_predict_entry_points(golden_cases, J, ctx):
 
 
 # ------------------------------------------------------------------ row-sharded path on ONE GPU (loopback communicator)
-def _run_sharded(J, fn_name, shards, nlv, scal, **kw):
+def _run_sharded(J, fn_name, shards, nlv, scal, post=None, **kw):
     """One thread per rank, each with its own ctx (private stream) joined to a loopback group (include/jchemo_hip.h):
     executes exactly the library code of a multi-GPU fit — global weight sum and row count, all-reduced moments and
     XtY, one all-reduce per LV — with the transport replaced by a host-staged sum."""
@@ -602,6 +602,8 @@ def _run_sharded(J, fn_name, shards, nlv, scal, **kw):
             ctxs[r].comm_init_loopback(grp, r, nr)
             Xs, Ys, ws = shards[r]
             out[r] = getattr(J, fn_name)(Xs, Ys, ws, nlv=nlv, scal=scal, ctx=ctxs[r], **kw)
+            if post is not None:    # further collective calls of the same rank (every rank makes the same sequence)
+                out[r] = (out[r], post(out[r], Xs, Ys, ctxs[r]))
         except Exception as e:  # noqa: BLE001
             err[r] = e
 
@@ -683,3 +685,47 @@ def test_pars_grids(J, ctx):
     res = J.gridscorelv(X, y, Xt, yt, score=J.rmsep, fun=J.lwplsr, nlv=range(0, 4), pars=lp, ctx=ctx)
     assert res["h"] == [1.0] * 4 + [3.0] * 4 + [1.0] * 4 + [3.0] * 4 and res["k"] == [40] * 8 + [80] * 8
     assert np.allclose(res["res"], ref, rtol=1e-6)
+
+
+def test_row_sharded_bf16_and_reductions(J):
+    """BASELINE configs[2] is the bf16 storage mode on 8 GPUs: its sharded path (fp64 statistics and all-reduces from
+    bf16 rows) on 3 loopback ranks vs the single-rank bf16 fit; plus the sharded `summary` (jch_weighted_ss) and
+    score sums (jch_score_sums), whose results are sums over all ranks' shards."""
+    import torch
+    n, p, q, nlv = 9000, 200, 3, 6
+    X = CO.fill_uniform(20250112, n, p); Y = CO.fill_uniform(20250113, n, q)
+    w = 0.25 + O.splitmix64_uniform(7, 0, n)
+    edges = [0, 2500, 2600, n]
+
+    def dev_shard(a, b, dtype):
+        Xs = J.colmajor_empty(b - a, p, dtype=dtype); Xs.copy_(torch.from_numpy(X[a:b]))
+        Ys = J.colmajor_empty(b - a, q, dtype=dtype); Ys.copy_(torch.from_numpy(Y[a:b]))
+        return Xs, Ys, torch.from_numpy(w[a:b].copy()).cuda()
+
+    # ---- bf16: sharded == unsharded (same arithmetic up to the order of the fp64 partial sums)
+    whole = dev_shard(0, n, torch.bfloat16)
+    tctx = J.Context(0)
+    one = J.plskern(*whole, nlv=nlv, scal=True, ctx=tctx)
+    torch.cuda.synchronize()
+    fms = _run_sharded(J, "plskern", [dev_shard(a, b, torch.bfloat16) for a, b in zip(edges[:-1], edges[1:])], nlv, True)
+    for f in ("P", "R", "W", "C", "TT", "xmeans", "xscales"):
+        assert np.array_equal(getattr(fms[0], f), getattr(fms[2], f)), f
+        assert O.rel_fro(getattr(one, f), getattr(fms[0], f)) < 1e-5, f       # fp32 row arithmetic: partial-sum order differs
+    T = torch.cat([fm.T for fm in fms], dim=0).cpu().numpy()
+    assert O.rel_fro(one.T.cpu().numpy(), T) < 1e-5
+    # ---- f64: summary and scores over the shards
+    ref = O.plskern(X, Y, w, nlv=nlv)
+    sm_ref = O.summary(ref, X)
+    pr_ref = np.concatenate(O.predict(ref, X, nlv=range(0, nlv + 1)), axis=1)
+    ms_ref = np.stack([O.msep(pr_ref[:, i * q:(i + 1) * q], Y) for i in range(nlv + 1)]).reshape(nlv + 1, q)
+
+    def post(fm, Xs, Ys, ctx):
+        sm = J.summary(fm, Xs, ctx=ctx)
+        res = J.gridscorelv(Xs, Ys, Xs, Ys, score=J.msep, fun=lambda a, b, nlv, ctx: fm, nlv=range(0, nlv + 1), ctx=ctx)
+        return sm["cumpvar"], res["res"]
+
+    outs = _run_sharded(J, "plskern", [dev_shard(a, b, torch.float64) for a, b in zip(edges[:-1], edges[1:])], nlv, False, post=post)
+    for fm, (cum, ms) in outs:
+        assert O.rel_fro(sm_ref["cumpvar"], cum) < 1e-9
+        assert np.allclose(ms, ms_ref, rtol=1e-8)
+    tctx.close()
