@@ -394,7 +394,7 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     // ---- prologue
     JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr));
     int64_t n_total = n;
-    if (ctx->nranks > 1) {
+    if (ctx->nranks > 1 && n < std::min<int64_t>(p, d.nlv)) {   // see fit.hip: larger shards never need the global count
         double hdr_h[2];
         JCH_HIP(ctx, hipMemcpyAsync(hdr_h, s.hdr, sizeof hdr_h, hipMemcpyDeviceToHost, ctx->stream));
         JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));

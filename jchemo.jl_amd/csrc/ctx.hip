@@ -83,6 +83,7 @@ extern "C" int32_t jch_ctx_destroy(jch_ctx *ctx)
     for (jch_buf *b : {&ctx->gram, &ctx->xr, &ctx->yr, &ctx->xstage, &ctx->ystage, &ctx->wstage, &ctx->tbuf, &ctx->dnorm, &ctx->part,
                        &ctx->kpart, &ctx->small, &ctx->colpart, &ctx->gemm_b, &ctx->gemm_out, &ctx->xq})
         free_buf(*b);
+    if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -106,6 +107,25 @@ int32_t jch_reserve(jch_ctx *ctx, jch_buf &b, size_t bytes)
         return jch_fail(ctx, JCH_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     b.bytes = bytes;
+    return JCH_OK;
+}
+
+int32_t jch_reserve_host(jch_ctx *ctx, size_t bytes)
+{
+    if (ctx->hstage_bytes >= bytes) return JCH_OK;
+    if (ctx->hstage) {
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipHostFree(ctx->hstage);
+        ctx->hstage = nullptr;
+        ctx->hstage_bytes = 0;
+    }
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    hipError_t e = hipHostMalloc(&ctx->hstage, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->hstage = nullptr;
+        return jch_fail(ctx, JCH_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    ctx->hstage_bytes = bytes;
     return JCH_OK;
 }
 

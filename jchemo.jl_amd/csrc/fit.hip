@@ -127,13 +127,34 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
     s.K = cv.take((size_t)p * qpad); s.w = cv.take(ldr); s.r = cv.take(ldr);
+    // everything the caller gets back lives in ONE contiguous range [P .. niter]: fetched with a single D2H copy
     s.P = cv.take((size_t)nlv_cap * p); s.R = cv.take((size_t)nlv_cap * p); s.W = cv.take((size_t)nlv_cap * p);
-    s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap); s.Z = cv.take((size_t)nlv_cap * 16);
+    s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap);
+    s.mom = cv.take(p + q); s.scl = cv.take(p + q);
+    double *niter_dev = cv.take(nlv_cap);
+    const size_t out_bytes = (size_t)((char *)(niter_dev + nlv_cap) - (char *)s.P);
+    s.Z = cv.take((size_t)nlv_cap * 16);
     const int ldz = (ldr + 1 + qpad + 7) & ~7;
     s.zt = cv.take((size_t)JCH_ZT_SLICES * ldz); s.zpc = cv.take((size_t)ldr + qpad);
-    s.mom = cv.take(p + q); s.scl = cv.take(p + q); s.hdr = cv.take(8);
+    s.hdr = cv.take(8);
     s.variant = 0;
-    s.niter = algo == ALGO_WOLD ? cv.take(nlv_cap) : nullptr;
+    s.niter = algo == ALGO_WOLD ? niter_dev : nullptr;
+    // host copies of the small outputs: one pinned staging buffer, then plain memcpy into the caller's arrays
+    auto fetch_small = [&](int k) -> int32_t {
+        JCH_TRY(jch_reserve_host(ctx, out_bytes));
+        char *h = (char *)ctx->hstage;
+        JCH_HIP(ctx, hipMemcpyAsync(h, s.P, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        auto put = [&](double *dst, const double *dev, size_t count) {
+            if (dst) memcpy(dst, h + ((const char *)dev - (const char *)s.P), sizeof(double) * count);
+        };
+        put(io.P, s.P, (size_t)k * p); put(io.R, s.R, (size_t)k * p);
+        put(io.W, algo == ALGO_SIMP ? s.R : s.W, (size_t)k * p);   // SIMPLS has no W: R in its place (src/plssimp.jl:85-87)
+        put(io.C, s.C, (size_t)k * q); put(io.TT, s.TT, k);
+        put(io.xmeans, s.mom, p); put(io.ymeans, s.mom + p, q); put(io.xscales, s.scl, p); put(io.yscales, s.scl + p, q);
+        if (algo == ALGO_WOLD) put(io.niter, niter_dev, k);
+        return JCH_OK;
+    };
     s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
 
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
@@ -145,15 +166,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         JCH_TRY(jch_fit_plskern_bf16(ctx, d, io.X, io.ldx, io.Y, io.ldy, wdev, dn, Tdev, s, ldr, qpad, ldz, fastb, &nlvb));
         hipEvent_t eve = jch_ev(ctx);
         const size_t ev_last = ctx->ev_used - 1;
-        auto d2hb = [&](double *dst, const double *src, size_t count) -> int32_t {
-            if (dst) JCH_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
-            return JCH_OK;
-        };
-        JCH_TRY(d2hb(io.P, s.P, (size_t)nlvb * p)); JCH_TRY(d2hb(io.R, s.R, (size_t)nlvb * p)); JCH_TRY(d2hb(io.W, s.W, (size_t)nlvb * p));
-        JCH_TRY(d2hb(io.C, s.C, (size_t)nlvb * q)); JCH_TRY(d2hb(io.TT, s.TT, nlvb));
-        JCH_TRY(d2hb(io.xmeans, s.mom, p)); JCH_TRY(d2hb(io.ymeans, s.mom + p, q));
-        JCH_TRY(d2hb(io.xscales, s.scl, p)); JCH_TRY(d2hb(io.yscales, s.scl + p, q));
-        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        JCH_TRY(fetch_small(nlvb));
         if (io.nlv_out) *io.nlv_out = nlvb;
         if (ctx->profiling) {
             jch_profile &pr = ctx->prof;
@@ -171,7 +184,9 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     // ---- K0 weights; global row count for the nlv clamp (src/plskern.jl:116-117)
     JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr));
     int64_t n_total = n;
-    if (ctx->nranks > 1) {
+    // only a shard smaller than min(p, nlv) has to learn the global row count (one host sync); every rank reaches the
+    // same clamp either way, because n_total >= the largest shard
+    if (ctx->nranks > 1 && n < std::min<int64_t>(p, d.nlv)) {
         double hdr_h[2];
         JCH_HIP(ctx, hipMemcpyAsync(hdr_h, s.hdr, sizeof hdr_h, hipMemcpyDeviceToHost, ctx->stream));
         JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -252,12 +267,6 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         if (dst) JCH_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
         return JCH_OK;
     };
-    JCH_TRY(d2h(io.P, s.P, (size_t)nlv * p)); JCH_TRY(d2h(io.R, s.R, (size_t)nlv * p));
-    JCH_TRY(d2h(io.W, algo == ALGO_SIMP ? s.R : s.W, (size_t)nlv * p));   // SIMPLS has no W: R in its place (src/plssimp.jl:85-87)
-    JCH_TRY(d2h(io.C, s.C, (size_t)nlv * q)); JCH_TRY(d2h(io.TT, s.TT, nlv));
-    if (algo == ALGO_WOLD) JCH_TRY(d2h(io.niter, s.niter, nlv));
-    JCH_TRY(d2h(io.xmeans, s.mom, p)); JCH_TRY(d2h(io.ymeans, s.mom + p, q));
-    JCH_TRY(d2h(io.xscales, s.scl, p)); JCH_TRY(d2h(io.yscales, s.scl + p, q));
     if (host) {
         JCH_TRY(d2h(io.T, Tdev, (size_t)n * nlv));
         JCH_TRY(d2h(io.weights_norm, dn, (size_t)n));
@@ -266,7 +275,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
             JCH_TRY(d2h_matrix(ctx, (double *)io.Y, Yc, n, q, io.ldy));
         }
     }
-    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JCH_TRY(fetch_small(nlv));   // (ends with the stream sync of the whole fit)
     if (io.nlv_out) *io.nlv_out = nlv;
     if (s.dbg) {
         std::vector<double> h(nlv + 1);

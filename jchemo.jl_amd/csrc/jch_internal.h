@@ -43,6 +43,8 @@ struct jch_ctx {
     void *loop = nullptr;            // loopback group (tests; ctx.hip)
     std::vector<double> loop_sum;
     // workspace (grow-only)
+    void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
+    size_t hstage_bytes = 0;
     jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq;
     // profiling
     bool profiling = false;
@@ -70,6 +72,7 @@ int32_t jch_fail(jch_ctx *ctx, int32_t code, const char *fmt, ...);
     } while (0)
 
 int32_t jch_reserve(jch_ctx *ctx, jch_buf &b, size_t bytes);
+int32_t jch_reserve_host(jch_ctx *ctx, size_t bytes);   // ctx->hstage (pinned)
 int32_t jch_allreduce_f64(jch_ctx *ctx, double *dev_buf, size_t count);  // no-op when nranks == 1
 
 // profiling helpers: record an event on the stream when profiling is on

@@ -215,6 +215,83 @@ __device__ static bool dominant_by_squaring(int q, int lda, const double *G, dou
     return true;
 }
 
+// uniform broadcast of one lane's double (lane index may be a runtime value as long as it is wave-uniform)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Same job as dominant_by_squaring for the 16 x 16 case, entirely in registers on the matrix cores.
+// v_mfma_f64_16x16x4 takes A[m = lane&15][k = lane>>4] and B[k = lane>>4][n = lane&15] and returns
+// D[m = (lane>>4) + 4 reg][n = lane&15].  For a SYMMETRIC matrix held as x[j] = A[4 j + (lane>>4)][lane&15]
+// (j = 0..3) the register x[j] is at once the A-operand and the B-operand of k-block j, and the four result registers
+// of A*A are again exactly that layout: one squaring = 4 dependent MFMAs, no LDS, no shuffles.  The trace lives on
+// the 16 lanes 16 (m&3) + m (register m>>2) and is collected with v_readlane.  Each trip normalises by the trace and
+// squares TWICE: x <- (x / tr x)^4, so tr x = sum mu^4 for the normalised eigenvalues mu of the previous matrix;
+// 1 - tr x < 1e-12 means the previous matrix already had its second eigenvalue below 2.5e-13 of the first, and x
+// (its 4th power) is rank one to far below rounding.  Returns false (wave-uniform) after 12 trips = 24 squarings
+// (singular-value gap below ~3e-5): the caller falls back to Jacobi.  One wave; G in LDS (ld lda), zero-padded to 16.
+__device__ static bool dominant_by_squaring_mfma16(int q, int lda, const double *G, double *vout, double *dbg, double *stamps = nullptr)
+{
+    typedef double v4f64 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    double x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = G[(4 * j + (lane >> 4)) * lda + (lane & 15)];
+    bool ok = false;
+    int it = 0;
+    double dg[16];
+    if (stamps && lane == 0) stamps[0] = (double)__builtin_readcyclecounter();
+    for (; it < 13; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) dg[m] = readlane_f64(x[m >> 2], 16 * (m & 3) + m);
+        const double t = (((dg[0] + dg[1]) + (dg[2] + dg[3])) + ((dg[4] + dg[5]) + (dg[6] + dg[7]))) +
+                         (((dg[8] + dg[9]) + (dg[10] + dg[11])) + ((dg[12] + dg[13]) + (dg[14] + dg[15])));
+        if (it > 0 && (1.0 - t) < 1e-12) { ok = true; break; }
+        if (it == 12) break;
+        double isc = __builtin_amdgcn_rcp(t);
+        isc = isc * (2.0 - t * isc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] *= isc;
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) {
+            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[j], x[j], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = acc[j];
+        }
+    }
+    if (lane == 0 && dbg) *dbg = ok ? 200 + 2 * it : -1;
+    if (stamps && lane == 0) stamps[1] = (double)__builtin_readcyclecounter();
+    if (!ok) return false;
+    // dominant eigenvector = the column of the largest diagonal entry (dg is wave-uniform), normalised, largest-|.| > 0
+    int best = 0;
+    double bd = dg[0];
+#pragma unroll
+    for (int m = 1; m < 16; ++m)
+        if (dg[m] > bd) { bd = dg[m]; best = m; }
+    best = __builtin_amdgcn_readfirstlane(best);
+    double col[16], ss = 0.0, bigv = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        col[m] = readlane_f64(x[m >> 2], 16 * (m & 3) + best);      // A[m][best]
+        ss += col[m] * col[m];
+        if (fabs(col[m]) > fabs(bigv)) bigv = col[m];
+    }
+    const double sc = (bigv < 0.0 ? -1.0 : 1.0) / sqrt(ss);
+    double mine = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        if (lane == m) mine = sc * col[m];
+    if (lane < 16) vout[lane] = lane < q ? mine : 0.0;
+    if (stamps && lane == 0) stamps[2] = (double)__builtin_readcyclecounter();
+    return true;
+}
+
 // dot of column k of the LDS-resident K (ld ldk) with an LDS vector over rows j = j0, j0+stride, ... :
 // 8 rows per batch with clamped addresses so the loads are unconditional and issue together.
 __device__ __forceinline__ double kcol_dot(const double *Kl, int ldk, int k, const double *x, int j0, int stride, int p)

@@ -214,7 +214,10 @@ __global__ __launch_bounds__(FT) void k_lv_update_simp(lvf_args g)
     if (q > 1) {
         gram_lds<QP>(Kl, p, q, G0, scratch);
         if (wv == 0) {
-            if (!dominant_by_squaring<QP>(q, lda, G0, A0, A1, vl, nullptr)) {
+            bool solved;
+            if constexpr (QP == 16) solved = dominant_by_squaring_mfma16(q, lda, G0, vl, nullptr);
+            else solved = dominant_by_squaring<QP>(q, lda, G0, A0, A1, vl, nullptr);
+            if (!solved) {
                 for (int e = lane; e < QP * lda; e += 64) A0[e] = G0[e];
                 wavesync();
                 jacobi_wave(q, lda, A0, A1, V0, V1, csl, vl, nullptr);

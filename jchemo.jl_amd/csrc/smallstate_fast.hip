@@ -269,7 +269,11 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         Zl[a * QP + tid] = t / ztl[ldr];
     }
     if (q > 1 && wv == 0) {
-        if (!dominant_by_squaring<QP>(q, lda, G0, A0, A1, vl, g.s.dbg ? g.s.dbg + anext : nullptr)) {
+        bool solved;
+        if constexpr (QP == 16) solved = dominant_by_squaring_mfma16(q, lda, G0, vl, g.s.dbg ? g.s.dbg + anext : nullptr,
+                                                                  g.s.dbg ? g.s.dbg + 512 + 16 * (g.do_a ? a + 1 : 0) + 9 : nullptr);
+        else solved = dominant_by_squaring<QP>(q, lda, G0, A0, A1, vl, g.s.dbg ? g.s.dbg + anext : nullptr);
+        if (!solved) {
             for (int e = lane; e < QP * lda; e += 64) A0[e] = G0[e];
             wavesync();
             jacobi_wave(q, lda, A0, A1, V0, V1, csl, vl, g.s.dbg ? g.s.dbg + anext : nullptr);
