@@ -420,6 +420,66 @@ def summary(fm: Plsr, X, *, ctx: Optional[Context] = None):
     return dict(nlv=np.arange(1, nlv + 1), var=tt_adj / n, pvar=pvar, cumpvar=np.cumsum(pvar))
 
 
+def xfit(fm: Plsr, X, *, nlv: Optional[int] = None, ctx: Optional[Context] = None):
+    """`xfit(object, X; nlv)` — src/xfit.jl:37-56: X reconstructed from nlv LVs in the original scale,
+    (cscale(X) R_k) (P_k' diag(xscales)) + xmeans: the scores pass over X, then a GEMM on the m x nlv scores."""
+    k = _nlv_arg(fm, nlv)
+    p = fm.P.shape[0]
+    if k == 0:   # the column means (src/xfit.jl:41-45); an m x p broadcast through the same device primitive
+        return _affine(X, None, None, np.zeros((p, p)), fm.xmeans, ctx)
+    Tq = transform(fm, X, nlv=k, ctx=ctx)
+    return _affine(Tq, None, None, fm.P[:, :k].T * fm.xscales[None, :], fm.xmeans, ctx)
+
+
+def xresid(fm: Plsr, X, *, nlv: Optional[int] = None, ctx: Optional[Context] = None):
+    """`xresid(object, X; nlv)` — src/xfit.jl:86-93: E = X - xfit(X) = cscale(X) (I - R_k P_k') diag(xscales),
+    one p x p device GEMM on X (no n x p temporary on the host)."""
+    k = _nlv_arg(fm, nlv)
+    p = fm.P.shape[0]
+    M = np.eye(p) - fm.R[:, :k] @ fm.P[:, :k].T
+    return _affine(X, fm.xmeans, fm.xscales, M * fm.xscales[None, :], None, ctx)
+
+
+def vip(fm: Plsr, Y=None, *, nlv: Optional[int] = None, ctx: Optional[Context] = None):
+    """`vip(object; nlv)` / `vip(object, Y; nlv)` — src/vip.jl:62-107.  Without Y everything follows from W, C and
+    TT = t'Dt (p x nlv host glue); with Y the redundancies rd(Y, T, weights) (src/angles.jl:97-105) come from ONE
+    weighted covariance of [Y | T] on the device (jch_weighted_cov)."""
+    a = fm.P.shape[1]
+    p = fm.W.shape[0]
+    k = a if nlv is None else min(int(nlv), a)
+    W2 = fm.W[:, :k] ** 2
+    if Y is None:
+        sst = np.sum(fm.C[:, :k] ** 2, axis=0) * fm.TT[:k]       # tr(C_a C_a') * t_a'D t_a  (src/vip.jl:76-82)
+        A = (sst[None, :] * W2).sum(axis=1)
+        return dict(imp=np.sqrt(A / (sst.sum() / p)), W2=W2, sst=sst)
+    Y = ensure_mat(Y)
+    q = Y.shape[1]
+    T = fm.T[:, :k]
+    dev = _is_torch(T)
+    if dev:
+        Yd = Y if _is_torch(Y) else torch.as_tensor(np.asarray(Y, dtype=np.float64), device=T.device)
+        A_ = colmajor_empty(T.shape[0], q + k, T.device)
+        A_[:, :q] = Yd; A_[:, q:] = T
+        w = fm.weights
+    else:
+        A_ = np.asfortranarray(np.hstack([np.asarray(Y, dtype=np.float64), T]))   # layout only
+        w = np.ascontiguousarray(fm.weights)
+    if q + k > 64:
+        raise NotImplementedError("vip(object, Y): q + nlv > 64 is not supported")
+    ctx = ctx or default_context((T.device.index or 0) if dev else 0)
+    S = np.empty((q + k, q + k), order="F")
+    aa, lda = _addr_ld(A_)
+    if dev:
+        torch.cuda.current_stream(T.device).synchronize()
+    ctx.check(_lib.load().jch_weighted_cov(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, aa, A_.shape[0], q + k, lda,
+                                           w.data_ptr() if dev else w.ctypes.data, S.ctypes.data, None))
+    sd = np.sqrt(np.diag(S))
+    cor = S[:q, q:] / sd[:q, None] / sd[None, q:]
+    rdd = (cor ** 2).sum(axis=0, keepdims=True) / q
+    A = (rdd * W2).sum(axis=1)
+    return dict(imp=np.sqrt(A / (rdd.sum() / p)), W2=W2, rdd=rdd)
+
+
 # ---------------------------------------------------------------------------------- kNN-LWPLSR (src/lwplsr.jl)
 @dataclass
 class Lwplsr:

@@ -692,6 +692,56 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None):
 
 
 # --------------------------------------------------------------------------
+# vip / xfit / xresid (thin accessors of a fitted Plsr)
+# --------------------------------------------------------------------------
+def corm(X, Y, w):
+    """src/utility.jl:361-374 — weighted correlation between the columns of X and of Y."""
+    X = np.array(ensure_mat(X), dtype=np.float64, copy=True); Y = np.array(ensure_mat(Y), dtype=np.float64, copy=True)
+    w = mweight(w)
+    X = (X - colmean(X, w)) / colstd(X, w)
+    Y = (Y - colmean(Y, w)) / colstd(Y, w)
+    return X.T @ (w[:, None] * Y)
+
+
+def vip(fm: Plsr, Y=None, *, nlv: Optional[int] = None):
+    """src/vip.jl:62-107 — variable importance in projection.  Without Y: sst_a = tr(C_a C_a') t_a'D t_a (:76-82);
+    with Y: the redundancies rd(Y, T, weights) (:101, src/angles.jl:97-105).  Returns dict(imp, W2, sst | rdd)."""
+    a = fm.T.shape[1]
+    p = fm.W.shape[0]
+    nlv = a if nlv is None else min(nlv, a)
+    W2 = fm.W[:, :nlv] ** 2
+    if Y is None:
+        sqrtw = np.sqrt(fm.weights)
+        sst = np.zeros(nlv)
+        for i in range(nlv):
+            t = sqrtw * fm.T[:, i]
+            sst[i] = np.sum(fm.C[:, i] ** 2) * np.dot(t, t)
+        A = (sst[None, :] * W2).sum(axis=1)
+        return dict(imp=np.sqrt(A / (sst.sum() / p)), W2=W2, sst=sst)
+    Y = ensure_mat(Y)
+    rdd = (corm(Y, fm.T[:, :nlv], fm.weights) ** 2).sum(axis=0, keepdims=True) / Y.shape[1]
+    A = (rdd * W2).sum(axis=1)
+    return dict(imp=np.sqrt(A / (rdd.sum() / p)), W2=W2, rdd=rdd)
+
+
+def xfit(fm: Plsr, X, *, nlv: Optional[int] = None) -> np.ndarray:
+    """src/xfit.jl:37-56 — X reconstructed from nlv LVs, in the original scale (nlv = 0: the column means)."""
+    X = np.array(ensure_mat(X), dtype=np.float64, copy=True)
+    a = fm.T.shape[1]
+    nlv = a if nlv is None else min(nlv, a)
+    if nlv == 0:
+        X[:] = fm.xmeans[None, :]
+        return X
+    return transform(fm, X, nlv=nlv) @ fm.P[:, :nlv].T * fm.xscales[None, :] + fm.xmeans[None, :]
+
+
+def xresid(fm: Plsr, X, *, nlv: Optional[int] = None) -> np.ndarray:
+    """src/xfit.jl:86-93 — E = X - xfit(X)."""
+    X = np.array(ensure_mat(X), dtype=np.float64, copy=True)
+    return X - xfit(fm, X, nlv=nlv)
+
+
+# --------------------------------------------------------------------------
 # PLSR-DA (SURVEY §8f rank 4): plskern on the dummy table of the classes
 # --------------------------------------------------------------------------
 def dummy(y):

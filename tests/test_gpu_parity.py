@@ -729,3 +729,26 @@ def test_row_sharded_bf16_and_reductions(J):
         assert O.rel_fro(sm_ref["cumpvar"], cum) < 1e-9
         assert np.allclose(ms, ms_ref, rtol=1e-8)
     tctx.close()
+
+
+def test_vip_xfit_xresid(golden_cases, J, ctx):
+    """§8f rank 4 accessors of a fitted Plsr: vip (src/vip.jl:62-107), xfit / xresid (src/xfit.jl:37-93)."""
+    import torch
+    for name in ("cfg1_scal_w", "wide_q"):
+        c = golden_cases.CASES[name]
+        X, Y, Xt, w = golden_cases.inputs(c)
+        ref = O.plskern(X, Y, w, nlv=c["nlv"], scal=c["scal"])
+        fm = J.plskern(X, Y, w, nlv=c["nlv"], scal=c["scal"], ctx=ctx)
+        for k in (None, 0, 1, 3):
+            assert O.rel_fro(O.xfit(ref, Xt, nlv=k), J.xfit(fm, Xt, nlv=k, ctx=ctx)) < TIGHT
+            assert O.rel_fro(O.xresid(ref, Xt, nlv=k), J.xresid(fm, Xt, nlv=k, ctx=ctx)) < 1e-8
+        for k in (None, 2):
+            assert O.rel_fro(O.vip(ref, nlv=k)["imp"], J.vip(fm, nlv=k)["imp"]) < TIGHT
+            vr, vg = O.vip(ref, Y, nlv=k), J.vip(fm, Y, nlv=k, ctx=ctx)
+            assert O.rel_fro(vr["imp"], vg["imp"]) < TIGHT and O.rel_fro(vr["rdd"], vg["rdd"]) < TIGHT
+    # device-resident model and data
+    Xd = J.colmajor_empty(*X.shape); Xd.copy_(torch.from_numpy(X))
+    Yd = J.colmajor_empty(*Y.shape); Yd.copy_(torch.from_numpy(Y))
+    fd = J.plskern(Xd, Yd, torch.from_numpy(w).cuda(), nlv=c["nlv"], scal=c["scal"], ctx=ctx)
+    assert O.rel_fro(O.vip(ref, Y)["imp"], J.vip(fd, Yd, ctx=ctx)["imp"]) < TIGHT
+    assert O.rel_fro(O.xresid(ref, X, nlv=2), J.xresid(fd, Xd, nlv=2, ctx=ctx).cpu().numpy()) < 1e-8

@@ -255,3 +255,22 @@ def test_mpar_and_pars_grids():
     segm = [[np.arange(0, 20), np.arange(20, 60)]]
     _, cv, rep = O.gridcvlv(X, Y, segm=segm, score=O.msep, fun=O.plskern, nlv=range(0, 4), pars=pars)
     assert cv.shape == (8, 2) and rep.shape == (1, 2, 8, 2) and np.allclose(cv, rep.mean(axis=(0, 1)))
+
+
+def test_vip_xfit_xresid_oracle(golden_cases):
+    """src/vip.jl:62-107, src/xfit.jl:37-93: identities that pin the restatements."""
+    c = golden_cases.CASES["ragged"]
+    X, Y, Xt, w = golden_cases.inputs(c)
+    fm = O.plskern(X, Y, w, nlv=c["nlv"], scal=True)          # nlv = p = 13: full rank -> exact reconstruction
+    assert O.rel_fro(X, O.xfit(fm, X)) < 1e-9
+    assert np.allclose(O.xfit(fm, Xt, nlv=0), np.tile(fm.xmeans, (Xt.shape[0], 1)))
+    for k in (1, 4):
+        assert O.rel_fro(Xt, O.xfit(fm, Xt, nlv=k) + O.xresid(fm, Xt, nlv=k)) < 1e-14
+    v = O.vip(fm, nlv=5)
+    assert v["imp"].shape == (13,) and abs(np.mean(v["imp"] ** 2) - 1) < 1e-12      # VIP^2 average to 1 (unit-norm W)
+    vy = O.vip(fm, Y, nlv=5)
+    assert abs(np.mean(vy["imp"] ** 2) - 1) < 1e-12 and vy["rdd"].shape == (1, 5) and np.all(vy["rdd"] <= 1 + 1e-12)
+    y1 = Y[:, :1]
+    f1 = O.plskern(X, y1, w, nlv=4)
+    # univariate y: rd(y, t_a) = cor(y, t_a)^2 is proportional to c_a^2 tt_a -> both VIP definitions coincide
+    assert O.rel_fro(O.vip(f1)["imp"], O.vip(f1, y1)["imp"]) < 1e-10
