@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=1_000_000)  # (--rows: torchrun's own parser trips over --n)
     ap.add_argument("--p", type=int, default=500)
     ap.add_argument("--q", type=int, default=10)
     ap.add_argument("--nlv", type=int, default=25)
@@ -100,6 +100,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # JCH_BENCH_REHEARSAL=1: every rank on GPU 0, gloo for the host-side exchange, P2P inbox as the only transport —
+    # the way to run the multi-rank code of this file on a one-GPU box (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("JCH_BENCH_REHEARSAL", "0") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -107,13 +112,43 @@ def main():
     from jchemo_hip import _lib
     lib = J.load()
     ctx = J.Context(local_rank, stream="torch")
+    p2p_candidate = False
+    fdev = dev
+    transport = "none (single GPU)"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        box = [J.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ctx.comm_init(box[0], rank, world)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            box = [J.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], rank, world)
+        fdev = torch.device("cpu") if rehearsal else dev      # where the small agreement tensors live
+        # P2P inbox transport for the latency-bound per-LV all-reduce (csrc/p2p.hip): IPC handles exchanged here, the
+        # library runs a collective self-test; it is only ENABLED further down, after a whole fit through it has
+        # reproduced the RCCL fit on every rank.  JCH_P2P=0 keeps RCCL for everything.
+        if os.environ.get("JCH_P2P", "1") != "0" and world <= 16:
+            try:
+                handle = ctx.p2p_export(world)
+            except Exception as e:  # noqa: BLE001
+                handle = None
+                print(f"[bench] rank {rank}: p2p export failed: {e}", file=sys.stderr)
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)
+            ok = False
+            if all(h is not None for h in handles):
+                ok = ctx.p2p_import(handles, rank, world)
+                if not ok:
+                    print(f"[bench] rank {rank}: p2p import/self-test failed: {getattr(ctx, 'p2p_error', '')}", file=sys.stderr)
+            flag = torch.tensor([1 if ok else 0], device=fdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            p2p_candidate = bool(flag.item() == 1)
+        if rehearsal:
+            if not p2p_candidate:
+                sys.exit("bench.py rehearsal: the P2P transport did not come up")
+            ctx.p2p_enable(True)
 
     n_total, p, q, nlv = args.n, args.p, args.q, args.nlv
     row0 = (n_total * rank) // world
@@ -157,6 +192,30 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if rehearsal:
+        transport = "p2p inbox only (one-GPU rehearsal)"
+    elif world > 1:
+        transport = "rccl"
+        step()                          # reference fit: every collective through RCCL
+        if p2p_candidate:
+            P_ref, TT_ref = P.copy(), TT.copy()
+            good = 0
+            try:
+                ctx.p2p_enable(True)
+                step()
+                den = max(float(np.linalg.norm(P_ref)), 1e-300)
+                good = int(np.linalg.norm(P - P_ref) <= 1e-9 * den and np.allclose(TT, TT_ref, rtol=1e-9, atol=0.0))
+            except Exception as e:  # noqa: BLE001   (a bounded wait timed out: the library has switched the transport off)
+                print(f"[bench] rank {rank}: fit through the p2p transport failed: {e}", file=sys.stderr)
+            flag = torch.tensor([good], device=fdev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if flag.item() == 1:
+                transport = "p2p inbox over xGMI for messages <= 256 KB (per-LV [zp, tt], moments, XtY), rccl otherwise"
+            else:
+                try:
+                    ctx.p2p_enable(False)
+                except Exception:  # noqa: BLE001
+                    pass
     ctx.set_profiling(True)        # HIP events on the ctx stream around every sweep launch
     for _ in range(args.warmup):
         step()
@@ -172,7 +231,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=fdev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -193,7 +252,8 @@ def main():
             "config": {"workload": f"{args.algo} n={n_total} p={p} q={q} nlv={nlv} {'bf16-stored' if bf16 else 'Float64'} "
                                    f"({'BASELINE.json configs[1]' if (args.algo, n_total, p, q, nlv, bf16) == ('plskern', 1000000, 500, 10, 25, False) else 'variant'}), "
                                    f"X/Y device-resident column-major, rows sharded over {world} GPU(s)",
-                       "n": n_total, "p": p, "q": q, "nlv": k, "rows_per_gpu": n, "timed": "prologue + LV loop, device-resident"},
+                       "n": n_total, "p": p, "q": q, "nlv": k, "rows_per_gpu": n, "timed": "prologue + LV loop, device-resident",
+                       "collective_transport": transport},
             "roofline": ({"bound": "mfma", "kernel": kernel, "achieved": n * p * (p + 1) / avg_sweep_s / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                           "frac": n * p * (p + 1) / avg_sweep_s / 1e12 / 78.6, "traffic": None, "flop_per_launch": n * p * (p + 1),
                           "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches} if args.algo == "plskern2" else

@@ -72,6 +72,21 @@ JCH_API int32_t jch_comm_unique_id(void *uid128);
 JCH_API int32_t jch_ctx_comm_init(jch_ctx *ctx, const void *uid128, int32_t rank, int32_t nranks);
 JCH_API int32_t jch_ctx_comm_info(const jch_ctx *ctx, int32_t *rank, int32_t *nranks);
 
+/* ---- P2P inbox transport for the latency-bound all-reduces (the per-LV [zp, tt] message is 4 KB) -----------------
+ * Each rank owns an inbox in fine-grained device memory; the other ranks' processes map it through a HIP IPC handle
+ * and store their contribution + an epoch flag straight into it over xGMI; one single-workgroup kernel per rank and
+ * all-reduce, sums in rank order (bit-identical on every rank), bounded waits (a lost peer yields JCH_ERCCL, never a
+ * hang).  Set-up, driven by the host side that already exchanged the RCCL id:
+ *   1. every rank: jch_ctx_p2p_export(ctx, nranks, handle64)             -> 64-byte IPC handle of its inbox
+ *   2. all-gather the handles (torch.distributed / MPI), every rank: jch_ctx_p2p_import(ctx, handles, rank, nranks, 0)
+ *      — maps the peers and runs a collective self-test; returns JCH_ERCCL on the ranks where it failed
+ *   3. agree (min over ranks of "import succeeded") and call jch_ctx_p2p_enable(ctx, 1) everywhere, or leave it off:
+ *      RCCL (jch_ctx_comm_init) remains the transport for large messages and the fallback.
+ * `flags` is reserved (0).  nranks <= 16. */
+JCH_API int32_t jch_ctx_p2p_export(jch_ctx *ctx, int32_t nranks, void *handle64);
+JCH_API int32_t jch_ctx_p2p_import(jch_ctx *ctx, const void *handles, int32_t rank, int32_t nranks, uint32_t flags);
+JCH_API int32_t jch_ctx_p2p_enable(jch_ctx *ctx, int32_t on);
+
 /* Loopback communicator — TEST HARNESS for the row-sharded path on a one-GPU box (RCCL refuses two ranks on one device):
  * the "ranks" are host threads of ONE process, each with its own ctx on the same GPU; all-reduces are staged through
  * host memory in rank order (bit-identical sums on every rank, like the RCCL path).  Every rank thread must make the

@@ -80,6 +80,7 @@ extern "C" int32_t jch_ctx_destroy(jch_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    jch_p2p_destroy(ctx);
     for (jch_buf *b : {&ctx->gram, &ctx->xr, &ctx->yr, &ctx->xstage, &ctx->ystage, &ctx->wstage, &ctx->tbuf, &ctx->dnorm, &ctx->part,
                        &ctx->kpart, &ctx->small, &ctx->colpart, &ctx->gemm_b, &ctx->gemm_out, &ctx->xq})
         free_buf(*b);
@@ -256,10 +257,19 @@ static int32_t loopback_allreduce(jch_ctx *ctx, double *dev_buf, size_t count)
     return JCH_OK;
 }
 
+// messages up to this many doubles go through the P2P inbox when it is enabled (latency-bound sizes); larger ones
+// (X'DX of the opt-in algorithm #2) stay on RCCL when a communicator exists
+static const size_t P2P_SMALL = 32768;
+
 int32_t jch_allreduce_f64(jch_ctx *ctx, double *dev_buf, size_t count)
 {
-    if (ctx->loop && count > 0) return loopback_allreduce(ctx, dev_buf, count);
-    if (!ctx->comm || count == 0) return JCH_OK;  // single rank: the local sum is the global sum
+    if (count == 0) return JCH_OK;
+    if (ctx->loop) return loopback_allreduce(ctx, dev_buf, count);
+    if (ctx->p2p.ready && (count <= P2P_SMALL || !ctx->comm)) return jch_p2p_allreduce(ctx, dev_buf, count, 1, 0, dev_buf);
+    if (!ctx->comm) {
+        if (ctx->nranks > 1) return jch_fail(ctx, JCH_ERCCL, "rank %d of %d has no enabled transport (jch_ctx_p2p_enable not called?)", ctx->rank, ctx->nranks);
+        return JCH_OK;  // single rank: the local sum is the global sum
+    }
     int r = g_rccl.AllReduce(dev_buf, dev_buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
     if (r != 0) return jch_fail(ctx, JCH_ERCCL, "ncclAllReduce(%zu f64): %s", count, g_rccl.GetErrorString(r));
     return JCH_OK;
@@ -291,4 +301,15 @@ extern "C" int32_t jch_ctx_get_profile(const jch_ctx *ctx, jch_profile *out)
     if (!ctx || !out) return JCH_EINVAL;
     *out = ctx->prof;
     return JCH_OK;
+}
+
+int32_t jch_allreduce_slices(jch_ctx *ctx, double *zt, int m, int nslice, int ldz, int *nslice_out)
+{
+    *nslice_out = nslice;
+    if (ctx->nranks <= 1) return JCH_OK;
+    if (ctx->p2p.ready && !ctx->loop) {   // the inbox kernel adds the slices itself: a 4 KB message instead of 33 KB
+        *nslice_out = 1;
+        return jch_p2p_allreduce(ctx, zt, (size_t)m, nslice, ldz, zt);
+    }
+    return jch_allreduce_f64(ctx, zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)m);
 }

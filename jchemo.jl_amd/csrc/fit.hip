@@ -167,6 +167,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         hipEvent_t eve = jch_ev(ctx);
         const size_t ev_last = ctx->ev_used - 1;
         JCH_TRY(fetch_small(nlvb));
+        JCH_TRY(jch_p2p_check(ctx));
         if (io.nlv_out) *io.nlv_out = nlvb;
         if (ctx->profiling) {
             jch_profile &pr = ctx->prof;
@@ -232,13 +233,13 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         if (kern_like) {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;   // rank-independent message size (a small shard may use 1 slice; the rest hold zeros)
-            JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1));  // ONE collective per LV: [zp (p), tt]
+            JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1, nslice, ldz, &nslice));  // ONE collective per LV: [zp (p), tt]
             if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
             else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
         } else {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;
-            JCH_TRY(jch_allreduce_f64(ctx, s.zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)ldr + 1 + qpad));  // [zp_raw, tt, c_raw]
+            JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + qpad, nslice, ldz, &nslice));  // [zp_raw, tt, c_raw]
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast));
             const bool last = a + 1 == nlv;
             if (!last || inplace) {
@@ -276,6 +277,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         }
     }
     JCH_TRY(fetch_small(nlv));   // (ends with the stream sync of the whole fit)
+    JCH_TRY(jch_p2p_check(ctx));
     if (io.nlv_out) *io.nlv_out = nlv;
     if (s.dbg) {
         std::vector<double> h(nlv + 1);

@@ -31,6 +31,19 @@ struct jch_rccl {  // RCCL entry points, dlopen'ed on first use (single-GPU user
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+#define JCH_P2P_MAXR 16
+struct jch_p2p {   // P2P inbox transport (p2p.hip)
+    bool ready = false, tested = false;
+    int nranks = 0, rank = 0;
+    void *local = nullptr;                     // own inbox (fine-grained device memory)
+    void *peer[JCH_P2P_MAXR] = {};             // every rank's inbox as mapped here
+    bool opened[JCH_P2P_MAXR] = {};
+    unsigned long long *host_status = nullptr, *host_status_dev = nullptr;   // pinned, device-visible sticky error word
+    unsigned long long epoch = 0;
+    long long timeout_ticks = 0;
+    size_t cap = 0;                            // doubles per (parity, rank) slot
+};
+
 struct jch_ctx {
     int device = 0;
     int cus = 256;
@@ -41,6 +54,7 @@ struct jch_ctx {
     void *comm = nullptr;
     int rank = 0, nranks = 1;
     void *loop = nullptr;            // loopback group (tests; ctx.hip)
+    jch_p2p p2p;
     std::vector<double> loop_sum;
     // workspace (grow-only)
     void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
@@ -74,6 +88,13 @@ int32_t jch_fail(jch_ctx *ctx, int32_t code, const char *fmt, ...);
 int32_t jch_reserve(jch_ctx *ctx, jch_buf &b, size_t bytes);
 int32_t jch_reserve_host(jch_ctx *ctx, size_t bytes);   // ctx->hstage (pinned)
 int32_t jch_allreduce_f64(jch_ctx *ctx, double *dev_buf, size_t count);  // no-op when nranks == 1
+// all-reduce of the per-LV sweep output zt [nslice][ldz] (first m entries of every slice); *nslice_out = slices the
+// consumer has to add afterwards (1 when the transport summed them)
+int32_t jch_allreduce_slices(jch_ctx *ctx, double *zt, int m, int nslice, int ldz, int *nslice_out);
+// p2p.hip
+int32_t jch_p2p_allreduce(jch_ctx *ctx, const double *src, size_t count, int nslice, int ldz, double *dst);
+int32_t jch_p2p_check(jch_ctx *ctx);
+void jch_p2p_destroy(jch_ctx *ctx);
 
 // profiling helpers: record an event on the stream when profiling is on
 struct jch_span {

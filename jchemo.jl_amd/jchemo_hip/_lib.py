@@ -26,6 +26,7 @@ SYMBOLS = (
     "jch_weighted_ss", "jch_fill_uniform", "jch_ctx_set_profiling", "jch_ctx_get_profile", "jch_lwplsr_predict",
     "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
     "jch_predict", "jch_loopback_group_create", "jch_loopback_group_destroy", "jch_ctx_comm_init_loopback",
+    "jch_ctx_p2p_export", "jch_ctx_p2p_import", "jch_ctx_p2p_enable",
 )
 
 
@@ -69,6 +70,9 @@ def load():
     L.jch_loopback_group_create.argtypes = [i32, C.POINTER(vp)]
     L.jch_loopback_group_destroy.argtypes = [vp]
     L.jch_ctx_comm_init_loopback.argtypes = [vp, vp, i32]
+    L.jch_ctx_p2p_export.argtypes = [vp, i32, vp]
+    L.jch_ctx_p2p_import.argtypes = [vp, vp, i32, i32, C.c_uint32]
+    L.jch_ctx_p2p_enable.argtypes = [vp, i32]
     fit = [vp, C.POINTER(PlsDesc), dp, i64, dp, i64, dp] + [dp] * 11 + [C.POINTER(i32)]
     L.jch_plskern_fit.argtypes = fit
     L.jch_plsnipals_fit.argtypes = fit
@@ -136,6 +140,26 @@ class Context:
         """Test harness: ranks = threads of this process on one GPU (include/jchemo_hip.h, loopback communicator)."""
         self.check(load().jch_ctx_comm_init_loopback(self._h, group, rank))
         self.rank, self.nranks = rank, nranks
+
+    # ---- P2P inbox transport (include/jchemo_hip.h): export -> exchange handles -> import (self-test) -> enable
+    def p2p_export(self, nranks: int) -> bytes:
+        buf = C.create_string_buffer(64)
+        self.check(load().jch_ctx_p2p_export(self._h, nranks, buf))
+        return buf.raw
+
+    def p2p_import(self, handles, rank: int, nranks: int) -> bool:
+        """handles: the nranks 64-byte IPC handles in rank order.  Collective call (maps the peers, runs the self-test);
+        returns whether THIS rank's self-test passed — agree over all ranks before p2p_enable."""
+        buf = C.create_string_buffer(b"".join(handles), 64 * nranks)
+        st = load().jch_ctx_p2p_import(self._h, buf, rank, nranks, 0)
+        if st == JCH_OK:
+            self.rank, self.nranks = rank, nranks
+        else:
+            self.p2p_error = load().jch_last_error(self._h).decode()
+        return st == JCH_OK
+
+    def p2p_enable(self, on: bool):
+        self.check(load().jch_ctx_p2p_enable(self._h, int(on)))
 
     def set_profiling(self, on: bool):
         self.check(load().jch_ctx_set_profiling(self._h, int(on)))
