@@ -55,6 +55,68 @@ __global__ __launch_bounds__(256) void k_moments_bf16(const bf16_t *__restrict__
     if (threadIdx.x == 0) colpart[(size_t)blockIdx.y * (size_t)(p + q) + j] = s;
 }
 
+// 16-byte variant of K1: a thread owns 8 consecutive rows (one 16-B load per column, the 8 weights stay in registers)
+// and walks over MCG columns, so the weight vector is read once per MCG columns instead of once per column (it is 4x
+// the bytes of a bf16 column) and every global access is 16 B.  Needs 16-B aligned bases and leading dimensions % 8.
+#define MCG 16
+template <bool VAR>
+__global__ __launch_bounds__(256) void k_moments_bf16_v8(const bf16_t *__restrict__ Xc, int64_t ldx, const bf16_t *__restrict__ Yc,
+                                                          int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
+                                                          int64_t chunk, const double *__restrict__ means,
+                                                          double *__restrict__ colpart)
+{
+    __shared__ double sc[4];
+    typedef double v2f64_ __attribute__((ext_vector_type(2)));
+    const int j0 = blockIdx.x * MCG;
+    const int m = p + q;
+    const int64_t i0 = (int64_t)blockIdx.y * chunk;                 // chunk is a multiple of 8 * 256
+    const int64_t i1 = i0 + chunk < n ? i0 + chunk : n;
+    double mj[MCG], acc[MCG];
+#pragma unroll
+    for (int c = 0; c < MCG; ++c) { mj[c] = (VAR && j0 + c < m) ? means[j0 + c] : 0.0; acc[c] = 0.0; }
+    for (int64_t i = i0 + 8 * (int64_t)threadIdx.x; i < i1; i += 8 * 256) {
+        double dv[8];
+        if (i + 8 <= n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v2f64_ t = *reinterpret_cast<const v2f64_ *>(d + i + 2 * k);
+                dv[2 * k] = t.x; dv[2 * k + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dv[k] = i + k < n ? d[i + k] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < MCG; ++c) {
+            const int j = j0 + c;
+            if (j >= m) break;
+            const bf16_t *col = j < p ? Xc + (size_t)j * (size_t)ldx : Yc + (size_t)(j - p) * (size_t)ldy;
+            float x[8];
+            if (i + 8 <= n) {
+                const v4u32 w = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(col + i));
+                x[0] = bflo(w.x); x[1] = bfhi(w.x); x[2] = bflo(w.y); x[3] = bfhi(w.y);
+                x[4] = bflo(w.z); x[5] = bfhi(w.z); x[6] = bflo(w.w); x[7] = bfhi(w.w);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = i + k < n ? bf2f(col[i + k]) : 0.0f;
+            }
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double v = (double)x[k];
+                if (VAR) { v -= mj[c]; v *= v; }
+                a += dv[k] * v;
+            }
+            acc[c] += a;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MCG; ++c) {
+        const double t = jch_block_sum<256>(acc[c], sc);
+        if (threadIdx.x == 0 && j0 + c < m) colpart[(size_t)blockIdx.y * (size_t)m + j0 + c] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_colreduce_b(const double *__restrict__ colpart, int S, int m, double *__restrict__ out)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -78,6 +140,23 @@ static int32_t launch_moments_bf16(jch_ctx *ctx, const bf16_t *Xc, int64_t ldx, 
                                    int64_t n, int p, int q, const double *means, double *out)
 {
     const int m = p + q;
+    const bool v8 = ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && ((uintptr_t)Yc) % 16 == 0 && ((uintptr_t)d) % 16 == 0 &&
+                    !getenv("JCH_BF16_SCALAR_PROLOGUE");
+    if (v8) {
+        const int cg = (m + MCG - 1) / MCG;
+        int S = std::max(1, (ctx->cus * 8 + cg - 1) / cg);
+        int64_t chunk = ((n + S - 1) / S + 2047) / 2048 * 2048;      // multiple of 8 rows x 256 threads
+        S = (int)std::max<int64_t>(1, (n + chunk - 1) / chunk);
+        JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * ((size_t)S * m + 4096)));
+        double *colpart = (double *)ctx->colpart.ptr;
+        if (means) hipLaunchKernelGGL(k_moments_bf16_v8<true>, dim3(cg, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk, means, colpart);
+        else hipLaunchKernelGGL(k_moments_bf16_v8<false>, dim3(cg, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk, means, colpart);
+        hipLaunchKernelGGL(k_colreduce_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, colpart, S, m, out);
+        JCH_TRY(jch_allreduce_f64(ctx, out, (size_t)m));
+        if (means) hipLaunchKernelGGL(k_sqrt_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, out, m);
+        JCH_HIP(ctx, hipGetLastError());
+        return JCH_OK;
+    }
     int S = std::min(64, std::max(1, (ctx->cus * 8 + m - 1) / m));
     int64_t chunk = ((n + S - 1) / S + 255) / 256 * 256;
     if (chunk < 256) chunk = 256;
@@ -166,6 +245,136 @@ __global__ __launch_bounds__(256) void k_center_xty_bf16(const bf16_t *__restric
     }
 }
 
+// 16-byte variant of K2: a lane loads 8 consecutive rows of one column (16 B), and stores 8 consecutive columns of
+// one row of the row-major copy (16 B); same tile, same LDS transposition, same MFMA XtY as above.
+#define XR_LD 72
+template <bool SCAL>
+__global__ __launch_bounds__(256) void k_center_xty_bf16_v8(const bf16_t *__restrict__ Xc, int64_t ldx, const bf16_t *__restrict__ Yc,
+                                                             int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
+                                                             const double *__restrict__ mom, const double *__restrict__ scl,
+                                                             bf16_t *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
+                                                             double *__restrict__ Kpart, int kp_rows)
+{
+    __shared__ double xt[64 * XT_LD];
+    __shared__ double yt[64 * YT_LD];
+    // raw bf16 tile, COLUMN-major [col][XR_LD rows]: a lane's 8 consecutive rows of one column go in with one 16-B store
+    // (row-major 2-B stores hit 8 banks with 64 lanes); the row-major output gathers 8 columns of one row, conflict-free
+    __shared__ __attribute__((aligned(16))) bf16_t xraw[64 * XR_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = blockIdx.y * 64, yg = blockIdx.z;
+    const int64_t nchunks = (n + 63) / 64;
+    const int rg = lane & 7, cl = lane >> 3;          // load role: rows 8 rg .. 8 rg + 7 of column (2 wv + k) * 8 + cl
+    double cm[2], cs[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int j = j0 + (2 * wv + k) * 8 + cl;
+        cm[k] = j < p ? mom[j] : 0.0;
+        cs[k] = (SCAL && j < p) ? scl[j] : 1.0;
+    }
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    // software pipeline: the global loads of chunk c + gridDim.x are in flight while chunk c is transposed / multiplied
+    v4u32 xw[2];
+    bf16_t yraw[4];
+    double dreg[4];
+    auto prefetch = [&](int64_t cc) {
+        const int64_t i0 = cc * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + 256 * k, row = e & 63, col = e >> 6;
+            const int yc = yg * 16 + col;
+            const int64_t i = i0 + row;
+            const bool ok = i < n && yc < q;
+            yraw[k] = ok ? Yc[(size_t)i + (size_t)yc * (size_t)ldy] : (bf16_t)0;
+            dreg[k] = ok ? d[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = j0 + (2 * wv + k) * 8 + cl;
+            const int64_t i = i0 + 8 * rg;
+            v4u32 w = {0u, 0u, 0u, 0u};
+            if (j < p && i + 8 <= n) {
+                w = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(Xc + (size_t)i + (size_t)j * (size_t)ldx));
+            } else if (j < p) {   // row tail: element loads, packed like the vector
+                unsigned h[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) h[r] = i + r < n ? (unsigned)Xc[(size_t)(i + r) + (size_t)j * (size_t)ldx] : 0u;
+                w.x = h[0] | (h[1] << 16); w.y = h[2] | (h[3] << 16); w.z = h[4] | (h[5] << 16); w.w = h[6] | (h[7] << 16);
+            }
+            xw[k] = w;
+        }
+    };
+    int64_t c = blockIdx.x;
+    if (c < nchunks) prefetch(c);
+    for (; c < nchunks; c += gridDim.x) {
+        const int64_t i0 = c * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + 256 * k, row = e & 63, col = e >> 6;
+            const int yc = yg * 16 + col;
+            const int64_t i = i0 + row;
+            double v = 0.0, dv = 0.0;
+            if (i < n && yc < q) {
+                v = (double)bf2f(yraw[k]) - mom[p + yc];
+                if (SCAL) v /= scl[p + yc];
+                dv = dreg[k];
+            }
+            if (blockIdx.y == 0 && i < n) Yr[(size_t)i * qpad + yc] = v;
+            yt[row * YT_LD + col] = dv * v;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = (2 * wv + k) * 8 + cl, j = j0 + col;
+            const int64_t i = i0 + 8 * rg;
+            bf16_t raw[8];
+            {
+                const v4u32 w = xw[k];
+                raw[0] = (bf16_t)(w.x & 0xffffu); raw[1] = (bf16_t)(w.x >> 16); raw[2] = (bf16_t)(w.y & 0xffffu); raw[3] = (bf16_t)(w.y >> 16);
+                raw[4] = (bf16_t)(w.z & 0xffffu); raw[5] = (bf16_t)(w.z >> 16); raw[6] = (bf16_t)(w.w & 0xffffu); raw[7] = (bf16_t)(w.w >> 16);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                double v = 0.0;
+                if (j < p && i + r < n) {
+                    v = (double)bf2f(raw[r]) - cm[k];
+                    if (SCAL) v /= cs[k];
+                }
+                xt[(8 * rg + r) * XT_LD + col] = v;
+            }
+            *reinterpret_cast<v4u32 *>(xraw + col * XR_LD + 8 * rg) = xw[k];
+        }
+        __syncthreads();
+        if (c + gridDim.x < nchunks) prefetch(c + gridDim.x);
+        if (yg == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int row = (2 * wv + k) * 8 + (lane >> 3), cg = lane & 7;
+                const int64_t i = i0 + row;
+                const int j = j0 + 8 * cg;
+                if (i < n && j < ldr) {
+                    unsigned h[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = xraw[(8 * cg + e) * XR_LD + row];
+                    const v4u32 w = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+                    __builtin_nontemporal_store(w, reinterpret_cast<v4u32 *>(Xr + (size_t)i * ldr + j));
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int row = 4 * kk + (lane >> 4);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[row * XT_LD + 16 * wv + (lane & 15)], yt[row * YT_LD + (lane & 15)], acc,
+                                                       0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double *kp = Kpart + ((size_t)blockIdx.x * kp_rows) * qpad;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int j = j0 + 16 * wv + (lane >> 4) + 4 * reg;
+        if (j < kp_rows) kp[(size_t)j * qpad + yg * 16 + (lane & 15)] = acc[reg];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_reduce_kpart_b(const double *__restrict__ Kpart, int nbx, int kp_rows, int p, int qpad,
                                                         double *__restrict__ K)
 {
@@ -225,7 +434,8 @@ __device__ __forceinline__ void wave_sum_rows(float (&s)[R], float (&t)[R])
 // lane l owns columns 8l..8l+7 (+512k): one 16-B load per row chunk.  rt, off: see the header comment.
 template <int KC, int R>
 __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ Xr, int64_t n, int ldr, const double *__restrict__ dw,
-                                                    const float *__restrict__ rt, const double *__restrict__ offp,
+                                                    const double *__restrict__ rvec, const double *__restrict__ mom,
+                                                    const double *__restrict__ scl, int p,
                                                     double *__restrict__ tcol, double *__restrict__ part, int ldpart)
 {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [4][KC*512] + [8]
@@ -237,9 +447,23 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
         const int col = 8 * lane + 512 * k;
         in[k] = col < ldr;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { rf[k][e] = in[k] ? rt[col + e] : 0.f; zp[k][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { rf[k][e] = 0.f; zp[k][e] = 0.f; }
     }
-    const float off = (float)offp[0];
+    // rt_j = r_j / s_j (fp32) and off = sum_j m_j * rt_j (fp64, from the fp32-rounded rt so that the row sums and the offset
+    // use the same coefficients): every wave derives them from the replicated fp64 r — identical bits in all waves
+    double offd = 0.0;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 8 * lane + 512 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < p) {
+                const float v = (float)(rvec[col + e] / scl[col + e]);
+                rf[k][e] = v;
+                offd += mom[col + e] * (double)v;
+            }
+    }
+    const float off = (float)jch_wave_sum(offd);
     double tt = 0.0, st = 0.0;
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * 4;
@@ -300,55 +524,26 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
     }
 }
 
-__global__ __launch_bounds__(1024) void k_reduce_part_b(const double *__restrict__ part, int nb, int ldpart, int m,
-                                                        double *__restrict__ zt)
-{
-    __shared__ double sc[16][64];
-    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0;
-    if (c < m)
-        for (int b = g; b < nb; b += 16) s += part[(size_t)b * ldpart + c];
-    sc[g][cl] = s;
-    __syncthreads();
-    if (g == 0 && c < m) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += sc[k][cl];
-        zt[c] = t;
-    }
-}
-
 // zp_j <- (zp_raw_j - m_j * st) / s_j ;  slot [ldz_tt] <- tt      (after the cross-GPU all-reduce)
-__global__ __launch_bounds__(256) void k_bf16_fix_zt(double *__restrict__ zt, int ldr_b, int p, int ldr_small,
+// (zt holds nslice partial slices of [zp_raw (ldr_b), tt, st], ld ldzb: summed here in fixed order)
+__global__ __launch_bounds__(256) void k_bf16_fix_zt(const double *__restrict__ zt, int nslice, int ldzb, int ldr_b, int p, int ldr_small,
                                                      const double *__restrict__ mom, const double *__restrict__ scl,
                                                      double *__restrict__ zt_small)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    const double tt = zt[ldr_b], st = zt[ldr_b + 1];
-    if (j < ldr_small) zt_small[j] = j < p ? (zt[j] - mom[j] * st) / scl[j] : 0.0;
+    double tt = 0.0, st = 0.0, z = 0.0;
+    for (int sl = 0; sl < nslice; ++sl) {
+        tt += zt[(size_t)sl * ldzb + ldr_b];
+        st += zt[(size_t)sl * ldzb + ldr_b + 1];
+        if (j < p) z += zt[(size_t)sl * ldzb + j];
+    }
+    if (j < ldr_small) zt_small[j] = j < p ? (z - mom[j] * st) / scl[j] : 0.0;
     if (j == 0) zt_small[ldr_small] = tt;
 }
 
-// rt_j = r_j / s_j (fp32), off = sum_j m_j * rt_j (fp64, from the fp32-rounded rt so that the sweep's row sums and the
-// offset use the same coefficients)
-__global__ __launch_bounds__(256) void k_bf16_make_rt(const double *__restrict__ r, int p, int ldr_b, const double *__restrict__ mom,
-                                                      const double *__restrict__ scl, float *__restrict__ rt, double *__restrict__ off)
-{
-    __shared__ double sc[4];
-    double s = 0.0;
-    for (int j = threadIdx.x; j < ldr_b; j += 256) {
-        float v = 0.f;
-        if (j < p) { v = (float)(r[j] / scl[j]); s += mom[j] * (double)v; }
-        rt[j] = v;
-    }
-    s = jch_block_sum<256>(s, sc);
-    if (threadIdx.x == 0) off[0] = s;
-}
-
 template <int KC, int R>
-static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, int ldr_b, const double *d, const float *rt,
-                                   const double *off, double *tcol, double *zt_raw)
+static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, int ldr_b, const double *d, const double *rvec,
+                                   const double *mom, const double *scl, int p, double *tcol, double *zt8, int ldzb, int *nslice)
 {
     const size_t lds = sizeof(double) * (4 * KC * 512 + 8);
     static int bpc = 0;
@@ -367,9 +562,9 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->part.ptr;
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL((k_sweep_bf16<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rt, off, tcol, part, ldpart);
+    hipLaunchKernelGGL((k_sweep_bf16<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
     (void)jch_ev(ctx);
-    JCH_TRY(jch_launch_reduce_rows(ctx, part, nb, ldpart, m, zt_raw));
+    JCH_TRY(jch_launch_reduce_part8(ctx, part, nb, ldpart, m, zt8, ldzb, nslice));
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }
@@ -387,10 +582,9 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     JCH_TRY(jch_reserve(ctx, ctx->yr, sizeof(double) * (size_t)n * qpad));
     bf16_t *Xr = (bf16_t *)ctx->xr.ptr;
     double *Yr = (double *)ctx->yr.ptr;
-    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, sizeof(double) * ((size_t)ldr_b + 16) + sizeof(float) * (size_t)ldr_b + 64));
-    double *zt_raw = (double *)ctx->gemm_b.ptr;        // [ldr_b + 2] (+pad)
-    float *rt = (float *)(zt_raw + ((ldr_b + 2 + 7) & ~7));
-    double *off = zt_raw + ldr_b + 4;
+    const int ldzb = (ldr_b + 2 + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, sizeof(double) * (size_t)JCH_ZT_SLICES * ldzb));
+    double *zt8 = (double *)ctx->gemm_b.ptr;           // [JCH_ZT_SLICES][ldzb]: partial slices of [zp_raw, tt, st]
     // ---- prologue
     JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr));
     int64_t n_total = n;
@@ -412,7 +606,12 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * qpad));
         double *Kpart = (double *)ctx->kpart.ptr;
         dim3 grid(nbx, ptiles, ygroups);
-        if (d.scal) hipLaunchKernelGGL(k_center_xty_bf16<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
+        const bool v8 = ldx % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && !getenv("JCH_BF16_SCALAR_PROLOGUE");
+        if (v8 && d.scal) hipLaunchKernelGGL(k_center_xty_bf16_v8<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
+                                             s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
+        else if (v8) hipLaunchKernelGGL(k_center_xty_bf16_v8<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
+                                        s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
+        else if (d.scal) hipLaunchKernelGGL(k_center_xty_bf16<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
                                        s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
         else hipLaunchKernelGGL(k_center_xty_bf16<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
                                 s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
@@ -424,18 +623,21 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     // ---- LV loop
     JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, -1, nlv, 0, 1, ldz, fast));
     for (int a = 0; a < nlv; ++a) {
-        hipLaunchKernelGGL(k_bf16_make_rt, dim3(1), dim3(256), 0, ctx->stream, s.r, p, ldr_b, s.mom, s.scl, rt, off);
         double *tcol = Tdev + (size_t)a * (size_t)n;
         static int rsel = -1;
         if (rsel < 0) { const char *e = getenv("JCH_BF16_R"); rsel = e ? atoi(e) : 2; }   // measured at n = 1e6, p = 500: R = 8 / 4 / 2 -> 4.0 / 4.85 / 5.2 TB/s
-        if (ldr_b <= 512 && rsel == 4) JCH_TRY((launch_sweep_bf16_t<1, 4>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
-        else if (ldr_b <= 512 && rsel == 2) JCH_TRY((launch_sweep_bf16_t<1, 2>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
-        else if (ldr_b <= 512) JCH_TRY((launch_sweep_bf16_t<1, 8>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
-        else if (ldr_b <= 1024) JCH_TRY((launch_sweep_bf16_t<2, 4>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
-        else JCH_TRY((launch_sweep_bf16_t<4, 2>(ctx, Xr, n, ldr_b, dn, rt, off, tcol, zt_raw)));
-        JCH_TRY(jch_allreduce_f64(ctx, zt_raw, (size_t)ldr_b + 2));   // ONE collective per LV: [zp_raw, tt, st]
-        hipLaunchKernelGGL(k_bf16_fix_zt, dim3((ldr_small + 255) / 256), dim3(256), 0, ctx->stream, zt_raw, ldr_b, p, ldr_small, s.mom,
-                           s.scl, s.zt);
+        int nslice = 1;
+#define JCH_SWB(KC, R) JCH_TRY((launch_sweep_bf16_t<KC, R>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)))
+        if (ldr_b <= 512 && rsel == 4) JCH_SWB(1, 4);
+        else if (ldr_b <= 512 && rsel == 2) JCH_SWB(1, 2);
+        else if (ldr_b <= 512) JCH_SWB(1, 8);
+        else if (ldr_b <= 1024) JCH_SWB(2, 4);
+        else JCH_SWB(4, 2);
+#undef JCH_SWB
+        if (ctx->nranks > 1) nslice = JCH_ZT_SLICES;                      // rank-independent message size (unused slices hold zeros)
+        JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));   // ONE collective per LV: [zp_raw, tt, st]
+        hipLaunchKernelGGL(k_bf16_fix_zt, dim3((ldr_small + 255) / 256), dim3(256), 0, ctx->stream, zt8, nslice, ldzb, ldr_b, p, ldr_small,
+                           s.mom, s.scl, s.zt);
         JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, 1, ldz, fast));
     }
     JCH_HIP(ctx, hipGetLastError());

@@ -155,6 +155,17 @@ int32_t jch_launch_reduce_rows(jch_ctx *ctx, const double *part, int nb, int ldp
     return JCH_OK;
 }
 
+// Stage 1 of the fixed-order reduction for callers that keep the slices (bf16 path): always writes JCH_ZT_SLICES slices
+// (unused ones zero); *nslice_out = 1 when only slice 0 is populated.
+int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *zt, int ldz, int *nslice_out)
+{
+    int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
+    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
+    JCH_HIP(ctx, hipGetLastError());
+    *nslice_out = nslice > 1 ? JCH_ZT_SLICES : 1;
+    return JCH_OK;
+}
+
 template <int KC, int R, bool NT = true>
 static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                               const double *Yr, int qpad, bool nipals, double *tcol, double *zt, int ldz, int max_slices,

@@ -752,3 +752,26 @@ def test_vip_xfit_xresid(golden_cases, J, ctx):
     fd = J.plskern(Xd, Yd, torch.from_numpy(w).cuda(), nlv=c["nlv"], scal=c["scal"], ctx=ctx)
     assert O.rel_fro(O.vip(ref, Y)["imp"], J.vip(fd, Yd, ctx=ctx)["imp"]) < TIGHT
     assert O.rel_fro(O.xresid(ref, X, nlv=2), J.xresid(fd, Xd, nlv=2, ctx=ctx).cpu().numpy()) < 1e-8
+
+
+def test_bf16_vector_prologue_tails(J):
+    """bf16 storage with a padded leading dimension (ld % 8 == 0, n % 8 != 0): the 16-byte prologue kernels take their
+    row-tail branches; result must equal the scalar-prologue result of the same data bit for bit in the fp64 statistics."""
+    import torch
+    n, ld, p, q, nlv = 1003, 1008, 77, 2, 5
+    X = CO.fill_uniform(20250112, n, p); Y = CO.fill_uniform(20250113, n, q)
+    w = 0.25 + O.splitmix64_uniform(7, 0, n)
+    Xb = J.colmajor_empty(ld, p, dtype=torch.bfloat16)[:n]; Xb.copy_(torch.from_numpy(X))
+    Yb = J.colmajor_empty(ld, q, dtype=torch.bfloat16)[:n]; Yb.copy_(torch.from_numpy(Y))
+    assert Xb.stride() == (1, ld)
+    Xq = Xb.to(torch.float64).cpu().numpy(); Yq = Yb.to(torch.float64).cpu().numpy()
+    ref = O.plskern(Xq, Yq, w, nlv=nlv, scal=True)
+    tctx = J.Context(0, stream="torch")
+    fm = J.plskern(Xb, Yb, w, nlv=nlv, scal=True, ctx=tctx)
+    s = O.sign_align(ref.W, fm.W)
+    assert O.rel_fro(ref.xmeans, fm.xmeans) < 1e-12 and O.rel_fro(ref.xscales, fm.xscales) < 1e-12
+    assert O.rel_fro(ref.ymeans, fm.ymeans) < 1e-12 and O.rel_fro(ref.yscales, fm.yscales) < 1e-12
+    for f in ("P", "C", "W", "R"):
+        assert O.rel_fro(getattr(ref, f), getattr(fm, f) * s) < 1e-3, f
+    assert O.rel_fro(ref.T, fm.T.cpu().numpy() * s) < 1e-3
+    tctx.close()
