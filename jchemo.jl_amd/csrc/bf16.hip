@@ -432,7 +432,7 @@ __device__ __forceinline__ void wave_sum_rows(float (&s)[R], float (&t)[R])
 
 // ---------------------------------------------------------------- K4 (bf16 storage): fused sweep, fp32 row arithmetic
 // lane l owns columns 8l..8l+7 (+512k): one 16-B load per row chunk.  rt, off: see the header comment.
-template <int KC, int R>
+template <int KC, int R, bool PF>
 __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ Xr, int64_t n, int ldr, const double *__restrict__ dw,
                                                     const double *__restrict__ rvec, const double *__restrict__ mom,
                                                     const double *__restrict__ scl, int p,
@@ -467,16 +467,34 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
     double tt = 0.0, st = 0.0;
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * 4;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wv; g < ngroups; g += gstride) {
-        const int64_t row0 = g * R;
-        v4u32 x[R][KC];
+    // software pipeline (PF): the rows of the wave's NEXT group are requested before the current group is reduced — a
+    // bf16 row is only 1 KB, so without it a CU has barely the bytes in flight that 8 TB/s x memory latency asks for
+    v4u32 xn[R][KC];
+    double dwn[R];
+    auto fetch = [&](int64_t gg) {
+        const int64_t r0 = gg * R;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            const bool live = row0 + rr < n;
-            const v4u32 *rp = reinterpret_cast<const v4u32 *>(Xr + (size_t)(row0 + rr) * (size_t)ldr) + lane;
+            const bool live = r0 + rr < n;
+            const v4u32 *rp = reinterpret_cast<const v4u32 *>(Xr + (size_t)(r0 + rr) * (size_t)ldr) + lane;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) x[rr][k] = (live && in[k]) ? __builtin_nontemporal_load(rp + 64 * k) : v4u32{0u, 0u, 0u, 0u};
+            for (int k = 0; k < KC; ++k) xn[rr][k] = (live && in[k]) ? __builtin_nontemporal_load(rp + 64 * k) : v4u32{0u, 0u, 0u, 0u};
+            dwn[rr] = live ? dw[r0 + rr] : 0.0;
         }
+    };
+    int64_t g = (int64_t)blockIdx.x * 4 + wv;
+    if (g < ngroups) fetch(g);
+    for (; g < ngroups; g += gstride) {
+        const int64_t row0 = g * R;
+        v4u32 x[R][KC];
+        double dwc[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            dwc[rr] = dwn[rr];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) x[rr][k] = xn[rr][k];
+        }
+        if (PF && g + gstride < ngroups) fetch(g + gstride);
         double tsel = 0.0;
         float sp[R], tr[R];
 #pragma unroll
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
         for (int rr = 0; rr < R; ++rr) {
             const bool live = row0 + rr < n;
             const float t = tr[rr] - off;
-            const float dtf = live ? (float)dw[row0 + rr] * t : 0.f;
+            const float dtf = live ? (float)dwc[rr] * t : 0.f;
             tt += (double)dtf * (double)t;
             st += (double)dtf;
 #pragma unroll
@@ -506,6 +524,7 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
             if (lane == rr) tsel = (double)t;
         }
         if (lane < R && row0 + lane < n) tcol[row0 + lane] = tsel;
+        if (!PF && g + gstride < ngroups) fetch(g + gstride);
     }
     double *zred = red;                 // [4][KC*512]
     double *tred = red + 4 * KC * 512;  // [8]
@@ -541,7 +560,7 @@ __global__ __launch_bounds__(256) void k_bf16_fix_zt(const double *__restrict__ 
     if (j == 0) zt_small[ldr_small] = tt;
 }
 
-template <int KC, int R>
+template <int KC, int R, bool PF = true>
 static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, int ldr_b, const double *d, const double *rvec,
                                    const double *mom, const double *scl, int p, double *tcol, double *zt8, int ldzb, int *nslice)
 {
@@ -549,10 +568,10 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
     static int bpc = 0;
     if (bpc == 0) {
         int nblk = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_bf16<KC, R>, 256, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_bf16<KC, R, PF>, 256, lds);
         bpc = (e == hipSuccess && nblk > 0) ? nblk : 2;
         if (lds > 64 * 1024)
-            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_bf16<KC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_bf16<KC, R, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int64_t ngroups = (n + R - 1) / R;
     static int bpc_env = -1;
@@ -562,7 +581,7 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->part.ptr;
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL((k_sweep_bf16<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
+    hipLaunchKernelGGL((k_sweep_bf16<KC, R, PF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
     (void)jch_ev(ctx);
     JCH_TRY(jch_launch_reduce_part8(ctx, part, nb, ldpart, m, zt8, ldzb, nslice));
     JCH_HIP(ctx, hipGetLastError());
@@ -625,10 +644,14 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
         static int rsel = -1;
-        if (rsel < 0) { const char *e = getenv("JCH_BF16_R"); rsel = e ? atoi(e) : 2; }   // measured at n = 1e6, p = 500: R = 8 / 4 / 2 -> 4.0 / 4.85 / 5.2 TB/s
+        if (rsel < 0) { const char *e = getenv("JCH_BF16_R"); rsel = e ? atoi(e) : 4; }   // measured at n = 1e6, p = 500 with the prefetch: R = 2 / 4 / 8 -> 5.35 / 5.84 / 5.40 TB/s (without: 4.67 / 5.07)
         int nslice = 1;
 #define JCH_SWB(KC, R) JCH_TRY((launch_sweep_bf16_t<KC, R>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)))
-        if (ldr_b <= 512 && rsel == 4) JCH_SWB(1, 4);
+        static int pfsel = -1;
+        if (pfsel < 0) { const char *e = getenv("JCH_BF16_PF"); pfsel = e ? atoi(e) : 1; }
+        if (ldr_b <= 512 && rsel == 4 && !pfsel) JCH_TRY((launch_sweep_bf16_t<1, 4, false>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)));
+        else if (ldr_b <= 512 && rsel == 2 && !pfsel) JCH_TRY((launch_sweep_bf16_t<1, 2, false>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)));
+        else if (ldr_b <= 512 && rsel == 4) JCH_SWB(1, 4);
         else if (ldr_b <= 512 && rsel == 2) JCH_SWB(1, 2);
         else if (ldr_b <= 512) JCH_SWB(1, 8);
         else if (ldr_b <= 1024) JCH_SWB(2, 4);

@@ -21,7 +21,7 @@
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
-template <int KC, int R, bool NIPALS, bool NT>
+template <int KC, int R, bool NIPALS, bool NT, bool PF>
 __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, int64_t n, int ldr,
                                                const double *__restrict__ dw, const double *__restrict__ rvec,
                                                const double *__restrict__ Yr, int qpad, double *__restrict__ tcol,
@@ -41,17 +41,34 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
     double tt = 0.0, cacc = 0.0;
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * nw;
-    for (int64_t g = (int64_t)blockIdx.x * nw + wv; g < ngroups; g += gstride) {
-        const int64_t row0 = g * R;
-        v2f64 x[R][KC];
+    // PF: the rows (and weights) of the wave's next group are requested before the current group is reduced
+    v2f64 xn[R][KC];
+    double dwn[R];
+    auto fetch = [&](int64_t gg) {
+        const int64_t r0 = gg * R;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            const bool live = row0 + rr < n;  // wave-uniform
-            const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xr + (size_t)(row0 + rr) * (size_t)ldr) + lane;
+            const bool live = r0 + rr < n;  // wave-uniform
+            const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xr + (size_t)(r0 + rr) * (size_t)ldr) + lane;
 #pragma unroll
             for (int k = 0; k < KC; ++k)
-                x[rr][k] = (live && in[k]) ? (NT ? __builtin_nontemporal_load(rp + 64 * k) : rp[64 * k]) : v2f64{0.0, 0.0};
+                xn[rr][k] = (live && in[k]) ? (NT ? __builtin_nontemporal_load(rp + 64 * k) : rp[64 * k]) : v2f64{0.0, 0.0};
+            dwn[rr] = live ? dw[r0 + rr] : 0.0;
         }
+    };
+    int64_t g = (int64_t)blockIdx.x * nw + wv;
+    if (g < ngroups) fetch(g);
+    for (; g < ngroups; g += gstride) {
+        const int64_t row0 = g * R;
+        v2f64 x[R][KC];
+        double dwc[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            dwc[rr] = dwn[rr];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) x[rr][k] = xn[rr][k];
+        }
+        if (PF && g + gstride < ngroups) fetch(g + gstride);
         double tsel = 0.0;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
@@ -60,7 +77,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
             for (int k = 0; k < KC; ++k) s += x[rr][k].x * rf[k].x + x[rr][k].y * rf[k].y;
             const double t = jch_wave_sum(s);
             const bool live = row0 + rr < n;
-            const double dt = live ? dw[row0 + rr] * t : 0.0;
+            const double dt = live ? dwc[rr] * t : 0.0;
             tt += dt * t;
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
@@ -74,6 +91,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
             if (lane == rr) tsel = t;
         }
         if (lane < R && row0 + lane < n) tcol[row0 + lane] = tsel;
+        if (!PF && g + gstride < ngroups) fetch(g + gstride);
     }
     // ---- combine the waves of the block in wave order, then one partial row per block
     double *zred = red;                     // [nw][KC*128]
@@ -166,7 +184,7 @@ int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ld
     return JCH_OK;
 }
 
-template <int KC, int R, bool NT = true>
+template <int KC, int R, bool NT = true, bool PF = false>
 static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                               const double *Yr, int qpad, bool nipals, double *tcol, double *zt, int ldz, int max_slices,
                               int *nslice_out, int m)
@@ -179,8 +197,8 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     const size_t lds = sizeof(double) * (4 * KC * 128 + 16 + 256);
     if (bpc_cache[nipals] == 0) {
         int nblk = 0;
-        hipError_t e = nipals ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, true, NT>, 256, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, false, NT>, 256, lds);
+        hipError_t e = nipals ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, true, NT, PF>, 256, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep<KC, R, false, NT, PF>, 256, lds);
         bpc_cache[nipals] = (e == hipSuccess && nblk > 0) ? nblk : 2;
     }
     const int bpc = ctx->sweep_blocks_per_cu > 0 ? ctx->sweep_blocks_per_cu : bpc_cache[nipals];
@@ -194,10 +212,10 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     double *part = (double *)ctx->part.ptr;
     (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
     if (nipals)
-        hipLaunchKernelGGL((k_sweep<KC, R, true, NT>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
+        hipLaunchKernelGGL((k_sweep<KC, R, true, NT, PF>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
                            tcol, part, ldpart);
     else
-        hipLaunchKernelGGL((k_sweep<KC, R, false, NT>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
+        hipLaunchKernelGGL((k_sweep<KC, R, false, NT, PF>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
                            tcol, part, ldpart);
     (void)jch_ev(ctx);  // (end)
     int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
@@ -219,24 +237,31 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
     (void)p;
     const bool nip = q_extra > 0;
     const int m = ldr + 1 + (nip ? qpad : 0);
-#define JCH_SWEEP_CASE(KC, R) return launch_sweep_t<KC, R>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m)
-    if (ldr <= 128) JCH_SWEEP_CASE(1, 4);
-    if (ldr <= 256) JCH_SWEEP_CASE(2, 4);
-    if (ldr <= 512) {   // tuning knobs for the headline shape (defaults chosen from measurements)
-        static int rsel = -1, ntsel = -1;
-        if (rsel < 0) { const char *e = getenv("JCH_SWEEP_R"); rsel = e ? atoi(e) : 4; }
-        if (ntsel < 0) { const char *e = getenv("JCH_SWEEP_NT"); ntsel = e ? atoi(e) : 1; }
-#define JCH_SWEEP_CASE_NT(KC, R, NT) return launch_sweep_t<KC, R, NT>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m)
-        if (rsel == 2 && !ntsel) JCH_SWEEP_CASE_NT(4, 2, false);
-        if (rsel == 2 && ntsel) JCH_SWEEP_CASE_NT(4, 2, true);
-        if (rsel == 8 && !ntsel) JCH_SWEEP_CASE_NT(4, 8, false);
-        if (rsel == 8 && ntsel) JCH_SWEEP_CASE_NT(4, 8, true);
-        if (!ntsel) JCH_SWEEP_CASE_NT(4, 4, false);
-        JCH_SWEEP_CASE(4, 4);
-#undef JCH_SWEEP_CASE_NT
+    // Default: software-prefetched kernels with 8 rows x 4 KB (32 KB) per wave in flight ahead of the 32 KB being reduced
+    // (measured at cfg2 on one box: R = 4 no prefetch 0.629 ms, R = 8 no prefetch 0.633, R = 8 prefetch 0.605).
+    // JCH_SWEEP_PF=0 selects the previous kernels, JCH_SWEEP_R / JCH_SWEEP_NT keep working for the p <= 512 shape.
+    static int pfsel = -1, rsel = -1, ntsel = -1;
+    if (pfsel < 0) { const char *e = getenv("JCH_SWEEP_PF"); pfsel = e ? atoi(e) : 1; }
+    if (rsel < 0) { const char *e = getenv("JCH_SWEEP_R"); rsel = e ? atoi(e) : 0; }
+    if (ntsel < 0) { const char *e = getenv("JCH_SWEEP_NT"); ntsel = e ? atoi(e) : 1; }
+#define JCH_SWEEP_CASE(KC, R, NT, PF) return launch_sweep_t<KC, R, NT, PF>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m)
+    // narrow rows keep the plain kernels: 16 rows per wave-iteration with prefetch were measured 1.5-1.8x SLOWER at
+    // p = 100 / 200 (the per-row butterfly dominates); p = 1000: +6.8 % (7.06 TB/s), p = 2000: +1.7 %
+    if (ldr <= 128) JCH_SWEEP_CASE(1, 4, true, false);
+    if (ldr <= 256) JCH_SWEEP_CASE(2, 4, true, false);
+    if (ldr <= 512) {
+        if (pfsel && rsel == 2) JCH_SWEEP_CASE(4, 2, true, true);
+        if (pfsel && rsel == 4) JCH_SWEEP_CASE(4, 4, true, true);
+        if (pfsel) JCH_SWEEP_CASE(4, 8, true, true);
+        if (rsel == 2 && !ntsel) JCH_SWEEP_CASE(4, 2, false, false);
+        if (rsel == 2 && ntsel) JCH_SWEEP_CASE(4, 2, true, false);
+        if (rsel == 8 && !ntsel) JCH_SWEEP_CASE(4, 8, false, false);
+        if (rsel == 8 && ntsel) JCH_SWEEP_CASE(4, 8, true, false);
+        if (!ntsel) JCH_SWEEP_CASE(4, 4, false, false);
+        JCH_SWEEP_CASE(4, 4, true, false);
     }
-    if (ldr <= 1024) JCH_SWEEP_CASE(8, 2);
-    if (ldr <= 2048) JCH_SWEEP_CASE(16, 1);
+    if (ldr <= 1024) { if (pfsel) JCH_SWEEP_CASE(8, 4, true, true); JCH_SWEEP_CASE(8, 2, true, false); }
+    if (ldr <= 2048) { if (pfsel) JCH_SWEEP_CASE(16, 2, true, true); JCH_SWEEP_CASE(16, 1, true, false); }
 #undef JCH_SWEEP_CASE
     // wider rows: two-pass fallback (sweep_wide.hip), single reduced vector
     *nslice_out = 1;
