@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_reduce_kpart2(const double *__restrict_
 // no LDS transpose, 16-B coalesced loads and stores, K_next accumulated like zp.  Per-block partials
 // part[b][k * ldr + c] are summed in fixed order by k_reduce_kstream (deterministic).
 typedef double v2f64 __attribute__((ext_vector_type(2)));
-template <int KC, int R, int Q>
+template <int KC, int R, int Q, bool PF>
 __global__ __launch_bounds__(256) void k_deflate_stream(double *__restrict__ Xr, int64_t n, int ldr, double *__restrict__ Yr,
                                                          int qpad, const double *__restrict__ dw,
                                                          const double *__restrict__ tcol, const double *__restrict__ zpc,
@@ -139,22 +139,41 @@ __global__ __launch_bounds__(256) void k_deflate_stream(double *__restrict__ Xr,
     for (int y = 0; y < Q; ++y) cf[y] = zpc[ldr + y];
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * 4;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wv; g < ngroups; g += gstride) {
-        const int64_t row0 = g * R;
-        v2f64 x[R][KC];
+    // software prefetch: rows, scores and weights of the wave's next group are requested before the current group is
+    // rewritten (JCH_DEFLATE_PF=0 restores the plain loop)
+    v2f64 xn[R][KC];
+    double tn[R], dn_[R];
+    auto fetch = [&](int64_t gg) {
+        const int64_t r0 = gg * R;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            const bool live = row0 + rr < n;
-            const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xr + (size_t)(row0 + rr) * (size_t)ldr) + lane;
+            const bool live = r0 + rr < n;
+            const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xr + (size_t)(r0 + rr) * (size_t)ldr) + lane;
 #pragma unroll
             for (int k = 0; k < KC; ++k)
-                x[rr][k] = (live && in[k]) ? __builtin_nontemporal_load(rp + 64 * k) : v2f64{0.0, 0.0};
+                xn[rr][k] = (live && in[k]) ? __builtin_nontemporal_load(rp + 64 * k) : v2f64{0.0, 0.0};
+            tn[rr] = live ? tcol[r0 + rr] : 0.0;
+            dn_[rr] = live ? dw[r0 + rr] : 0.0;
         }
+    };
+    int64_t g = (int64_t)blockIdx.x * 4 + wv;
+    if (g < ngroups) fetch(g);
+    for (; g < ngroups; g += gstride) {
+        const int64_t row0 = g * R;
+        v2f64 x[R][KC];
+        double tc[R], dc[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            tc[rr] = tn[rr]; dc[rr] = dn_[rr];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) x[rr][k] = xn[rr][k];
+        }
+        if (PF && g + gstride < ngroups) fetch(g + gstride);
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int64_t row = row0 + rr;
             if (row < n) {   // wave-uniform
-                const double t = tcol[row], dv = dw[row];
+                const double t = tc[rr], dv = dc[rr];
                 v2f64 *wp = reinterpret_cast<v2f64 *>(Xr + (size_t)row * (size_t)ldr) + lane;
 #pragma unroll
                 for (int k = 0; k < KC; ++k) {
@@ -175,6 +194,7 @@ __global__ __launch_bounds__(256) void k_deflate_stream(double *__restrict__ Xr,
                 }
             }
         }
+        if (!PF && g + gstride < ngroups) fetch(g + gstride);
     }
     double *prow = part + (size_t)blockIdx.x * ldpart;
 #pragma unroll
@@ -214,18 +234,18 @@ __global__ __launch_bounds__(1024) void k_reduce_kstream(const double *__restric
     }
 }
 
-template <int KC, int R, int Q>
-static int32_t launch_deflate_stream(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, const double *d,
+template <int KC, int R, int Q, bool PF>
+static int32_t launch_deflate_stream_pf(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, const double *d,
                                      const double *tcol, const double *zpc, double *Knext)
 {
     const size_t lds = sizeof(double) * 4 * Q * KC * 128;
     static int bpc = 0;
     if (bpc == 0) {
         int nblk = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_deflate_stream<KC, R, Q>, 256, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_deflate_stream<KC, R, Q, PF>, 256, lds);
         bpc = (e == hipSuccess && nblk > 0) ? nblk : 2;
         if (lds > 64 * 1024)
-            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_deflate_stream<KC, R, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_deflate_stream<KC, R, Q, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int64_t ngroups = (n + R - 1) / R;
     int64_t nb64 = std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * bpc);
@@ -234,7 +254,7 @@ static int32_t launch_deflate_stream(jch_ctx *ctx, double *Xr, int64_t n, int p,
     JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->kpart.ptr;
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL((k_deflate_stream<KC, R, Q>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, Yr, qpad, d, tcol, zpc,
+    hipLaunchKernelGGL((k_deflate_stream<KC, R, Q, PF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, Yr, qpad, d, tcol, zpc,
                        part, ldpart);
     (void)jch_ev(ctx);
     if (Knext) {
@@ -245,6 +265,16 @@ static int32_t launch_deflate_stream(jch_ctx *ctx, double *Xr, int64_t n, int p,
     }
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
+}
+
+template <int KC, int R, int Q>
+static int32_t launch_deflate_stream(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, const double *d,
+                                     const double *tcol, const double *zpc, double *Knext)
+{
+    static int pf = -1;
+    if (pf < 0) { const char *e = getenv("JCH_DEFLATE_PF"); pf = e ? atoi(e) : 1; }
+    if (pf) return launch_deflate_stream_pf<KC, R, Q, true>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
+    return launch_deflate_stream_pf<KC, R, Q, false>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
 }
 
 int32_t jch_launch_deflate(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q,
