@@ -17,3 +17,7 @@ python tools/bench_gridcv.py 2>/dev/null | tail -1 > gpurun_out/final/gridcv.jso
 python tools/bench_accessors.py 2>/dev/null | tail -1 > gpurun_out/final/accessors.json
 python bench.py --algo plskern2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_plskern2.json 2>/dev/null
 ls -la gpurun_out/final
+for a in plssimp plsrosa plswold; do python bench.py --algo $a --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_$a.json 2>/dev/null; done
+python tools/p2p_cost.py 2>/dev/null | tail -1 > gpurun_out/final/p2p_cost.json
+python bench.py --rows 125000 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/final/bench_rank_share_125k.json 2>/dev/null
+ls -la gpurun_out/final
