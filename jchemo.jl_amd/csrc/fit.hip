@@ -199,6 +199,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     // the fast small-state kernel sums the second-stage slices itself; with several GPUs the [slices][ldz] block is
     // all-reduced as one message (still latency-bound at 32 KB) instead of being collapsed by an extra launch
     const int max_slices = fast ? JCH_ZT_SLICES : 1;
+    const bool fuse_inbox = fast && ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
     if ((algo == ALGO_SIMP || algo == ALGO_WOLD) && !jch_sibling_supported(p, q, ldr, nlv))
         return jch_fail(ctx, JCH_EINVAL, "%s: needs q <= 16, p <= %d and the p x q state inside LDS (p=%d q=%d nlv=%d)", who, JCH_SWEEP_MAXP, p, q, nlv);
     int nslice = 1;
@@ -233,14 +234,24 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         if (kern_like) {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;   // rank-independent message size (a small shard may use 1 slice; the rest hold zeros)
-            JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1, nslice, ldz, &nslice));  // ONE collective per LV: [zp (p), tt]
-            if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
-            else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
+            // ONE collective per LV: [zp (p), tt].  With the inbox transport and the fast small-state kernel it happens
+            // INSIDE that kernel (no launch of its own); otherwise here (RCCL / inbox kernel / loopback).
+            if (fuse_inbox && algo != ALGO_SIMP) {
+                JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast, true));
+            } else {
+                JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1, nslice, ldz, &nslice));
+                if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
+                else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
+            }
         } else {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;
-            JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + qpad, nslice, ldz, &nslice));  // [zp_raw, tt, c_raw]
-            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast));
+            if (fuse_inbox) {   // [zp_raw, tt, c_raw] reduced inside the phase-A kernel
+                JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast, true));
+            } else {
+                JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + qpad, nslice, ldz, &nslice));
+                JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast));
+            }
             const bool last = a + 1 == nlv;
             if (!last || inplace) {
                 // X -= t zp', Y -= t c' fused with the next K = X'DY (src/plsnipals.jl:86-87,71; src/plswold.jl:98-99)

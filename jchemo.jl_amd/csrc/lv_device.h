@@ -2,6 +2,7 @@
 // wave-synchronous Jacobi and repeated-squaring eigen-solvers for the q x q Gram matrix, batched LDS dot products.
 #pragma once
 #include "jch_internal.h"
+#include "p2p_dev.h"
 
 #define FT 512   // threads of a single-workgroup small-state kernel
 
@@ -10,6 +11,7 @@ struct lvf_args {
     int p, q, qpad, ldr, a, nlv, algo, do_a, do_b, nslice, ldz, skip, tt_from_r;
     int maxit;    // plswold: inner-iteration cap (src/plswold.jl:89)
     double tol;   // plswold: convergence threshold on ||wx - w0||^2
+    p2p_dev px;   // fused inbox all-reduce of the sweep output (only read by the P2P instantiations)
 };
 
 __device__ __forceinline__ void wavesync()

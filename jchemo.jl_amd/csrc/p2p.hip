@@ -15,76 +15,44 @@
 #include <stdlib.h>
 
 #include "jch_internal.h"
+#include "p2p_dev.h"
 
-#define P2P_HDR_BYTES 4096          // flags [2][16] u64 at 0, status u64 at 256
 #define P2P_NT 1024
 
 struct p2p_args {
-    char *peer[JCH_P2P_MAXR];       // inbox base of every rank as mapped into THIS process (peer[rank] = own)
-    unsigned long long *host_status;
+    p2p_dev t;
     const double *src;              // [nslice][ldz] partial slices (device)
     double *dst;                    // [count] result (may alias src)
-    unsigned long long epoch;
-    long long timeout_ticks;        // wall_clock64 ticks (100 MHz)
-    size_t cap;                     // doubles per (parity, rank) slot
-    int nranks, rank, count, nslice, ldz;
+    int count, nslice, ldz;
 };
-
-__device__ __forceinline__ unsigned long long *p2p_flag(char *base, int par, int r)
-{
-    return reinterpret_cast<unsigned long long *>(base) + par * JCH_P2P_MAXR + r;
-}
-__device__ __forceinline__ double *p2p_slot(char *base, int par, int r, int nranks, size_t cap)
-{
-    return reinterpret_cast<double *>(base + P2P_HDR_BYTES) + ((size_t)par * nranks + r) * cap;
-}
 
 __global__ __launch_bounds__(P2P_NT) void k_p2p_allreduce(p2p_args g)
 {
     __shared__ int bail;
     const int tid = threadIdx.x;
-    const int par = (int)(g.epoch & 1ull);
-    char *mine = g.peer[g.rank];
-    unsigned long long *status = reinterpret_cast<unsigned long long *>(mine + 256);
-    if (tid == 0) bail = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+    const int par = (int)(g.t.epoch & 1ull);
+    char *mine = g.t.peer[g.t.rank];
+    if (tid == 0) bail = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
     __syncthreads();
     if (bail) return;
     // ---- 1. local slice sum, scattered into slot [par][rank] of every inbox
     for (int i = tid; i < g.count; i += P2P_NT) {
         double v = 0.0;
         for (int sl = 0; sl < g.nslice; ++sl) v += g.src[(size_t)sl * g.ldz + i];
-        for (int r = 0; r < g.nranks; ++r) p2p_slot(g.peer[r], par, g.rank, g.nranks, g.cap)[i] = v;
+        for (int r = 0; r < g.t.nranks; ++r) p2p_slot(g.t.peer[r], par, g.t.rank, g.t.nranks, g.t.cap)[i] = v;
     }
     __threadfence_system();
     __syncthreads();
-    if (tid < g.nranks) __hip_atomic_store(p2p_flag(g.peer[tid], par, g.rank), g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // ---- 2. wait for every rank's flag in the own inbox (bounded)
-    if (tid < g.nranks) {
-        unsigned long long *f = p2p_flag(mine, par, tid);
-        const long long t0 = wall_clock64();
-        bool ok = false;
-        for (;;) {
-            ok = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == g.epoch;
-            if (ok || wall_clock64() - t0 > g.timeout_ticks) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (!ok) {
-            __hip_atomic_store(status, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.host_status, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    // ---- 2. publish the epoch, wait for every rank's flag in the own inbox (bounded)
+    p2p_publish_and_wait(g.t, tid);
     __syncthreads();
-    if (tid == 0) bail = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+    if (tid == 0) bail = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
     __syncthreads();
     if (bail) return;
     // ---- 3. ordered sum of the nranks slots (system-scope loads: the slots were written by other devices)
     for (int i = tid; i < g.count; i += P2P_NT) {
         double s = 0.0;
-        for (int r = 0; r < g.nranks; ++r) {
-            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long *>(p2p_slot(mine, par, r, g.nranks, g.cap) + i),
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s += __longlong_as_double((long long)bits);
-        }
+        for (int r = 0; r < g.t.nranks; ++r) s += p2p_load_slot(p2p_slot(mine, par, r, g.t.nranks, g.t.cap) + i);
         g.dst[i] = s;
     }
 }
@@ -115,17 +83,23 @@ extern "C" int32_t jch_ctx_p2p_export(jch_ctx *ctx, int32_t nranks, void *handle
     return JCH_OK;
 }
 
-static int32_t p2p_launch(jch_ctx *ctx, const double *src, int count, int nslice, int ldz, double *dst)
+// fills the device view of the transport for the NEXT all-reduce (advances the epoch)
+void jch_p2p_next(jch_ctx *ctx, p2p_dev *out)
 {
     jch_p2p &t = ctx->p2p;
+    for (int r = 0; r < JCH_P2P_MAXR; ++r) out->peer[r] = r < t.nranks ? (char *)t.peer[r] : nullptr;
+    out->host_status = t.host_status_dev;
+    out->epoch = ++t.epoch;
+    out->timeout_ticks = t.timeout_ticks;
+    out->cap = t.cap;
+    out->nranks = t.nranks; out->rank = t.rank;
+}
+
+static int32_t p2p_launch(jch_ctx *ctx, const double *src, int count, int nslice, int ldz, double *dst)
+{
     p2p_args g;
-    for (int r = 0; r < JCH_P2P_MAXR; ++r) g.peer[r] = r < t.nranks ? (char *)t.peer[r] : nullptr;
-    g.host_status = t.host_status_dev;
-    g.src = src; g.dst = dst;
-    g.epoch = ++t.epoch;
-    g.timeout_ticks = t.timeout_ticks;
-    g.cap = t.cap;
-    g.nranks = t.nranks; g.rank = t.rank; g.count = count; g.nslice = nslice; g.ldz = ldz;
+    jch_p2p_next(ctx, &g.t);
+    g.src = src; g.dst = dst; g.count = count; g.nslice = nslice; g.ldz = ldz;
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(P2P_NT), 0, ctx->stream, g);
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;

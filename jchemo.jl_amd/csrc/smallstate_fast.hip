@@ -22,7 +22,9 @@
 #define JCH_STAMP(k) do { if (g.s.dbg && tid == 0) g.s.dbg[512 + 16 * (g.do_a ? a + 1 : 0) + (k)] = (double)__builtin_readcyclecounter(); } while (0)
 
 
-template <int QP>
+// P2P: the cross-GPU all-reduce of the sweep output is done HERE through the inbox transport (p2p.hip) instead of by a
+// kernel of its own: local slice sums pushed into every rank's inbox, epoch flags, bounded wait, rank-ordered sum.
+template <int QP, bool P2P>
 __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -83,7 +85,42 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     for (int e = tid; e < g.nlv; e += FT) ul[e] = 0.0;           // (prefetched R rows beyond a_old multiply zeros)
     if (rec)
         for (int e = tid; e < a_old * QP; e += FT) Zl[e] = g.s.Z[e];
-    if (g.do_a) {
+    if (P2P && g.do_a) {
+        const int mz = ldr + 1 + (g.algo == 1 ? 16 : 0);
+        const int par = (int)(g.px.epoch & 1ull);
+        char *mine = g.px.peer[g.px.rank];
+        volatile int *bail_s = reinterpret_cast<volatile int *>(scratch);   // (scratch is idle during the staging phase; all of the
+        // 160 KB the kernel may ask for is dynamic LDS, so no static __shared__ here)
+        if (tid == 0) *bail_s = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+        __syncthreads();
+        if (*bail_s) return;
+        __syncthreads();
+        for (int c = tid; c < mz; c += FT) {
+            double s = 0.0;
+            if (g.nslice == 1) s = g.s.zt[c];
+            else {
+                double z[JCH_ZT_SLICES];
+#pragma unroll
+                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) z[sl] = g.s.zt[(size_t)sl * g.ldz + c];
+#pragma unroll
+                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) s += z[sl];
+            }
+            for (int r = 0; r < g.px.nranks; ++r) p2p_slot(g.px.peer[r], par, g.px.rank, g.px.nranks, g.px.cap)[c] = s;
+        }
+        __threadfence_system();
+        __syncthreads();
+        p2p_publish_and_wait(g.px, tid);
+        __syncthreads();
+        if (tid == 0) *bail_s = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+        __syncthreads();
+        if (*bail_s) return;
+        for (int c = tid; c < mz; c += FT) {
+            double s = 0.0;
+            for (int r = 0; r < g.px.nranks; ++r) s += p2p_load_slot(p2p_slot(mine, par, r, g.px.nranks, g.px.cap) + c);
+            ztl[c] = s;
+        }
+        for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
+    } else if (g.do_a) {
         const int mz = ldr + 1 + (g.algo == 1 ? 16 : 0);
         for (int c = tid; c < mz; c += FT) {
             double s;
@@ -347,27 +384,34 @@ size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv)
 }
 
 int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
-                                  int do_a, int do_b, int nslice, int ldz)
+                                  int do_a, int do_b, int nslice, int ldz, bool fuse_p2p)
 {
     if (qpad != 16) return jch_fail(ctx, JCH_EINVAL, "internal: fast small-state kernel needs q <= 16");
     lvf_args g;
     g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.a = a; g.nlv = nlv; g.algo = algo;
     g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz; g.skip = 0; g.tt_from_r = s.variant == 1; g.maxit = 0; g.tol = 0.0;
+    g.px = p2p_dev{};
+    const bool fuse = fuse_p2p && do_a;
+    if (fuse) jch_p2p_next(ctx, &g.px);
     const size_t lds = jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv);
     static bool attr_set = false;
     if (!attr_set) {
-        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define JCH_ATTR(QP) do { \
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<QP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<QP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); } while (0)
+        JCH_ATTR(1); JCH_ATTR(2); JCH_ATTR(4); JCH_ATTR(8); JCH_ATTR(16);
+#undef JCH_ATTR
         attr_set = true;
     }
-    if (q <= 1) hipLaunchKernelGGL(k_lv_update_fast<1>, dim3(1), dim3(FT), lds, ctx->stream, g);
-    else if (q <= 2) hipLaunchKernelGGL(k_lv_update_fast<2>, dim3(1), dim3(FT), lds, ctx->stream, g);
-    else if (q <= 4) hipLaunchKernelGGL(k_lv_update_fast<4>, dim3(1), dim3(FT), lds, ctx->stream, g);
-    else if (q <= 8) hipLaunchKernelGGL(k_lv_update_fast<8>, dim3(1), dim3(FT), lds, ctx->stream, g);
-    else hipLaunchKernelGGL(k_lv_update_fast<16>, dim3(1), dim3(FT), lds, ctx->stream, g);
+#define JCH_LVF(QP) do { \
+        if (fuse) hipLaunchKernelGGL((k_lv_update_fast<QP, true>), dim3(1), dim3(FT), lds, ctx->stream, g); \
+        else hipLaunchKernelGGL((k_lv_update_fast<QP, false>), dim3(1), dim3(FT), lds, ctx->stream, g); } while (0)
+    if (q <= 1) JCH_LVF(1);
+    else if (q <= 2) JCH_LVF(2);
+    else if (q <= 4) JCH_LVF(4);
+    else if (q <= 8) JCH_LVF(8);
+    else JCH_LVF(16);
+#undef JCH_LVF
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }
