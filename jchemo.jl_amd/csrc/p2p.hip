@@ -129,7 +129,7 @@ extern "C" int32_t jch_ctx_p2p_import(jch_ctx *ctx, const void *handles, int32_t
         t.opened[r] = true;
     }
     JCH_HIP(ctx, hipHostGetDevicePointer((void **)&t.host_status_dev, t.host_status, 0));
-    double ms = 2000.0;
+    double ms = 10000.0;   // generous: a spurious timeout would abort a fit; a lost peer still cannot hang the GPU
     if (const char *e = getenv("JCH_P2P_TIMEOUT_MS")) ms = atof(e);
     t.timeout_ticks = (long long)(ms * 1e5);   // wall_clock64 runs at 100 MHz
     if (!ctx->comm) { ctx->rank = rank; ctx->nranks = nranks; }
