@@ -658,10 +658,18 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         else JCH_SWB(4, 2);
 #undef JCH_SWB
         if (ctx->nranks > 1) nslice = JCH_ZT_SLICES;                      // rank-independent message size (unused slices hold zeros)
-        JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));   // ONE collective per LV: [zp_raw, tt, st]
-        hipLaunchKernelGGL(k_bf16_fix_zt, dim3((ldr_small + 255) / 256), dim3(256), 0, ctx->stream, zt8, nslice, ldzb, ldr_b, p, ldr_small,
-                           s.mom, s.scl, s.zt);
-        JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, 1, ldz, fast));
+        // ONE collective per LV: [zp_raw, tt, st].  Fast small-state kernel: it adds the slices, (with the inbox transport)
+        // all-reduces them and applies the centring / scaling fix-up itself; generic kernel: separate steps.
+        if (fast) {
+            const bool fuse = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
+            if (!fuse) JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));
+            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, nslice, ldz, true, fuse, zt8, ldzb, ldr_b));
+        } else {
+            JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));
+            hipLaunchKernelGGL(k_bf16_fix_zt, dim3((ldr_small + 255) / 256), dim3(256), 0, ctx->stream, zt8, nslice, ldzb, ldr_b, p, ldr_small,
+                               s.mom, s.scl, s.zt);
+            JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, 1, ldz, false));
+        }
     }
     JCH_HIP(ctx, hipGetLastError());
     *nlv_out = nlv;

@@ -12,6 +12,8 @@ struct lvf_args {
     int maxit;    // plswold: inner-iteration cap (src/plswold.jl:89)
     double tol;   // plswold: convergence threshold on ||wx - w0||^2
     p2p_dev px;   // fused inbox all-reduce of the sweep output (only read by the P2P instantiations)
+    const double *bf_src;   // bf16 storage mode: raw slices [nslice][bf_ld] of [zp_raw (bf_ldr), tt, st]; null otherwise
+    int bf_ld, bf_ldr;
 };
 
 __device__ __forceinline__ void wavesync()

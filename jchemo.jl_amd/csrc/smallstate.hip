@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
 }
 
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
-                             int nslice, int ldz, bool fast, bool fuse_p2p)
+                             int nslice, int ldz, bool fast, bool fuse_p2p, const double *bf_src, int bf_ld, int bf_ldr)
 {
     // a encodes the phase:  a == -1           -> phase B only (first w, r)
     //                       a >= 0, a < nlv   -> phase A for LV a, then phase B unless it was the last LV
@@ -259,8 +259,8 @@ int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int
     else if (flags & 0x40000000) { g.a = aa; g.do_a = 1; g.do_b = 0; }
     else if (flags & 0x20000000) { g.a = aa; g.do_a = 0; g.do_b = 1; }
     else { g.a = aa; g.do_a = 1; g.do_b = (aa + 1 < nlv) ? 1 : 0; }
-    if (fast) return jch_launch_lv_update_fast(ctx, s, p, q, qpad, ldr, g.a, nlv, algo, g.do_a, g.do_b, nslice, ldz, fuse_p2p);
-    if (fuse_p2p) return jch_fail(ctx, JCH_EINVAL, "internal: the fused inbox all-reduce needs the fast small-state kernel");
+    if (fast) return jch_launch_lv_update_fast(ctx, s, p, q, qpad, ldr, g.a, nlv, algo, g.do_a, g.do_b, nslice, ldz, fuse_p2p, bf_src, bf_ld, bf_ldr);
+    if (fuse_p2p || bf_src) return jch_fail(ctx, JCH_EINVAL, "internal: the fused inbox all-reduce / bf16 fix-up need the fast small-state kernel");
     if (nslice != 1) return jch_fail(ctx, JCH_EINVAL, "internal: generic small-state kernel needs a single zt slice");
     if (nlv > 256) return jch_fail(ctx, JCH_EINVAL, "nlv > 256 not supported");
     const int lda = q + 1;

@@ -85,8 +85,12 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     for (int e = tid; e < g.nlv; e += FT) ul[e] = 0.0;           // (prefetched R rows beyond a_old multiply zeros)
     if (rec)
         for (int e = tid; e < a_old * QP; e += FT) Zl[e] = g.s.Z[e];
+    // sweep output to reduce: f64 path: s.zt [nslice][ldz], first mz entries; bf16 storage mode (g.bf_src): the raw
+    // [zp_raw (bf_ldr), tt, st] slices, turned into [zp, tt] below (zp_j = (zp_raw_j - m_j st) / s_j, bf16.hip header)
+    const double *zsrc = g.bf_src ? g.bf_src : g.s.zt;
+    const int zld = g.bf_src ? g.bf_ld : g.ldz;
+    const int mz = g.bf_src ? g.bf_ldr + 2 : ldr + 1 + (g.algo == 1 ? 16 : 0);
     if (P2P && g.do_a) {
-        const int mz = ldr + 1 + (g.algo == 1 ? 16 : 0);
         const int par = (int)(g.px.epoch & 1ull);
         char *mine = g.px.peer[g.px.rank];
         volatile int *bail_s = reinterpret_cast<volatile int *>(scratch);   // (scratch is idle during the staging phase; all of the
@@ -97,11 +101,11 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         __syncthreads();
         for (int c = tid; c < mz; c += FT) {
             double s = 0.0;
-            if (g.nslice == 1) s = g.s.zt[c];
+            if (g.nslice == 1) s = zsrc[c];
             else {
                 double z[JCH_ZT_SLICES];
 #pragma unroll
-                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) z[sl] = g.s.zt[(size_t)sl * g.ldz + c];
+                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) z[sl] = zsrc[(size_t)sl * zld + c];
 #pragma unroll
                 for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) s += z[sl];
             }
@@ -121,15 +125,14 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         }
         for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
     } else if (g.do_a) {
-        const int mz = ldr + 1 + (g.algo == 1 ? 16 : 0);
         for (int c = tid; c < mz; c += FT) {
             double s;
             if (g.nslice == 1) {
-                s = g.s.zt[c];
+                s = zsrc[c];
             } else {   // all JCH_ZT_SLICES slices are written by k_reduce_part (unused ones hold zeros)
                 double z[JCH_ZT_SLICES];
 #pragma unroll
-                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) z[sl] = g.s.zt[(size_t)sl * g.ldz + c];
+                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) z[sl] = zsrc[(size_t)sl * zld + c];
                 s = 0.0;
 #pragma unroll
                 for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) s += z[sl];
@@ -137,6 +140,13 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             ztl[c] = s;
         }
         for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
+    }
+    if (g.do_a && g.bf_src) {   // (each thread rewrites only the entries it reads; slot ldr is outside every j < ldr)
+        __syncthreads();
+        const double tt_ = ztl[g.bf_ldr], st_ = ztl[g.bf_ldr + 1];
+        __syncthreads();
+        for (int j = tid; j < ldr; j += FT) ztl[j] = j < p ? (ztl[j] - g.s.mom[j] * st_) / g.s.scl[j] : 0.0;
+        if (tid == 0) ztl[ldr] = tt_;
     }
     __syncthreads();
     JCH_STAMP(1);
@@ -384,13 +394,14 @@ size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv)
 }
 
 int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
-                                  int do_a, int do_b, int nslice, int ldz, bool fuse_p2p)
+                                  int do_a, int do_b, int nslice, int ldz, bool fuse_p2p, const double *bf_src, int bf_ld, int bf_ldr)
 {
     if (qpad != 16) return jch_fail(ctx, JCH_EINVAL, "internal: fast small-state kernel needs q <= 16");
     lvf_args g;
     g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.a = a; g.nlv = nlv; g.algo = algo;
     g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz; g.skip = 0; g.tt_from_r = s.variant == 1; g.maxit = 0; g.tol = 0.0;
     g.px = p2p_dev{};
+    g.bf_src = bf_src; g.bf_ld = bf_ld; g.bf_ldr = bf_ldr;
     const bool fuse = fuse_p2p && do_a;
     if (fuse) jch_p2p_next(ctx, &g.px);
     const size_t lds = jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv);
