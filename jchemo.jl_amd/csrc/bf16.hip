@@ -566,12 +566,14 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
 {
     const size_t lds = sizeof(double) * (4 * KC * 512 + 8);
     static int bpc = 0;
-    if (bpc == 0) {
+    static jch_per_device_once occ_once;
+    if (!occ_once.done(ctx->device)) {
         int nblk = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_bf16<KC, R, PF>, 256, lds);
         bpc = (e == hipSuccess && nblk > 0) ? nblk : 2;
         if (lds > 64 * 1024)
             JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_bf16<KC, R, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        occ_once.mark(ctx->device);
     }
     const int64_t ngroups = (n + R - 1) / R;
     static int bpc_env = -1;

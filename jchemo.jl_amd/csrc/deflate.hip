@@ -240,12 +240,14 @@ static int32_t launch_deflate_stream_pf(jch_ctx *ctx, double *Xr, int64_t n, int
 {
     const size_t lds = sizeof(double) * 4 * Q * KC * 128;
     static int bpc = 0;
-    if (bpc == 0) {
+    static jch_per_device_once occ_once;
+    if (!occ_once.done(ctx->device)) {
         int nblk = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_deflate_stream<KC, R, Q, PF>, 256, lds);
         bpc = (e == hipSuccess && nblk > 0) ? nblk : 2;
         if (lds > 64 * 1024)
             JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_deflate_stream<KC, R, Q, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        occ_once.mark(ctx->device);
     }
     const int64_t ngroups = (n + R - 1) / R;
     int64_t nb64 = std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * bpc);

@@ -70,6 +70,14 @@ struct jch_ctx {
     int sweep_blocks_per_cu = 0;
 };
 
+// One-time initialisation per (call site, device): hipFuncSetAttribute and occupancy queries are per device, and a
+// process may hold ctxs on several GPUs.  The flag is raised AFTER the initialisation (two threads may both run it: benign).
+struct jch_per_device_once {
+    unsigned long long mask = 0;
+    bool done(int dev) const { return (mask >> (dev & 63)) & 1ull; }
+    void mark(int dev) { mask |= 1ull << (dev & 63); }
+};
+
 // ---- error plumbing --------------------------------------------------------------------------------
 int32_t jch_fail(jch_ctx *ctx, int32_t code, const char *fmt, ...);
 #define JCH_HIP(ctx, expr)                                                                         \

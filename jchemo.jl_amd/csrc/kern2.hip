@@ -197,8 +197,8 @@ int32_t jch_launch_syrk(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ld
     JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nsplit * npairs * 128 * 128));   // (free after the prologue)
     double *Gpart = (double *)ctx->kpart.ptr;
     const size_t lds = sizeof(double) * 2 * SY_KB * SY_LD;
-    static bool attr = false;
-    if (!attr) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    static jch_per_device_once attr;
+    if (!attr.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.mark(ctx->device); }
     (void)jch_ev(ctx);
     hipLaunchKernelGGL(k_syrk, dim3(nsplit, npairs), dim3(256), lds, ctx->stream, Xr, n, p, ldr, d, Gpart, nsplit, nblk);
     (void)jch_ev(ctx);

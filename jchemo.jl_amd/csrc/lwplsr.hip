@@ -347,10 +347,10 @@ template <int KC>
 static int32_t launch_locw(jch_ctx *ctx, locw_args &g)
 {
     const size_t lds = sizeof(double) * (2 * (size_t)g.k + 6 * (size_t)g.ldr + 4 * KC * 128 + 128) + sizeof(int) * (size_t)g.k + 64;
-    static bool attr = false;
-    if (!attr) {
+    static jch_per_device_once attr;
+    if (!attr.done(ctx->device)) {
         JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_locw_plskern<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        attr.mark(ctx->device);
     }
     if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k / p too large for the batched local-PLS kernel");
     int nb = std::min(g.m, ctx->cus * 2);
@@ -415,8 +415,8 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         a.h = h; a.cri = 4.0; a.tol = tol; a.ind = dind; a.dist = ddist; a.w = dw;
         const size_t lds = (sizeof(double) + sizeof(int)) * KNN_QB * KNN_CAP + sizeof(double) * (KNN_QB * (size_t)dd + KNN_QB) + sizeof(int) * KNN_QB + 64;
         if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: score dimension %lld too large", (long long)dd);
-        static bool attr = false;
-        if (!attr) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_weights, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        static jch_per_device_once attr;
+        if (!attr.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_weights, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.mark(ctx->device); }
         hipLaunchKernelGGL(k_knn_weights, dim3((unsigned)((m + KNN_QB - 1) / KNN_QB)), dim3(256), lds, ctx->stream, a);
     }
     {

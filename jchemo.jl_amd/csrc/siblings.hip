@@ -399,12 +399,12 @@ int32_t jch_launch_lv_update_simp(jch_ctx *ctx, const jch_small &s, int p, int q
     if (a < 0) { g.a = 0; g.do_a = 0; g.do_b = 1; }
     else { g.a = a; g.do_a = 1; g.do_b = a + 1 < nlv ? 1 : 0; }
     const size_t lds = sib_lds_bytes(p, q, ldr, nlv);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static jch_per_device_once attr_once;
+    if (!attr_once.done(ctx->device)) {
         JCH_TRY(set_lds_attr(ctx, k_lv_update_simp<1>)); JCH_TRY(set_lds_attr(ctx, k_lv_update_simp<2>));
         JCH_TRY(set_lds_attr(ctx, k_lv_update_simp<4>)); JCH_TRY(set_lds_attr(ctx, k_lv_update_simp<8>));
         JCH_TRY(set_lds_attr(ctx, k_lv_update_simp<16>));
-        attr_set = true;
+        attr_once.mark(ctx->device);
     }
     if (q <= 1) hipLaunchKernelGGL(k_lv_update_simp<1>, dim3(1), dim3(FT), lds, ctx->stream, g);
     else if (q <= 2) hipLaunchKernelGGL(k_lv_update_simp<2>, dim3(1), dim3(FT), lds, ctx->stream, g);
@@ -421,11 +421,11 @@ int32_t jch_launch_wold_b(jch_ctx *ctx, const jch_small &s, int p, int q, int ld
     g.s = s; g.p = p; g.q = q; g.qpad = 16; g.ldr = ldr; g.nlv = nlv; g.algo = 4; g.a = a; g.do_b = 1;
     g.tol = tol; g.maxit = maxit < 1 ? 1 : maxit;
     const size_t lds = sib_lds_bytes(p, q, ldr, nlv);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static jch_per_device_once attr_once;
+    if (!attr_once.done(ctx->device)) {
         JCH_TRY(set_lds_attr(ctx, k_wold_b<1>)); JCH_TRY(set_lds_attr(ctx, k_wold_b<2>)); JCH_TRY(set_lds_attr(ctx, k_wold_b<4>));
         JCH_TRY(set_lds_attr(ctx, k_wold_b<8>)); JCH_TRY(set_lds_attr(ctx, k_wold_b<16>));
-        attr_set = true;
+        attr_once.mark(ctx->device);
     }
     if (q <= 1) hipLaunchKernelGGL(k_wold_b<1>, dim3(1), dim3(FT), lds, ctx->stream, g);
     else if (q <= 2) hipLaunchKernelGGL(k_wold_b<2>, dim3(1), dim3(FT), lds, ctx->stream, g);

@@ -405,14 +405,14 @@ int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q
     const bool fuse = fuse_p2p && do_a;
     if (fuse) jch_p2p_next(ctx, &g.px);
     const size_t lds = jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static jch_per_device_once attr_once;
+    if (!attr_once.done(ctx->device)) {
 #define JCH_ATTR(QP) do { \
         JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<QP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update_fast<QP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); } while (0)
         JCH_ATTR(1); JCH_ATTR(2); JCH_ATTR(4); JCH_ATTR(8); JCH_ATTR(16);
 #undef JCH_ATTR
-        attr_set = true;
+        attr_once.mark(ctx->device);
     }
 #define JCH_LVF(QP) do { \
         if (fuse) hipLaunchKernelGGL((k_lv_update_fast<QP, true>), dim3(1), dim3(FT), lds, ctx->stream, g); \

@@ -100,8 +100,8 @@ int32_t jch_launch_sweep_wide(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     const int ldp1 = 72, ldp2 = 2048;
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldp2));
     double *part = (double *)ctx->part.ptr;
-    static bool attr = false;
-    if (!attr) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_colacc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    static jch_per_device_once attr;
+    if (!attr.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_colacc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.mark(ctx->device); }
     (void)jch_ev(ctx);
     if (nipals) hipLaunchKernelGGL(k_rowdot<true>, dim3(nb), dim3(256), 0, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad, tcol, part, ldp1);
     else hipLaunchKernelGGL(k_rowdot<false>, dim3(nb), dim3(256), 0, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad, tcol, part, ldp1);
