@@ -197,13 +197,14 @@ JCH_API int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int6
  * jch_lwplsr_predict — the prediction path of kNN-LWPLSR, batched over the m queries: replaces getknn
  * (src/getknn.jl:29-57), the wdist weight loop (src/lwplsr.jl:152-159, src/wdist.jl:64-75) and locwlv
  * (src/locwlv.jl:9-48, `Threads.@threads` over queries: one weighted plskern + 1-row predict per query).
- *   Xtrain n x p, Ytrain n x 1, Xq m x p                                   [loc], column-major
+ *   Xtrain n x p, Ytrain n x q, Xq m x p                                   [loc], column-major
  *   Ztrain n x dd, Zq m x dd: the space the neighbours are searched in (global PLS scores, already whitened by
  *     the host side for metric = "mahal": scores * inv(chol(cov).U), src/getknn.jl:37-49)      [loc]
  *   k neighbours (clamped to n), h / tol: weight shape and floor; scal; nlv range nlv_lo..nlv_hi (contiguous)
- *   pred  m x (nlv_hi - nlv_lo + 1), ROW-major per query: pred[i*le + a]                          [HOST]
+ *   pred  m x le x q (le = nlv_hi - nlv_lo + 1), query-major: pred[(i*le + a)*q + y]              [HOST]
  *   ind_out (m x k, 0-based, row-major), dist_out, w_out (m x k): optional                       [HOST]
- * q == 1 only in the batched kernel (other q: the host mirror loops jch_plskern_fit per query).
+ * 1 <= q <= 8 (one workgroup per query holds the k x p slab, the p x q kernel matrix and its q x q eigen-solver);
+ * the constant-y shortcut of src/locwlv.jl:25-28 applies to q == 1 only, as in the reference.
  */
 JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
                                    const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt,

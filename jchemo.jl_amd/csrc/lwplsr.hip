@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "jch_internal.h"
+#include "lv_device.h"
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
@@ -173,61 +174,96 @@ __global__ __launch_bounds__(256) void k_knn_weights(knn_args g)
     }
 }
 
-// ---------------------------------------------------------------- K8: batched local weighted plskern (q == 1)
+// ---------------------------------------------------------------- K8: batched local weighted plskern (q <= 8)
 struct locw_args {
     const double *Xrm; int ldr; int p;      // row-major training X (uncentred)
-    const double *Y; int64_t ldy;           // training y (column-major n x 1)
+    const double *Y; int64_t ldy; int q;    // training Y (column-major n x q)
     const double *Xq; int64_t ldxq; int m;  // queries, column-major m x p
     const int *ind; const double *w; int k; // neighbours / weights [m][k]
     int scal, nlv_lo, nlv_hi;
     double *scratch; size_t slab;           // per-block slab: Xg [k][ldr], P [nlv][ldr], R [nlv][ldr]
-    double *pred;                           // [m][le]  (q == 1), le = nlv_hi - nlv_lo + 1
+    double *pred;                           // [m][le][q], le = nlv_hi - nlv_lo + 1
 };
 
-template <int KC>
+// block sum of NV values held one per thread-array slot: wave shuffles, then the 4 wave partials through LDS.
+// out[v] valid in every thread after the call.  scratch: >= 4 * NV doubles.
+template <int NV>
+__device__ __forceinline__ void locw_block_sums(double (&v)[NV], double *scratch)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = jch_wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[wv * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ((scratch[i] + scratch[NV + i]) + scratch[2 * NV + i]) + scratch[3 * NV + i];
+}
+
+// Q = number of responses padded to {1, 2, 4, 8}; the actual q = g.q <= Q (pad responses are all-zero columns).
+template <int KC, int Q>
 __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p = g.p, ldr = g.ldr, k = g.k;
-    double *dl = lds;                 // [k]   normalised weights
-    double *yc = dl + k;              // [k]   centred/scaled y
-    double *mu = yc + k;              // [ldr] local means
-    double *sg = mu + ldr;            // [ldr] local scales
-    double *Kv = sg + ldr;            // [ldr] kernel vector X'Dy (q = 1)
-    double *wv_ = Kv + ldr;           // [ldr] w
+    const int p = g.p, ldr = g.ldr, k = g.k, q = g.q;
+    constexpr int lda = Q + 2;
+    double *dl = lds;                 // [k]      normalised weights
+    double *yc = dl + k;              // [k][Q]   centred/scaled Y rows of the neighbours
+    double *mu = yc + (size_t)k * Q;  // [ldr]    local means
+    double *sg = mu + ldr;            // [ldr]    local scales
+    double *Kv = sg + ldr;            // [Q][ldr] kernel matrix X'DY, one row per response
+    double *wv_ = Kv + (size_t)Q * ldr;  // [ldr] w
     double *rv = wv_ + ldr;           // [ldr] r
     double *xq = rv + ldr;            // [ldr] centred/scaled query
     double *zred = xq + ldr;          // [4][KC*128]
     double *sc = zred + 4 * KC * 128; // [128] scratch scalars; dots w.P_l at sc[64 + l]
-    int *idx = reinterpret_cast<int *>(sc + 128);  // [k]
+    double *ys = sc + 128;            // [4 Q]: ymean, ysd, c, running prediction
+    double *vl = ys + 4 * Q;          // [16]   dominant right singular vector
+    double *G0 = vl + 16;             // 5 x [Q][lda] Gram / eigen-solver work + csl [2 (Q + 2) + 8]
+    double *A0 = G0 + Q * lda, *A1 = A0 + Q * lda, *V0 = A1 + Q * lda, *V1 = V0 + Q * lda, *csl = V1 + Q * lda;
+    double *red = csl + 2 * (Q + 2) + 8;   // [4 * max(Q (Q + 1) / 2, Q + 1)]
+    int *idx = reinterpret_cast<int *>(red + 4 * (Q * (Q + 1) / 2 + Q + 1));  // [k]
     double *Xg = g.scratch + (size_t)blockIdx.x * g.slab;
     double *Pm = Xg + (size_t)k * ldr;
     double *Rm = Pm + (size_t)g.nlv_hi * ldr;
     const int le = g.nlv_hi - g.nlv_lo + 1;
     const int nlvloc = min(min(k, p), g.nlv_hi);
+    double *ymean = ys, *ysd = ys + Q, *prun = ys + 3 * Q;
 
     for (int qi = blockIdx.x; qi < g.m; qi += gridDim.x) {
         __syncthreads();
-        // ---- weights (mweight), neighbour ids, y
+        // ---- weights (mweight), neighbour ids, Y rows
         double s = 0.0;
         for (int e = tid; e < k; e += 256) { idx[e] = g.ind[(size_t)qi * k + e]; s += g.w[(size_t)qi * k + e]; }
         const double sw = jch_block_sum<256>(s, sc);
-        double sy = 0.0, ymin = __builtin_inf(), ymax = -__builtin_inf();
+        double sy[Q];
+#pragma unroll
+        for (int y = 0; y < Q; ++y) sy[y] = 0.0;
+        double ymin = __builtin_inf(), ymax = -__builtin_inf();
         for (int e = tid; e < k; e += 256) {
-            const double d = g.w[(size_t)qi * k + e] / sw, y = g.Y[idx[e]];
-            dl[e] = d; yc[e] = y; sy += d * y;
-            ymin = fmin(ymin, y); ymax = fmax(ymax, y);
+            const double d = g.w[(size_t)qi * k + e] / sw;
+            dl[e] = d;
+#pragma unroll
+            for (int y = 0; y < Q; ++y) {
+                const double yv = y < q ? g.Y[(size_t)idx[e] + (size_t)y * (size_t)g.ldy] : 0.0;
+                yc[(size_t)e * Q + y] = yv;
+                sy[y] += d * yv;
+                if (y == 0) { ymin = fmin(ymin, yv); ymax = fmax(ymax, yv); }
+            }
         }
-        const double ymean = jch_block_sum<256>(sy, sc);
-        // constant-y shortcut (src/locwlv.jl:25-28)
+        locw_block_sums<Q>(sy, red);
+        if (tid < Q) ymean[tid] = sy[tid];
+        // constant-y shortcut, univariate y only (src/locwlv.jl:25-28)
         __syncthreads();
         for (int o = 32; o > 0; o >>= 1) { ymin = fmin(ymin, __shfl_xor(ymin, o, 64)); ymax = fmax(ymax, __shfl_xor(ymax, o, 64)); }
         if (lane == 0) { sc[8 + wv] = ymin; sc[12 + wv] = ymax; }
         __syncthreads();
         const double gmin = fmin(fmin(sc[8], sc[9]), fmin(sc[10], sc[11])), gmax = fmax(fmax(sc[12], sc[13]), fmax(sc[14], sc[15]));
         __syncthreads();
-        if (gmin == gmax) {
+        if (q == 1 && gmin == gmax) {
             for (int a = tid; a < le; a += 256) g.pred[(size_t)qi * le + a] = gmin;
             continue;
         }
@@ -244,15 +280,25 @@ __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
             }
             mu[j] = m1; sg[j] = sd;
         }
-        double ysd = 1.0;
-        if (g.scal) {
-            double v = 0.0;
-            for (int e = tid; e < k; e += 256) { const double z = yc[e] - ymean; v += dl[e] * z * z; }
-            ysd = sqrt(jch_block_sum<256>(v, sc));
+        {
+            double vv[Q];
+#pragma unroll
+            for (int y = 0; y < Q; ++y) vv[y] = 0.0;
+            if (g.scal)
+                for (int e = tid; e < k; e += 256)
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) { const double z = yc[(size_t)e * Q + y] - ymean[y]; vv[y] += dl[e] * z * z; }
+            locw_block_sums<Q>(vv, red);
+            if (tid < Q) ysd[tid] = (g.scal && tid < q) ? sqrt(vv[tid]) : 1.0;
         }
         __syncthreads();
-        for (int e = tid; e < k; e += 256) yc[e] = g.scal ? (yc[e] - ymean) / ysd : yc[e] - ymean;
-        // ---- gather + centre/scale into the slab; centred query; K = X' D y
+        for (int e = tid; e < k; e += 256)
+#pragma unroll
+            for (int y = 0; y < Q; ++y) {
+                const double z = yc[(size_t)e * Q + y] - ymean[y];
+                yc[(size_t)e * Q + y] = y < q ? (g.scal ? z / ysd[y] : z) : 0.0;
+            }
+        // ---- gather + centre/scale into the slab; centred query; K = X' D Y
         for (int e = wv; e < k; e += 4) {
             const double *src = g.Xrm + (size_t)idx[e] * ldr;
             double *dst = Xg + (size_t)e * ldr;
@@ -263,20 +309,73 @@ __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
                                     : g.Xq[(size_t)qi + (size_t)j * (size_t)g.ldxq] - mu[j]) : 0.0;
         __syncthreads();
         for (int j = tid; j < ldr; j += 256) {
-            double s2 = 0.0;
+            double s2[Q];
+#pragma unroll
+            for (int y = 0; y < Q; ++y) s2[y] = 0.0;
             if (j < p)
-                for (int e = 0; e < k; ++e) s2 += (dl[e] * yc[e]) * Xg[(size_t)e * ldr + j];
-            Kv[j] = s2;
+                for (int e = 0; e < k; ++e) {
+                    const double xv = dl[e] * Xg[(size_t)e * ldr + j];
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) s2[y] += xv * yc[(size_t)e * Q + y];
+                }
+#pragma unroll
+            for (int y = 0; y < Q; ++y) Kv[(size_t)y * ldr + j] = s2[y];
         }
+        if (tid < Q) prun[tid] = ymean[tid];   // nlv = 0: the intercept alone (src/plskern.jl:207-217 with B = 0)
         __syncthreads();
-        double predrun = ymean;   // nlv = 0: the intercept alone (src/plskern.jl:207-217 with B = 0)
-        if (tid == 0 && g.nlv_lo == 0) g.pred[(size_t)qi * le] = predrun;
-        // ---- LV loop (src/plskern.jl:149-175 with q == 1)
+        if (tid < q && g.nlv_lo == 0) g.pred[((size_t)qi * le) * q + tid] = prun[tid];
+        // ---- LV loop (src/plskern.jl:149-175)
         for (int a = 0; a < nlvloc; ++a) {
+            // w = dominant left singular vector of K: q == 1 the normalised column (:150-152), else K v / ||K v|| with v the
+            // dominant eigenvector of K'K (Gram + repeated squaring / Jacobi in wave 0, same solver and sign rule as the
+            // global fit: lv_device.h)
+            if constexpr (Q > 1) {
+                constexpr int NE = Q * (Q + 1) / 2;
+                double ge[NE];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) ge[e] = 0.0;
+                for (int j = tid; j < p; j += 256) {
+                    double kr[Q];
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) kr[y] = Kv[(size_t)y * ldr + j];
+                    int e = 0;
+#pragma unroll
+                    for (int y1 = 0; y1 < Q; ++y1)
+#pragma unroll
+                        for (int y2 = y1; y2 < Q; ++y2) ge[e++] += kr[y1] * kr[y2];
+                }
+                locw_block_sums<NE>(ge, red);
+                for (int e = tid; e < 5 * Q * lda; e += 256) G0[e] = 0.0;
+                __syncthreads();
+                if (tid == 0) {
+                    int e = 0;
+                    for (int y1 = 0; y1 < Q; ++y1)
+                        for (int y2 = y1; y2 < Q; ++y2) { G0[y1 * lda + y2] = ge[e]; G0[y2 * lda + y1] = ge[e]; ++e; }
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    if (!dominant_by_squaring<Q>(q, lda, G0, A0, A1, vl, nullptr)) {
+                        for (int e = lane; e < Q * lda; e += 64) A0[e] = G0[e];
+                        wavesync();
+                        jacobi_wave(q, lda, A0, A1, V0, V1, csl, vl, nullptr);
+                    }
+                }
+                __syncthreads();
+            }
             double s2 = 0.0;
-            for (int j = tid; j < p; j += 256) s2 += Kv[j] * Kv[j];
+            for (int j = tid; j < ldr; j += 256) {
+                double wj = 0.0;
+                if (j < p) {
+                    if (Q == 1) wj = Kv[j];
+                    else
+#pragma unroll
+                        for (int y = 0; y < Q; ++y) wj += Kv[(size_t)y * ldr + j] * vl[y];
+                }
+                wv_[j] = wj;
+                s2 += wj * wj;
+            }
             const double nrm = sqrt(jch_block_sum<256>(s2, sc));
-            for (int j = tid; j < ldr; j += 256) wv_[j] = j < p ? Kv[j] / nrm : 0.0;
+            for (int j = tid; j < ldr; j += 256) wv_[j] = wv_[j] / nrm;   // (own entries only)
             __syncthreads();
             for (int l = wv; l < a; l += 4) {   // dots w . P_l
                 double s3 = 0.0;
@@ -320,46 +419,68 @@ __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
             if (lane == 0) sc[wv] = tt;
             __syncthreads();
             const double ttot = ((sc[0] + sc[1]) + sc[2]) + sc[3];
-            // c = K'r / tt ; tq = xq . r
-            double s5 = 0.0, s6 = 0.0;
-            for (int j = tid; j < p; j += 256) { s5 += Kv[j] * rv[j]; s6 += xq[j] * rv[j]; }
-            __syncthreads();
-            const double cc = jch_block_sum<256>(s5, sc) / ttot;
-            const double tq = jch_block_sum<256>(s6, sc + 32);
+            // c = K'r / tt (one entry per response) ; tq = xq . r
+            double cs[Q + 1];
+#pragma unroll
+            for (int y = 0; y <= Q; ++y) cs[y] = 0.0;
+            for (int j = tid; j < p; j += 256) {
+                const double rj = rv[j];
+#pragma unroll
+                for (int y = 0; y < Q; ++y) cs[y] += Kv[(size_t)y * ldr + j] * rj;
+                cs[Q] += xq[j] * rj;
+            }
+            locw_block_sums<Q + 1>(cs, red);
+            const double tq = cs[Q];
             for (int j = tid; j < ldr; j += 256) {
                 const double z = ((zred[j] + zred[KC * 128 + j]) + zred[2 * KC * 128 + j]) + zred[3 * KC * 128 + j];
-                Kv[j] -= z * cc;
+#pragma unroll
+                for (int y = 0; y < Q; ++y) Kv[(size_t)y * ldr + j] -= z * (cs[y] / ttot);
                 Pm[(size_t)a * ldr + j] = z / ttot;
                 Rm[(size_t)a * ldr + j] = rv[j];
             }
-            predrun += tq * cc * ysd;
             const int kk = a + 1;
-            if (tid == 0 && kk >= g.nlv_lo && kk <= g.nlv_hi) g.pred[(size_t)qi * le + (kk - g.nlv_lo)] = predrun;
+            if (tid < Q) {
+                const double pr = prun[tid] + tq * (cs[tid] / ttot) * ysd[tid];
+                prun[tid] = pr;
+                if (tid < q && kk >= g.nlv_lo && kk <= g.nlv_hi) g.pred[((size_t)qi * le + (kk - g.nlv_lo)) * q + tid] = pr;
+            }
             __syncthreads();
         }
         // requested nlv beyond what the local model has: predict clamps to the model's nlv (src/plskern.jl:228-229)
-        for (int kk = nlvloc + 1 + tid; kk <= g.nlv_hi; kk += 256)
-            if (kk >= g.nlv_lo) g.pred[(size_t)qi * le + (kk - g.nlv_lo)] = predrun;
+        for (int e = tid; e < (g.nlv_hi - nlvloc) * q; e += 256) {
+            const int kk = nlvloc + 1 + e / q, y = e % q;
+            if (kk >= g.nlv_lo) g.pred[((size_t)qi * le + (kk - g.nlv_lo)) * q + y] = prun[y];
+        }
     }
+}
+
+template <int KC, int Q>
+static int32_t launch_locw_q(jch_ctx *ctx, locw_args &g)
+{
+    const size_t lds = sizeof(double) * ((1 + (size_t)Q) * g.k + (5 + (size_t)Q) * g.ldr + 4 * KC * 128 + 128 + 4 * Q + 16 + 5 * Q * (Q + 2) +
+                                         2 * (Q + 2) + 8 + 4 * (Q * (Q + 1) / 2 + Q + 1)) + sizeof(int) * (size_t)g.k + 64;
+    static jch_per_device_once attr;
+    if (!attr.done(ctx->device)) {
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_locw_plskern<KC, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.mark(ctx->device);
+    }
+    if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k / p / q too large for the batched local-PLS kernel");
+    int nb = std::min(g.m, ctx->cus * 2);
+    g.slab = ((size_t)g.k * g.ldr + 2 * (size_t)g.nlv_hi * g.ldr + 31) & ~(size_t)31;
+    JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
+    g.scratch = (double *)ctx->xstage.ptr;
+    hipLaunchKernelGGL((k_locw_plskern<KC, Q>), dim3(nb), dim3(256), lds, ctx->stream, g);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
 }
 
 template <int KC>
 static int32_t launch_locw(jch_ctx *ctx, locw_args &g)
 {
-    const size_t lds = sizeof(double) * (2 * (size_t)g.k + 6 * (size_t)g.ldr + 4 * KC * 128 + 128) + sizeof(int) * (size_t)g.k + 64;
-    static jch_per_device_once attr;
-    if (!attr.done(ctx->device)) {
-        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_locw_plskern<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr.mark(ctx->device);
-    }
-    if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k / p too large for the batched local-PLS kernel");
-    int nb = std::min(g.m, ctx->cus * 2);
-    g.slab = ((size_t)g.k * g.ldr + 2 * (size_t)g.nlv_hi * g.ldr + 31) & ~(size_t)31;
-    JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
-    g.scratch = (double *)ctx->xstage.ptr;
-    hipLaunchKernelGGL(k_locw_plskern<KC>, dim3(nb), dim3(256), lds, ctx->stream, g);
-    JCH_HIP(ctx, hipGetLastError());
-    return JCH_OK;
+    if (g.q <= 1) return launch_locw_q<KC, 1>(ctx, g);
+    if (g.q <= 2) return launch_locw_q<KC, 2>(ctx, g);
+    if (g.q <= 4) return launch_locw_q<KC, 4>(ctx, g);
+    return launch_locw_q<KC, 8>(ctx, g);
 }
 
 // ---------------------------------------------------------------- C ABI
@@ -373,7 +494,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     if (!Xtrain || !Ytrain || !Ztrain || !Zq || !Xq || !pred || n < 1 || p < 1 || m < 1 || dd < 1 || k < 1 || nlv_lo < 0 ||
         nlv_hi < nlv_lo || ldx < n || ldy < n || ldzt < n || ldzq < m || ldxq < m)
         return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad arguments");
-    if (q != 1) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: the batched local-PLS kernel handles q == 1 (got q=%lld)", (long long)q);
+    if (q < 1 || q > 8) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: the batched local-PLS kernel handles 1 <= q <= 8 (got q=%lld)", (long long)q);
     if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad loc");
     if (p > JCH_SWEEP_MAXP) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: p > %d not supported", JCH_SWEEP_MAXP);
     if (k > n) k = (int32_t)n;                                    // src/getknn.jl:33
@@ -385,7 +506,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     const double *dX = Xtrain, *dY = Ytrain, *dZt = Ztrain, *dZq = Zq, *dXq = Xq;
     int64_t ldxd = ldx, ldyd = ldy, ldztd = ldzt, ldzqd = ldzq, ldxqd = ldxq;
     if (loc == JCH_LOC_HOST) {
-        const size_t need = sizeof(double) * ((size_t)n * p + (size_t)n + (size_t)n * dd + (size_t)m * dd + (size_t)m * p);
+        const size_t need = sizeof(double) * ((size_t)n * p + (size_t)n * q + (size_t)n * dd + (size_t)m * dd + (size_t)m * p);
         JCH_TRY(jch_reserve(ctx, ctx->xq, need));
         double *b = (double *)ctx->xq.ptr;
         auto up = [&](const double *src, int64_t rows, int64_t cols, int64_t ld, const double *&dst, int64_t &ldd) -> int32_t {
@@ -394,15 +515,15 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
             dst = b; ldd = rows; b += (size_t)rows * cols;
             return JCH_OK;
         };
-        JCH_TRY(up(Xtrain, n, p, ldx, dX, ldxd)); JCH_TRY(up(Ytrain, n, 1, ldy, dY, ldyd)); JCH_TRY(up(Ztrain, n, dd, ldzt, dZt, ldztd));
+        JCH_TRY(up(Xtrain, n, p, ldx, dX, ldxd)); JCH_TRY(up(Ytrain, n, q, ldy, dY, ldyd)); JCH_TRY(up(Ztrain, n, dd, ldzt, dZt, ldztd));
         JCH_TRY(up(Zq, m, dd, ldzq, dZq, ldzqd)); JCH_TRY(up(Xq, m, p, ldxq, dXq, ldxqd));
     }
     // ---- workspace: row-major X, neighbour lists, predictions
     JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
-    JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * ((size_t)m * k * 2 + (size_t)m * le) + sizeof(int) * (size_t)m * k + 256));
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * ((size_t)m * k * 2 + (size_t)m * le * q) + sizeof(int) * (size_t)m * k + 256));
     double *Xrm = (double *)ctx->xr.ptr;
     double *ddist = (double *)ctx->gemm_out.ptr, *dw = ddist + (size_t)m * k, *dpred = dw + (size_t)m * k;
-    int *dind = (int *)(dpred + (size_t)m * le);
+    int *dind = (int *)(dpred + (size_t)m * le * q);
     {
         const int ptiles = (ldr + 63) / 64;
         const int64_t nchunks = (n + 63) / 64;
@@ -421,7 +542,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     }
     {
         locw_args g;
-        g.Xrm = Xrm; g.ldr = ldr; g.p = (int)p; g.Y = dY; g.ldy = ldyd; g.Xq = dXq; g.ldxq = ldxqd; g.m = (int)m;
+        g.Xrm = Xrm; g.ldr = ldr; g.p = (int)p; g.Y = dY; g.ldy = ldyd; g.q = (int)q; g.Xq = dXq; g.ldxq = ldxqd; g.m = (int)m;
         g.ind = dind; g.w = dw; g.k = k; g.scal = scal; g.nlv_lo = nlv_lo; g.nlv_hi = nlv_hi; g.pred = dpred;
         g.scratch = nullptr; g.slab = 0;
         if (ldr <= 128) JCH_TRY(launch_locw<1>(ctx, g));
@@ -431,7 +552,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         else JCH_TRY(launch_locw<16>(ctx, g));
     }
     JCH_HIP(ctx, hipGetLastError());
-    JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le, hipMemcpyDeviceToHost, ctx->stream));
+    JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
     if (ind_out) JCH_HIP(ctx, hipMemcpyAsync(ind_out, dind, sizeof(int) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     if (dist_out) JCH_HIP(ctx, hipMemcpyAsync(dist_out, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     if (w_out) JCH_HIP(ctx, hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));

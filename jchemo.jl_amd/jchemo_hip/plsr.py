@@ -587,17 +587,18 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None) -
     le = hi - lo + 1
     k = min(obj.k, n)
     Zt, Zq = _knn_space(obj, X, ctx)
-    pred = np.empty((m, le))
+    batched = q <= 8                                           # the batched kernel's envelope (include/jchemo_hip.h)
+    pred = np.empty((m, le, q if batched else 1))
     ind = np.empty((m, k), dtype=np.int32); dist = np.empty((m, k)); w = np.empty((m, k))
     xa, ldx = _addr_ld(Xt); ya, ldy = _addr_ld(Yt); za, ldz = _addr_ld(Zt); qa, ldq = _addr_ld(Zq); xqa, ldxq = _addr_ld(X)
     if dev:
         torch.cuda.current_stream(X.device).synchronize()
-    # the batched kernel fits q == 1; for q > 1 it is still used (on the first y column) for neighbours + weights
-    ctx.check(_lib.load().jch_lwplsr_predict(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, ya, 1, ldy, za, ldz,
-                                             qa, ldq, Zt.shape[1], xqa, m, ldxq, k, float(obj.h), float(obj.tol), int(obj.scal), lo, hi,
-                                             pred.ctypes.data, ind.ctypes.data, dist.ctypes.data, w.ctypes.data))
-    if q != 1:
-        # q > 1: one weighted plskern + predict per query through the same device library (unbatched; src/locwlv.jl:18-39)
+    # q > 8: the kernel is still used (on the first y column) for neighbours + weights
+    ctx.check(_lib.load().jch_lwplsr_predict(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, ya, q if batched else 1, ldy,
+                                             za, ldz, qa, ldq, Zt.shape[1], xqa, m, ldxq, k, float(obj.h), float(obj.tol), int(obj.scal),
+                                             lo, hi, pred.ctypes.data, ind.ctypes.data, dist.ctypes.data, w.ctypes.data))
+    if not batched:
+        # one weighted plskern + predict per query through the same device library (unbatched; src/locwlv.jl:18-39)
         rng = list(range(lo, hi + 1))
         out = np.empty((m, q, le))
         for i in range(m):
@@ -616,7 +617,7 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None) -
                 out[i, :, a_] = (pa_.cpu().numpy() if _is_torch(pa_) else pa_)[0]
         preds = [out[:, :, a_].copy() for a_ in range(le)]
         return LwplsrPred(preds[0] if le == 1 else preds, ind, dist, w)
-    preds = [pred[:, i:i + 1].copy() for i in range(le)]
+    preds = [pred[:, i, :].copy() for i in range(le)]
     return LwplsrPred(preds[0] if le == 1 else preds, ind, dist, w)
 
 

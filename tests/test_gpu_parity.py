@@ -351,17 +351,29 @@ def test_gridcvlv_zero_weight_folds(scal, J, ctx):
     assert res["res"][0, 0] > res["res"][best, 0]
 
 
-def test_lwplsr_multiresponse(J, ctx):
-    """q > 1: neighbours/weights from the batched kernel, local fits through the unbatched device plskern."""
-    n, p, q, m = 800, 25, 3, 6
+@pytest.mark.parametrize("case", [dict(q=3, p=25, scal=False, metric="mahal"), dict(q=2, p=140, scal=True, metric="eucl"),
+                                  dict(q=8, p=300, scal=False, metric="mahal"), dict(q=10, p=25, scal=False, metric="mahal")])
+def test_lwplsr_multiresponse(case, J, ctx):
+    """q > 1: the batched local-fit kernel (q <= 8: kernel matrix p x q and its q x q eigen-solver inside the query's
+    workgroup); q > 8 falls back to one device plskern per query.  Host and device-resident inputs."""
+    import torch
+    q, p = case["q"], case["p"]
+    n, m = 800, 6
     X = O.rand_matrix(1, n, p); B = O.rand_matrix(2, p, q) - 0.5
     Y = X @ B + np.sin(2 * X[:, :q]) + 0.05 * O.rand_matrix(3, n, q)
     Xq = O.rand_matrix(4, m, p)
-    kw = dict(nlvdis=6, metric="mahal", h=1.5, k=60, nlv=5)
+    kw = dict(nlvdis=6, metric=case["metric"], h=1.5, k=60, nlv=5, scal=case["scal"])
     ref = O.lwplsr_predict(O.lwplsr(X, Y, **kw), Xq, nlv=range(0, 6))
     res = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=range(0, 6), ctx=ctx)
     assert np.array_equal(res.listnn, ref["listnn"])
     assert O.rel_fro(ref["pred"], np.stack(res.pred, axis=2)) < 1e-8
+    one = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=3, ctx=ctx)              # a single nlv -> one matrix (m x q)
+    assert one.pred.shape == (m, q) and O.rel_fro(ref["pred"][:, :, 3], one.pred) < 1e-8
+    if q <= 8:
+        Xd = J.colmajor_empty(n, p); Xd.copy_(torch.from_numpy(X)); Yd = J.colmajor_empty(n, q); Yd.copy_(torch.from_numpy(Y))
+        Xqd = J.colmajor_empty(m, p); Xqd.copy_(torch.from_numpy(Xq))
+        rd = J.predict(J.lwplsr(Xd, Yd, ctx=ctx, **kw), Xqd, nlv=range(0, 6), ctx=ctx)
+        assert O.rel_fro(ref["pred"], np.stack(rd.pred, axis=2)) < 1e-8
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 1, 1), (3, 5, 2, 4), (1, 3, 1, 2), (7, 1, 3, 2), (65, 129, 16, 3), (129, 2, 2, 2)])
