@@ -379,6 +379,8 @@ def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Op
         return lwplsr_predict(fm, X, nlv=nlv, ctx=ctx)
     if isinstance(fm, Plsrda):
         return plsrda_predict(fm, X, nlv=nlv, ctx=ctx)
+    if isinstance(fm, Plslda):
+        return plslda_predict(fm, X, nlv=nlv, ctx=ctx)
     a = fm.P.shape[1]
     if nlv is None:
         rng = [a]
@@ -846,3 +848,120 @@ def plsrda_predict(obj: Plsrda, X, *, nlv=None, ctx: Optional[Context] = None):
     posts = post if many else [post]
     preds = [obj.lev[np.argmax(z.cpu().numpy() if _is_torch(z) else z, axis=1)].reshape(-1, 1) for z in posts]
     return (preds, posts) if many else (preds[0], posts[0])
+
+
+# ---------------------------------------------------------------------------------- PLS-LDA / PLS-QDA (§8f rank 4)
+@dataclass
+class Plslda:
+    """src/plslda.jl:1-5 — struct Plslda (fm = (fm_pls, fm_da), lev, ni); also what plsqda returns.  fm_da[i-1] is the
+    discriminant model on the first i scores: dict(mu (nlev, i), Uinv [nlev] (i, i), detS (nlev), wprior)."""
+    fm_pls: Plsr
+    fm_da: list
+    lev: np.ndarray
+    ni: np.ndarray
+
+
+def _class_score_stats(fm: Plsr, yv, lev, ctx):
+    """Per class: mean and uncorrected covariance of the scores T (src/matW.jl:27-57 on T), from ONE device pass over T
+    per class (jch_weighted_cov with the class indicator as weights); a single-observation class gets the covariance of
+    all rows."""
+    T = fm.T
+    dev = _is_torch(T)
+    n, a = T.shape
+    if a > 64:
+        raise NotImplementedError("plslda / plsqda: more than 64 LVs are not supported")
+    ctx = ctx or default_context((T.device.index or 0) if dev else 0)
+    aa, lda_ = _addr_ld(T)
+    if dev:
+        torch.cuda.current_stream(T.device).synchronize()
+
+    def cov_of(mask):
+        S = np.empty((a, a), order="F"); mu = np.empty(a)
+        if mask is None:
+            wa = None
+        elif dev:
+            mask = torch.as_tensor(mask, device=T.device); wa = mask.data_ptr()
+        else:
+            mask = np.ascontiguousarray(mask); wa = mask.ctypes.data
+        ctx.check(_lib.load().jch_weighted_cov(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, aa, n, a, lda_, wa, S.ctypes.data,
+                                               mu.ctypes.data))
+        return mu, S
+
+    ni = np.array([(yv == l).sum() for l in lev])
+    all_cov = cov_of(None)[1] if np.any(ni == 1) else None
+    mus, Wi = [], []
+    for i, l in enumerate(lev):
+        mu, S = cov_of((yv == l).astype(np.float64))
+        mus.append(mu); Wi.append(all_cov if ni[i] == 1 else S)
+    return np.stack(mus), Wi, ni
+
+
+def _dmnorm(mu, S):
+    """src/dmnorm.jl:112-128."""
+    U = np.linalg.cholesky(S).T
+    detS = float(np.prod(np.diag(U)) ** 2)
+    return np.linalg.inv(U), (1e-20 if detS == 0 else detS)
+
+
+def _plsda(X, y, weights, nlv, prior, scal, ctx, quadratic):
+    if prior not in ("unif", "prop"):
+        raise ValueError("prior must be 'unif' or 'prop'")
+    Yd, lev = dummy(y)
+    yv = np.asarray(y.cpu() if _is_torch(y) else y).reshape(-1)
+    X = ensure_mat(X)
+    if _is_torch(X):
+        Yt = colmajor_empty(Yd.shape[0], Yd.shape[1], X.device); Yt.copy_(torch.from_numpy(Yd)); Yd = Yt
+    fm = plskern(X, Yd, weights, nlv=nlv, scal=scal, ctx=ctx)
+    mus, Wi, ni = _class_score_stats(fm, yv, lev, ctx)
+    n, a = fm.T.shape
+    nlev = len(lev)
+    wprior = np.ones(nlev) / nlev if prior == "unif" else ni / ni.sum()
+    fm_da = []
+    for i in range(1, a + 1):
+        if quadratic:   # src/qda.jl:68-75
+            cs = [Wi[c][:i, :i] if ni[c] == 1 else Wi[c][:i, :i] * ni[c] / (ni[c] - 1) for c in range(nlev)]
+        else:           # src/lda.jl:64-75: pooled, unbiased
+            W = sum((ni[c] / n) * Wi[c][:i, :i] for c in range(nlev)) * n / (n - nlev)
+            cs = [W] * nlev
+        dm = [_dmnorm(mus[c, :i], cs[c]) for c in range(nlev)]
+        fm_da.append(dict(mu=mus[:, :i].copy(), Uinv=[d[0] for d in dm], detS=np.array([d[1] for d in dm]), wprior=wprior))
+    return Plslda(fm, fm_da, lev, ni)
+
+
+def plslda(X, y, weights=None, *, nlv: int, prior: str = "unif", scal: bool = False, ctx: Optional[Context] = None) -> Plslda:
+    """`plslda(X, y, weights; nlv, prior, scal)` — src/plslda.jl:76-88: plskern on the class dummy table, then one LDA
+    per number of LVs on the scores.  The class statistics of the n x nlv scores come from the device."""
+    return _plsda(X, y, weights, nlv, prior, scal, ctx, False)
+
+
+def plsqda(X, y, weights=None, *, nlv: int, prior: str = "unif", scal: bool = False, ctx: Optional[Context] = None) -> Plslda:
+    """`plsqda` — src/plsqda.jl:23-34: as plslda with one covariance per class (QDA)."""
+    return _plsda(X, y, weights, nlv, prior, scal, ctx, True)
+
+
+def plslda_predict(obj: Plslda, X, *, nlv=None, ctx: Optional[Context] = None):
+    """`predict(object::Plslda, X; nlv)` — src/plslda.jl:107-130: (pred, posterior); lists over the clamped nlv range.
+    The scores of X come from ONE device pass (transform at the largest nlv: its leading columns are the scores of every
+    smaller model); the Gaussian posteriors on the m x nlv scores are p x nlev host glue like the reference's."""
+    a = obj.fm_pls.P.shape[1]
+    if nlv is None:
+        rng = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng = list(range(max(int(vals.min()), 0), min(int(vals.max()), a) + 1))
+    if not rng or rng[0] < 1:
+        raise ValueError("BoundsError: a discriminant model needs nlv >= 1 (src/plslda.jl:120 indexes fm_da[nlv])")
+    T = transform(obj.fm_pls, X, nlv=rng[-1], ctx=ctx)
+    T = T.cpu().numpy() if _is_torch(T) else T
+    preds, posts = [], []
+    for k in rng:
+        da = obj.fm_da[k - 1]
+        nlev = len(obj.lev)
+        dens = np.empty((T.shape[0], nlev))
+        for c in range(nlev):
+            z = (T[:, :k] - da["mu"][c][None, :]) @ da["Uinv"][c]
+            dens[:, c] = (2 * np.pi) ** (-k / 2) / np.sqrt(da["detS"][c]) * np.exp(-0.5 * np.sum(z * z, axis=1))
+        A = da["wprior"][None, :] * dens
+        post = A / A.sum(axis=1, keepdims=True)
+        preds.append(obj.lev[np.argmax(post, axis=1)].reshape(-1, 1)); posts.append(post)
+    return (preds[0], posts[0]) if len(rng) == 1 else (preds, posts)

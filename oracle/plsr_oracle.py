@@ -770,3 +770,108 @@ def plsrda_predict(model, X, *, nlv=None):
     post = [predict(fm, X, nlv=k) for k in rng]
     pred = [lev[np.argmax(z, axis=1)].reshape(-1, 1) for z in post]      # ties: the first maximum, like Julia's argmax
     return (pred[0], post[0]) if len(rng) == 1 else (pred, post)
+
+
+# --------------------------------------------------------------------------
+# PLS-LDA / PLS-QDA: plskern on the class dummy table, then LDA / QDA on the scores
+# --------------------------------------------------------------------------
+def matW(X, y):
+    """src/matW.jl:27-57 — within-class covariances (uncorrected) Wi and their pooled W = sum (ni / n) Wi; a class with
+    a single observation gets the covariance of the whole X."""
+    X = ensure_mat(X); y = np.asarray(y).reshape(-1)
+    lev = np.unique(y)
+    ni = np.array([(y == l).sum() for l in lev])
+    sigma_1 = np.cov(X, rowvar=False, bias=True).reshape(X.shape[1], X.shape[1]) if np.any(ni == 1) else None
+    Wi = [sigma_1 if ni[i] == 1 else np.cov(X[y == lev[i]], rowvar=False, bias=True).reshape(X.shape[1], X.shape[1])
+          for i in range(len(lev))]
+    w = ni / ni.sum()
+    W = sum(w[i] * Wi[i] for i in range(len(lev)))
+    return W, Wi, lev, ni
+
+
+def dmnorm(mu, S):
+    """src/dmnorm.jl:112-128 — (mu, inv(chol(S).U), det S) of a Gaussian density."""
+    U = np.linalg.cholesky(np.asarray(S, dtype=np.float64)).T
+    detS = float(np.prod(np.diag(U)) ** 2)
+    if detS == 0:
+        detS = 1e-20
+    return np.asarray(mu, dtype=np.float64), np.linalg.inv(U), detS
+
+
+def dmnorm_predict(dm, X):
+    """src/dmnorm.jl:136-143."""
+    mu, Uinv, detS = dm
+    X = ensure_mat(X)
+    z = (X - mu[None, :]) @ Uinv
+    d = np.sum(z * z, axis=1)
+    return (2 * np.pi) ** (-X.shape[1] / 2) / np.sqrt(detS) * np.exp(-0.5 * d)
+
+
+def _wprior(prior, ni):
+    if prior == "unif":
+        return np.ones(len(ni)) / len(ni)
+    if prior == "prop":
+        return ni / ni.sum()
+    raise ValueError("prior must be 'unif' or 'prop'")
+
+
+def lda(X, y, *, prior="unif"):
+    """src/lda.jl:56-78 — class centres, pooled W * n / (n - nlev), one Gaussian per class."""
+    X = ensure_mat(X); y = np.asarray(y).reshape(-1)
+    n = X.shape[0]
+    W, Wi, lev, ni = matW(X, y)
+    ct = np.stack([X[y == l].mean(axis=0) for l in lev])
+    W = W * n / (n - len(lev))
+    return dict(fm=[dmnorm(ct[i], W) for i in range(len(lev))], wprior=_wprior(prior, ni), lev=lev, ni=ni)
+
+
+def qda(X, y, *, prior="unif"):
+    """src/qda.jl:55-79 — one covariance per class, Wi * ni / (ni - 1)."""
+    X = ensure_mat(X); y = np.asarray(y).reshape(-1)
+    W, Wi, lev, ni = matW(X, y)
+    ct = np.stack([X[y == l].mean(axis=0) for l in lev])
+    fm = [dmnorm(ct[i], Wi[i] if ni[i] == 1 else Wi[i] * ni[i] / (ni[i] - 1)) for i in range(len(lev))]
+    return dict(fm=fm, wprior=_wprior(prior, ni), lev=lev, ni=ni)
+
+
+def da_predict(model, X):
+    """src/lda.jl:85-99 / src/qda.jl:87-102 — (pred, dens, posterior)."""
+    X = ensure_mat(X)
+    dens = np.stack([dmnorm_predict(dm, X) for dm in model["fm"]], axis=1)
+    A = model["wprior"][None, :] * dens
+    posterior = A / A.sum(axis=1, keepdims=True)
+    pred = model["lev"][np.argmax(posterior, axis=1)].reshape(-1, 1)
+    return pred, dens, posterior
+
+
+def plslda(X, y, weights=None, *, nlv: int, prior="unif", scal: bool = False, da=lda):
+    """src/plslda.jl:76-88 (plsqda: src/plsqda.jl:23-34 with da = qda): plskern on dummy(y), then one discriminant
+    model per number of LVs on the scores T[:, 1:i]."""
+    Yd, lev = dummy(y)
+    fm_pls = plskern(X, Yd, weights, nlv=nlv, scal=scal)
+    yv = np.asarray(y).reshape(-1)
+    fm_da = [da(fm_pls.T[:, :i + 1], yv, prior=prior) for i in range(fm_pls.T.shape[1])]
+    return dict(fm_pls=fm_pls, fm_da=fm_da, lev=lev, ni=np.array([(yv == l).sum() for l in lev]))
+
+
+def plsqda(X, y, weights=None, *, nlv: int, prior="unif", scal: bool = False):
+    return plslda(X, y, weights, nlv=nlv, prior=prior, scal=scal, da=qda)
+
+
+def plslda_predict(model, X, *, nlv=None):
+    """src/plslda.jl:107-130 — per requested nlv: scores, discriminant prediction on them.  Returns lists (pred,
+    posterior) over the clamped range (single entry -> the bare arrays)."""
+    a = model["fm_pls"].T.shape[1]
+    if nlv is None:
+        rng = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng = list(range(max(int(vals.min()), 0), min(int(vals.max()), a) + 1))
+    if not rng or rng[0] < 1:
+        raise ValueError("BoundsError: fm_da[nlv] needs nlv >= 1 (src/plslda.jl:120)")
+    preds, posts = [], []
+    for k in rng:
+        T = transform(model["fm_pls"], X, nlv=k)
+        pr, _, po = da_predict(model["fm_da"][k - 1], T)
+        preds.append(pr); posts.append(po)
+    return (preds[0], posts[0]) if len(rng) == 1 else (preds, posts)

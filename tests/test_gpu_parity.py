@@ -787,3 +787,37 @@ def test_bf16_vector_prologue_tails(J):
         assert O.rel_fro(getattr(ref, f), getattr(fm, f) * s) < 1e-3, f
     assert O.rel_fro(ref.T, fm.T.cpu().numpy() * s) < 1e-3
     tctx.close()
+
+
+@pytest.mark.parametrize("quad", [False, True])
+@pytest.mark.parametrize("prior", ["unif", "prop"])
+def test_plslda_plsqda(quad, prior, J, ctx):
+    """§8f rank 4: plslda / plsqda (src/plslda.jl:76-130, src/plsqda.jl:23-34; lda.jl, qda.jl, matW.jl, dmnorm.jl)."""
+    import torch
+    rng = np.random.default_rng(8)
+    n, p, nlv = 900, 40, 5
+    y = rng.integers(0, 4, n)
+    y[0] = 7                                           # a class with ONE observation (src/matW.jl:36-45)
+    X = rng.standard_normal((n, p)) + (y % 4)[:, None] * np.linspace(0, 1.5, p)[None, :] + 0.3 * rng.standard_normal((n, 1))
+    Xt = rng.standard_normal((60, p)) + rng.integers(0, 4, 60)[:, None] * np.linspace(0, 1.5, p)[None, :]
+    w = rng.uniform(0.5, 1.5, n)
+    of, jf = (O.plsqda, J.plsqda) if quad else (O.plslda, J.plslda)
+    if quad:
+        y = np.where(y == 7, 0, y)                     # (QDA of a single point has no Cholesky; the reference fails there too)
+    ref = of(X, y, w, nlv=nlv, prior=prior, scal=True)
+    mod = jf(X, y, w, nlv=nlv, prior=prior, scal=True, ctx=ctx)
+    assert np.array_equal(ref["lev"], mod.lev) and np.array_equal(ref["ni"], mod.ni)
+    rp, rpo = O.plslda_predict(ref, Xt, nlv=range(1, nlv + 1))
+    gp, gpo = J.predict(mod, Xt, nlv=range(1, nlv + 1), ctx=ctx)
+    for k in range(nlv):
+        assert np.abs(rpo[k] - gpo[k]).max() < 1e-8, k
+        assert np.array_equal(rp[k], gp[k])
+    one_p, one_po = J.predict(mod, Xt, ctx=ctx)
+    assert np.array_equal(one_p, rp[-1]) and np.abs(one_po - rpo[-1]).max() < 1e-8
+    with pytest.raises(ValueError):
+        J.predict(mod, Xt, nlv=0, ctx=ctx)
+    # device-resident training data and queries
+    Xd = J.colmajor_empty(n, p); Xd.copy_(torch.from_numpy(X)); Xtd = J.colmajor_empty(60, p); Xtd.copy_(torch.from_numpy(Xt))
+    md = jf(Xd, y, torch.from_numpy(w).cuda(), nlv=nlv, prior=prior, scal=True, ctx=ctx)
+    dp, dpo = J.predict(md, Xtd, nlv=3, ctx=ctx)
+    assert np.abs(dpo - rpo[2]).max() < 1e-8 and np.array_equal(dp, rp[2])

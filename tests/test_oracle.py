@@ -274,3 +274,26 @@ def test_vip_xfit_xresid_oracle(golden_cases):
     f1 = O.plskern(X, y1, w, nlv=4)
     # univariate y: rd(y, t_a) = cor(y, t_a)^2 is proportional to c_a^2 tt_a -> both VIP definitions coincide
     assert O.rel_fro(O.vip(f1)["imp"], O.vip(f1, y1)["imp"]) < 1e-10
+
+
+def test_plslda_plsqda_oracle():
+    """src/lda.jl, src/qda.jl, src/matW.jl, src/dmnorm.jl restatements: QDA posteriors equal scikit-learn's; LDA equals
+    scikit-learn's once its pooled covariance gets the reference's n / (n - nlev) factor (src/lda.jl:65)."""
+    from sklearn.discriminant_analysis import QuadraticDiscriminantAnalysis
+    rng = np.random.default_rng(0)
+    n, p = 300, 20
+    y = rng.integers(0, 3, n)
+    X = rng.standard_normal((n, p)) + y[:, None] * np.linspace(0, 1, p)[None, :]
+    m = O.plsqda(X, y, nlv=4, prior="prop")
+    T = m["fm_pls"].T
+    sk = QuadraticDiscriminantAnalysis(priors=np.bincount(y) / n).fit(T, y)
+    assert np.abs(sk.predict_proba(T) - O.da_predict(m["fm_da"][3], T)[2]).max() < 1e-12
+    ml = O.plslda(X, y, nlv=4, prior="unif")
+    W, Wi, lev, ni = O.matW(T, y)
+    assert np.allclose(W, sum((ni[i] / n) * np.cov(T[y == lev[i]], rowvar=False, bias=True) for i in range(3)))
+    mu, Uinv, detS = ml["fm_da"][3]["fm"][1]
+    assert np.allclose(np.linalg.inv(Uinv @ Uinv.T), W * n / (n - 3)) and abs(detS - np.linalg.det(W * n / (n - 3))) < 1e-12 * detS
+    pr, po = O.plslda_predict(ml, X[:40], nlv=range(1, 99))
+    assert len(pr) == 4 and all(np.allclose(q_.sum(axis=1), 1) for q_ in po)          # nlv clamped to the model's 4
+    with pytest.raises(ValueError):
+        O.plslda_predict(ml, X[:40], nlv=range(0, 3))                                  # fm_da[0]: BoundsError in the reference
