@@ -134,6 +134,20 @@ JCH_API int32_t jch_plsnipals_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *
                           double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
                           double *weights_norm, int32_t *nlv_out);
 
+/* jch_plskern_fit_scaled — jch_plskern_fit with CALLER-SUPPLIED column divisors instead of `scal`: X is centred by its
+ * weighted means and divided by xscales_in (p, HOST), Y by yscales_in (q, HOST; NULL = ones); desc->scal is ignored and
+ * the divisors are echoed in xscales / yscales.  This is what multiblock PLSR needs (src/mbplsr.jl:77-113: per-block
+ * column scales times one scalar per block, then plskern with scal = false on the concatenated blocks).  Float64. */
+JCH_API int32_t jch_plskern_fit_scaled(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                        const double *weights, const double *xscales_in, const double *yscales_in, double *T, double *P,
+                        double *R, double *W, double *C, double *TT, double *xmeans, double *xscales, double *ymeans,
+                        double *yscales, double *weights_norm, int32_t *nlv_out);
+
+/* jch_col_stats — weighted column means and (stds != NULL) uncorrected standard deviations: `colmean`, `colstd`
+ * (src/utility.jl:193-195,312-323) on their own.  X n x p [loc], weights n or NULL [loc]; means, stds (p) HOST. */
+JCH_API int32_t jch_col_stats(jch_ctx *ctx, int32_t loc, const double *X, int64_t n, int64_t p, int64_t ldx, const double *weights,
+                      double *means, double *stds);
+
 /* ---- sibling algorithms: same row kernels, different small state --------------------------------
  * jch_plssimp_fit — `plssimp!` / `plssimp` (src/plssimp.jl:22-88, SIMPLS with un-normed scores); W is returned equal to R
  *   (src/plssimp.jl:85-87).  One fused sweep over X per LV, like plskern.

@@ -21,6 +21,7 @@ struct fit_io {
     double *T, *P, *R, *W, *C, *TT, *xmeans, *xscales, *ymeans, *yscales, *weights_norm;
     int32_t *nlv_out;
     double tol = 0.0; int maxit = 0; double *niter = nullptr;   // plswold only
+    const double *xscales_in = nullptr, *yscales_in = nullptr;   // jch_plskern_fit_scaled: caller-supplied column divisors (host)
 };
 
 // algorithm codes of fit_impl
@@ -205,9 +206,17 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
     JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
-    if (d.scal) JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl));
+    const bool ext_scales = io.xscales_in != nullptr;
+    if (ext_scales) {   // divisors handed in by the caller (multiblock scaling): no second-moment pass
+        JCH_TRY(jch_reserve_host(ctx, sizeof(double) * (size_t)(p + q)));
+        double *h = (double *)ctx->hstage;
+        for (int j = 0; j < p; ++j) h[j] = io.xscales_in[j];
+        for (int k = 0; k < q; ++k) h[p + k] = io.yscales_in ? io.yscales_in[k] : 1.0;
+        JCH_HIP(ctx, hipMemcpyAsync(s.scl, h, sizeof(double) * (size_t)(p + q), hipMemcpyHostToDevice, ctx->stream));
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the staging buffer is reused for the outputs)
+    } else if (d.scal) JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl));
     else hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
-    JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && kern_like, Xr, ldr, Yr, qpad, s.K, d.scal != 0));
+    JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && kern_like, Xr, ldr, Yr, qpad, s.K, d.scal != 0 || ext_scales));
     hipEvent_t ev_prologue = jch_ev(ctx);
 
     // ---- LV loop
@@ -368,4 +377,51 @@ extern "C" int32_t jch_plswold_fit(jch_ctx *ctx, const jch_pls_desc *desc, void 
     fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
     io.tol = tol; io.maxit = maxit; io.niter = niter;
     return fit_impl(ctx, io, ALGO_WOLD);
+}
+
+extern "C" int32_t jch_plskern_fit_scaled(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
+                                          const double *weights, const double *xscales_in, const double *yscales_in, double *T,
+                                          double *P, double *R, double *W, double *C, double *TT, double *xmeans, double *xscales,
+                                          double *ymeans, double *yscales, double *weights_norm, int32_t *nlv_out)
+{
+    fit_io io{desc, X, ldx, Y, ldy, weights, T, P, R, W, C, TT, xmeans, xscales, ymeans, yscales, weights_norm, nlv_out};
+    if (ctx && !xscales_in) return jch_fail(ctx, JCH_EINVAL, "jch_plskern_fit_scaled: xscales_in is NULL");
+    if (ctx && desc && desc->dtype != JCH_F64) return jch_fail(ctx, JCH_EINVAL, "jch_plskern_fit_scaled: Float64 only");
+    io.xscales_in = xscales_in; io.yscales_in = yscales_in;
+    return fit_impl(ctx, io, ALGO_KERN);
+}
+
+// Weighted column means and (optionally) uncorrected standard deviations: `colmean` / `colstd` (src/utility.jl:193-195,
+// 312-323) as a call of their own (K0 + K1 of the fit).
+extern "C" int32_t jch_col_stats(jch_ctx *ctx, int32_t loc, const double *X, int64_t n, int64_t p, int64_t ldx, const double *weights,
+                                 double *means, double *stds)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!X || !means || n < 1 || p < 1 || ldx < n) return jch_fail(ctx, JCH_EINVAL, "jch_col_stats: bad arguments");
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_col_stats: bad loc");
+    if (p > (1 << 20)) return jch_fail(ctx, JCH_EINVAL, "jch_col_stats: p too large");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const double *dX = X, *dw = weights;
+    int64_t ldxd = ldx;
+    if (loc == JCH_LOC_HOST) {
+        JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * (size_t)n * p));
+        JCH_TRY(h2d_matrix(ctx, (double *)ctx->xstage.ptr, X, n, p, ldx));
+        dX = (const double *)ctx->xstage.ptr; ldxd = n;
+        if (weights) {
+            JCH_TRY(jch_reserve(ctx, ctx->wstage, sizeof(double) * (size_t)n));
+            JCH_HIP(ctx, hipMemcpyAsync(ctx->wstage.ptr, weights, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+            dw = (const double *)ctx->wstage.ptr;
+        }
+    }
+    JCH_TRY(jch_reserve(ctx, ctx->dnorm, sizeof(double) * (size_t)n));
+    JCH_TRY(jch_reserve(ctx, ctx->small, sizeof(double) * (2 * (size_t)p + 64)));
+    double *mom = (double *)ctx->small.ptr, *scl = mom + p, *hdr = scl + p;
+    double *dn = (double *)ctx->dnorm.ptr;
+    JCH_TRY(jch_launch_weights(ctx, dw, n, dn, hdr));
+    JCH_TRY(jch_launch_moments(ctx, dX, ldxd, nullptr, 0, dn, n, (int)p, 0, nullptr, mom));
+    if (stds) JCH_TRY(jch_launch_moments(ctx, dX, ldxd, nullptr, 0, dn, n, (int)p, 0, mom, scl));
+    JCH_HIP(ctx, hipMemcpyAsync(means, mom, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, ctx->stream));
+    if (stds) JCH_HIP(ctx, hipMemcpyAsync(stds, scl, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, ctx->stream));
+    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JCH_OK;
 }

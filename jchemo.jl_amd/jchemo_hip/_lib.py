@@ -26,7 +26,7 @@ SYMBOLS = (
     "jch_weighted_ss", "jch_fill_uniform", "jch_ctx_set_profiling", "jch_ctx_get_profile", "jch_lwplsr_predict",
     "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
     "jch_predict", "jch_loopback_group_create", "jch_loopback_group_destroy", "jch_ctx_comm_init_loopback",
-    "jch_ctx_p2p_export", "jch_ctx_p2p_import", "jch_ctx_p2p_enable",
+    "jch_ctx_p2p_export", "jch_ctx_p2p_import", "jch_ctx_p2p_enable", "jch_plskern_fit_scaled", "jch_col_stats",
 )
 
 
@@ -79,6 +79,8 @@ def load():
     L.jch_plssimp_fit.argtypes = fit
     L.jch_plsrosa_fit.argtypes = fit
     L.jch_plswold_fit.argtypes = ([vp, C.POINTER(PlsDesc), dp, i64, dp, i64, dp, C.c_double, i32] + [dp] * 11 + [dp, C.POINTER(i32)])
+    L.jch_plskern_fit_scaled.argtypes = [vp, C.POINTER(PlsDesc), dp, i64, dp, i64, dp, dp, dp] + [dp] * 11 + [C.POINTER(i32)]
+    L.jch_col_stats.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp]
     L.jch_transform.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, i32, dp, i64]
     L.jch_predict.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, dp, dp, dp, i64, i32, i32, dp, i64]
     L.jch_affine_gemm.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, i64, dp, dp, i64]

@@ -121,7 +121,7 @@ def _np(a):
 
 # ---------------------------------------------------------------------------------- fits
 def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Optional[Context], variant: int = 0,
-         wold: Optional[tuple] = None):
+         wold: Optional[tuple] = None, ext_scales: Optional[tuple] = None):
     dev = _is_torch(X)
     if dev != _is_torch(Y):
         raise TypeError("X and Y must both be host arrays or both device tensors")
@@ -167,7 +167,15 @@ def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Op
     if dev:
         torch.cuda.current_stream(X.device).synchronize()  # inputs produced on other streams are complete
     niter = None
-    if wold is not None:   # jch_plswold_fit: tol, maxit after weights; niter before nlv_out
+    if ext_scales is not None:   # jch_plskern_fit_scaled: caller-supplied column divisors after weights
+        xdiv = np.ascontiguousarray(ext_scales[0], dtype=np.float64)
+        ydiv = None if ext_scales[1] is None else np.ascontiguousarray(ext_scales[1], dtype=np.float64)
+        if xdiv.shape[0] != p or (ydiv is not None and ydiv.shape[0] != q):
+            raise ValueError("DimensionMismatch: scale vectors")
+        st = _lib.load().jch_plskern_fit_scaled(ctx._h, C.byref(desc), xa, ldx, ya, ldy, w_addr, _np(xdiv), _np(ydiv), t_addr, _np(P),
+                                                _np(R), _np(W), _np(Cm), _np(TT), _np(xm), _np(xs), _np(ym), _np(ys), wn_addr,
+                                                C.byref(got))
+    elif wold is not None:   # jch_plswold_fit: tol, maxit after weights; niter before nlv_out
         niter = np.zeros(kmax)
         st = _lib.load().jch_plswold_fit(ctx._h, C.byref(desc), xa, ldx, ya, ldy, w_addr, float(wold[0]), int(wold[1]), t_addr,
                                          _np(P), _np(R), _np(W), _np(Cm), _np(TT), _np(xm), _np(xs), _np(ym), _np(ys), wn_addr,
@@ -381,6 +389,8 @@ def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Op
         return plsrda_predict(fm, X, nlv=nlv, ctx=ctx)
     if isinstance(fm, Plslda):
         return plslda_predict(fm, X, nlv=nlv, ctx=ctx)
+    if isinstance(fm, Mbplsr):
+        return mbplsr_predict(fm, X, nlv=nlv, ctx=ctx)
     a = fm.P.shape[1]
     if nlv is None:
         rng = [a]
@@ -965,3 +975,124 @@ def plslda_predict(obj: Plslda, X, *, nlv=None, ctx: Optional[Context] = None):
         post = A / A.sum(axis=1, keepdims=True)
         preds.append(obj.lev[np.argmax(post, axis=1)].reshape(-1, 1)); posts.append(post)
     return (preds[0], posts[0]) if len(rng) == 1 else (preds, posts)
+
+
+# ---------------------------------------------------------------------------------- multiblock PLSR (§8f rank 4)
+@dataclass
+class Mbplsr:
+    """src/mbplsr.jl:1-12 — same fields."""
+    fm: Plsr
+    T: object
+    R: np.ndarray
+    C: np.ndarray
+    bscales: np.ndarray
+    xmeans: list
+    xscales: list
+    ymeans: np.ndarray
+    yscales: np.ndarray
+    weights: object
+
+
+def _col_stats(X, weights, want_std, ctx):
+    """jch_col_stats: weighted column means (and uncorrected stds) from the device."""
+    X = ensure_mat(X)
+    try:
+        _addr_ld(X)
+    except (ValueError, TypeError):
+        X = _as_colmajor_copy(X)
+    dev = _is_torch(X)
+    n, p = X.shape
+    ctx = ctx or default_context((X.device.index or 0) if dev else 0)
+    if weights is None:
+        wa = None
+    elif dev:
+        weights = (weights if _is_torch(weights) else torch.as_tensor(np.asarray(weights, dtype=np.float64), device=X.device)).to(torch.float64).contiguous()
+        wa = weights.data_ptr()
+    else:
+        weights = np.ascontiguousarray(np.asarray(weights.cpu() if _is_torch(weights) else weights, dtype=np.float64).reshape(-1))
+        wa = weights.ctypes.data
+    m = np.empty(p); sd = np.empty(p) if want_std else None
+    xa, ldx = _addr_ld(X)
+    if dev:
+        torch.cuda.current_stream(X.device).synchronize()
+    ctx.check(_lib.load().jch_col_stats(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, wa, m.ctypes.data, _np(sd)))
+    return m, sd
+
+
+def _hcat(blocks):
+    """`reduce(hcat, Xbl)`: one column-major matrix (a copy of the blocks side by side; no arithmetic)."""
+    blocks = [ensure_mat(b) for b in blocks]
+    if _is_torch(blocks[0]):
+        n = blocks[0].shape[0]
+        out = colmajor_empty(n, sum(b.shape[1] for b in blocks), blocks[0].device)
+        j = 0
+        for b in blocks:
+            out[:, j:j + b.shape[1]] = b.to(torch.float64); j += b.shape[1]
+        return out
+    return np.asfortranarray(np.hstack([np.asarray(b, dtype=np.float64) for b in blocks]))
+
+
+def mbplsr(Xbl, Y, weights=None, *, nlv: int, bscal: str = "none", scal: bool = False, ctx: Optional[Context] = None) -> Mbplsr:
+    """`mbplsr(Xbl, Y, weights; nlv, bscal, scal)` — src/mbplsr.jl:64-113.  The reference materialises every centred /
+    scaled / block-scaled block and concatenates them; here the blocks are concatenated RAW and the whole scaling is ONE
+    vector of column divisors (column std x block scale) handed to jch_plskern_fit_scaled.  Column stds / block
+    Frobenius norms come from jch_col_stats."""
+    if bscal not in ("none", "frob"):
+        raise ValueError("bscal must be 'none' or 'frob' (src/mbplsr.jl:26)")
+    Y = ensure_mat(Y)
+    X = _hcat(Xbl)
+    dev = _is_torch(X)
+    widths = [ensure_mat(b).shape[1] for b in Xbl]
+    need_std = scal or bscal == "frob"
+    xm, xsd = _col_stats(X, weights, need_std, ctx)
+    edges = np.concatenate([[0], np.cumsum(widths)])
+    xscales = [xsd[a:b].copy() if scal else np.ones(b - a) for a, b in zip(edges[:-1], edges[1:])]
+    if bscal == "frob":   # || centred (/ scaled) block ||_F in the weight metric = sqrt(sum_j var_j / scale_j^2)
+        bscales = np.array([np.sqrt(np.sum((xsd[a:b] / xs) ** 2)) for (a, b), xs in zip(zip(edges[:-1], edges[1:]), xscales)])
+    else:
+        bscales = np.ones(len(widths))
+    div = np.concatenate([xs * bs for xs, bs in zip(xscales, bscales)])
+    ym, ysd = _col_stats(Y, weights, scal, ctx) if scal else (None, None)
+    if dev and not _is_torch(Y):
+        Yt = colmajor_empty(Y.shape[0], Y.shape[1], X.device); Yt.copy_(torch.as_tensor(np.asarray(Y, dtype=np.float64))); Y = Yt
+    try:
+        _addr_ld(Y)
+    except (ValueError, TypeError):
+        Y = _as_colmajor_copy(Y)
+    fm = _fit("jch_plskern_fit_scaled", X, Y, weights, nlv, False, False, ctx, ext_scales=(div, ysd))
+    xmeans = [fm.xmeans[a:b].copy() for a, b in zip(edges[:-1], edges[1:])]
+    yscales = fm.yscales.copy()
+    # the reference's inner fit sees pre-scaled data with scal = false: its Plsr carries unit scales and zero means
+    inner = Plsr(fm.T, fm.P, fm.R, fm.W, fm.C, fm.TT, np.zeros_like(fm.xmeans), np.ones_like(fm.xscales), np.zeros_like(fm.ymeans),
+                 np.ones_like(fm.yscales), fm.weights, None)
+    return Mbplsr(inner, fm.T, fm.R, fm.C, bscales, xmeans, xscales, fm.ymeans.copy(), yscales, fm.weights)
+
+
+def mbplsr_transform(obj: Mbplsr, Xbl, *, nlv: Optional[int] = None, ctx: Optional[Context] = None):
+    """`transform(object::Mbplsr, Xbl; nlv)` — src/mbplswest.jl:220-231, as one device GEMM on the raw concatenation."""
+    a = obj.R.shape[1]
+    k = a if nlv is None else min(int(nlv), a)
+    if k < 1:
+        raise ValueError("transform needs nlv >= 1")
+    shift = np.concatenate(obj.xmeans)
+    div = np.concatenate([xs * bs for xs, bs in zip(obj.xscales, obj.bscales)])
+    return _affine(_hcat(Xbl), shift, div, obj.R[:, :k], None, ctx)
+
+
+def mbplsr_predict(obj: Mbplsr, Xbl, *, nlv=None, ctx: Optional[Context] = None):
+    """`predict(object::Mbplsr, Xbl; nlv)` — src/mbplswest.jl:239-254: ymeans .+ T[:, 1:nlv] * C[:, 1:nlv]' (the reference
+    does not multiply by yscales here; reproduced as is)."""
+    a = obj.R.shape[1]
+    if nlv is None:
+        rng = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng = list(range(max(0, int(vals.min())), min(a, int(vals.max())) + 1))
+    q = obj.C.shape[0]
+    T = mbplsr_transform(obj, Xbl, ctx=ctx)
+    Bc = np.zeros((a, len(rng) * q))
+    for i, k in enumerate(rng):
+        Bc[:k, i * q:(i + 1) * q] = obj.C[:, :k].T
+    out = _affine(T, None, None, Bc, np.tile(obj.ymeans, len(rng)), ctx)
+    preds = [out[:, i * q:(i + 1) * q] for i in range(len(rng))]
+    return preds[0] if len(preds) == 1 else preds

@@ -875,3 +875,56 @@ def plslda_predict(model, X, *, nlv=None):
         pr, _, po = da_predict(model["fm_da"][k - 1], T)
         preds.append(pr); posts.append(po)
     return (preds[0], posts[0]) if len(rng) == 1 else (preds, posts)
+
+
+# --------------------------------------------------------------------------
+# Multiblock PLSR: block-scaled concatenation, then plskern
+# --------------------------------------------------------------------------
+def mbplsr(Xbl, Y, weights=None, *, nlv: int, bscal: str = "none", scal: bool = False):
+    """src/mbplsr.jl:64-113 — per-block centring (/ column scaling), optional "frob" block scaling
+    (src/blockscal.jl:86-94: each block divided by its weighted Frobenius norm), plskern(scal = false) on the
+    concatenation.  Returns a dict with the fields of `Mbplsr` (:1-12)."""
+    Xbl = [np.array(ensure_mat(b), dtype=np.float64, copy=True) for b in Xbl]
+    Y = np.array(ensure_mat(Y), dtype=np.float64, copy=True)
+    n = Xbl[0].shape[0]
+    w = mweight(np.ones(n) if weights is None else weights)
+    xmeans, xscales = [], []
+    for k, b in enumerate(Xbl):
+        m = colmean(b, w); sc = colstd(b, w) if scal else np.ones(b.shape[1])
+        Xbl[k] = (b - m) / sc
+        xmeans.append(m); xscales.append(sc)
+    ymeans = colmean(Y, w); yscales = colstd(Y, w) if scal else np.ones(Y.shape[1])
+    Y = (Y - ymeans) / yscales
+    if bscal == "none":
+        bscales = np.ones(len(Xbl))
+    elif bscal == "frob":
+        bscales = np.array([np.sqrt(np.sum(w[:, None] * b ** 2)) for b in Xbl])     # frob(X, w): src/utility.jl:591-599
+    else:
+        raise ValueError("bscal must be 'none' or 'frob'")
+    X = np.hstack([b / bs for b, bs in zip(Xbl, bscales)])
+    fm = plskern(X, Y, w, nlv=nlv, scal=False)
+    return dict(fm=fm, T=fm.T, R=fm.R, C=fm.C, bscales=bscales, xmeans=xmeans, xscales=xscales, ymeans=ymeans, yscales=yscales,
+                weights=w)
+
+
+def mbplsr_transform(obj, Xbl, *, nlv: Optional[int] = None):
+    """src/mbplswest.jl:220-231."""
+    a = obj["T"].shape[1]
+    nlv = a if nlv is None else min(nlv, a)
+    Z = np.hstack([(np.asarray(ensure_mat(b), dtype=np.float64) - m) / sc / bs
+                   for b, m, sc, bs in zip(Xbl, obj["xmeans"], obj["xscales"], obj["bscales"])])
+    return Z @ obj["R"][:, :nlv]
+
+
+def mbplsr_predict(obj, Xbl, *, nlv=None):
+    """src/mbplswest.jl:239-254 — `int .+ T[:, 1:nlv] * C[:, 1:nlv]'` with int = ymeans: the reference does NOT multiply
+    by yscales here (with scal = true its predictions stay in the scaled Y units, shifted by ymeans); reproduced as is."""
+    a = obj["T"].shape[1]
+    if nlv is None:
+        rng = [a]
+    else:
+        vals = np.atleast_1d(np.asarray(nlv))
+        rng = list(range(max(0, int(vals.min())), min(a, int(vals.max())) + 1))
+    T = mbplsr_transform(obj, Xbl)
+    pred = [obj["ymeans"][None, :] + T[:, :k] @ obj["C"][:, :k].T for k in rng]
+    return pred[0] if len(rng) == 1 else pred

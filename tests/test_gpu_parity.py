@@ -821,3 +821,39 @@ def test_plslda_plsqda(quad, prior, J, ctx):
     md = jf(Xd, y, torch.from_numpy(w).cuda(), nlv=nlv, prior=prior, scal=True, ctx=ctx)
     dp, dpo = J.predict(md, Xtd, nlv=3, ctx=ctx)
     assert np.abs(dpo - rpo[2]).max() < 1e-8 and np.array_equal(dp, rp[2])
+
+
+@pytest.mark.parametrize("bscal", ["none", "frob"])
+@pytest.mark.parametrize("scal", [False, True])
+def test_mbplsr(bscal, scal, J, ctx):
+    """§8f rank 4: multiblock PLSR (src/mbplsr.jl:64-113; transform / predict src/mbplswest.jl:220-254) — raw blocks
+    side by side + ONE vector of column divisors through jch_plskern_fit_scaled vs the oracle's materialised blocks."""
+    import torch
+    rng = np.random.default_rng(2)
+    n, nlv = 700, 4
+    Lt = rng.standard_normal((n, 5))
+    Xbl = [Lt @ rng.standard_normal((5, 30)) * 3 + 1 + 0.2 * rng.standard_normal((n, 30)), Lt[:, :2] @ rng.standard_normal((2, 8)) + 0.1 * rng.standard_normal((n, 8)),
+           0.2 * (Lt @ rng.standard_normal((5, 17))) + 0.05 * rng.standard_normal((n, 17))]
+    Y = Lt[:, :3] @ rng.standard_normal((3, 2)) + 0.1 * rng.standard_normal((n, 2))
+    w = rng.uniform(0.5, 1.5, n)
+    Xnew = [b[:40] + 0.01 for b in Xbl]
+    ref = O.mbplsr(Xbl, Y, w, nlv=nlv, bscal=bscal, scal=scal)
+    fm = J.mbplsr(Xbl, Y, w, nlv=nlv, bscal=bscal, scal=scal, ctx=ctx)
+    s = O.sign_align(ref["R"], fm.R)
+    assert O.rel_fro(ref["T"], fm.T * s) < TIGHT and O.rel_fro(ref["R"], fm.R * s) < TIGHT and O.rel_fro(ref["C"], fm.C * s) < TIGHT
+    assert O.rel_fro(ref["bscales"], fm.bscales) < 1e-12 and O.rel_fro(ref["ymeans"], fm.ymeans) < 1e-12 and O.rel_fro(ref["yscales"], fm.yscales) < 1e-12
+    for k in range(3):
+        assert O.rel_fro(ref["xmeans"][k], fm.xmeans[k]) < 1e-12 and O.rel_fro(ref["xscales"][k], fm.xscales[k]) < 1e-12
+    assert O.rel_fro(ref["fm"].P, fm.fm.P * s) < TIGHT and np.all(fm.fm.xscales == 1.0) and np.all(fm.fm.xmeans == 0.0)
+    assert O.rel_fro(O.mbplsr_transform(ref, Xnew, nlv=3), J.mbplsr_transform(fm, Xnew, nlv=3, ctx=ctx) * s[:3]) < TIGHT
+    rp = O.mbplsr_predict(ref, Xnew, nlv=range(0, nlv + 1))
+    gp = J.predict(fm, Xnew, nlv=range(0, nlv + 1), ctx=ctx)
+    assert O.rel_fro(np.stack(rp), np.stack(gp)) < TIGHT
+    # device-resident blocks
+    Xd = []
+    for b in Xbl:
+        t = J.colmajor_empty(*b.shape); t.copy_(torch.from_numpy(b)); Xd.append(t)
+    fd = J.mbplsr(Xd, Y, w, nlv=nlv, bscal=bscal, scal=scal, ctx=ctx)
+    assert O.rel_fro(ref["T"], fd.T.cpu().numpy() * O.sign_align(ref["R"], fd.R)) < TIGHT
+    with pytest.raises(ValueError):
+        J.mbplsr(Xbl, Y, nlv=2, bscal="mfa", ctx=ctx)
