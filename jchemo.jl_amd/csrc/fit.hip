@@ -123,7 +123,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
     const size_t small_bytes = 256 * 16 + sizeof(double) * ((size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
-                                                         (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8);
+                                                         (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + (size_t)ldr + 64);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
@@ -133,6 +133,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap);
     s.mom = cv.take(p + q); s.scl = cv.take(p + q);
     double *niter_dev = cv.take(nlv_cap);
+    s.mshift = nullptr;
     const size_t out_bytes = (size_t)((char *)(niter_dev + nlv_cap) - (char *)s.P);
     s.Z = cv.take((size_t)nlv_cap * 16);
     const int ldz = (ldr + 1 + qpad + 7) & ~7;
@@ -205,8 +206,27 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         return jch_fail(ctx, JCH_EINVAL, "%s: needs q <= 16, p <= %d and the p x q state inside LDS (p=%d q=%d nlv=%d)", who, JCH_SWEEP_MAXP, p, q, nlv);
     int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
-    JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
     const bool ext_scales = io.xscales_in != nullptr;
+    // RAW MODE (plskern / plsrosa, no scaling, not in place): the separate means pass over X is dropped.  K2 copies X
+    // UNCENTRED into the row-major working copy and computes X'D[Yc | 1] — the kernel matrix against the centred Y plus,
+    // in a spare pad column, the weighted column sums, i.e. the means (one read of X instead of two, one all-reduce
+    // instead of two).  The sweeps then use t_i = x_i.r - mu.r and zp = zp_raw - mu * sum_i d_i t_i (sweep.hip,
+    // smallstate_fast.hip); T, P, C, TT, xmeans are the same quantities as in the centred formulation.
+    const bool raw_mode = (algo == ALGO_KERN || algo == ALGO_ROSA) && fast && !d.scal && !ext_scales && !inplace && q <= 15 &&
+                          d.reserved == 0 && !getenv("JCH_CENTRED_COPY");
+    if (raw_mode) {
+        s.mshift = cv.take((size_t)ldr + 2);
+        JCH_HIP(ctx, hipMemsetAsync(s.mshift, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));
+        JCH_TRY(jch_launch_pivot(ctx, Xc, ldxc, n, p, s.scl));                                      // scl[0..p): the pivot K2 subtracts
+        JCH_TRY(jch_launch_moments(ctx, Yc, ldyc, nullptr, 0, dn, n, q, 0, nullptr, s.scl + p));  // Y means -> scl[p..p+q)
+        hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.mom, p + q, 1.0);   // divisors (unused: SCAL = false)
+        JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, /*mom =*/s.scl, /*scl =*/s.mom, false, Xr, ldr, Yr, qpad, s.K, false,
+                                      /*means_out =*/s.mom, /*mshift_out =*/s.mshift));
+        JCH_HIP(ctx, hipMemcpyAsync(s.mom + p, s.scl + p, sizeof(double) * (size_t)q, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
+        s.variant = 2;
+    } else {
+    JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
     if (ext_scales) {   // divisors handed in by the caller (multiblock scaling): no second-moment pass
         JCH_TRY(jch_reserve_host(ctx, sizeof(double) * (size_t)(p + q)));
         double *h = (double *)ctx->hstage;
@@ -217,6 +237,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     } else if (d.scal) JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl));
     else hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
     JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && kern_like, Xr, ldr, Yr, qpad, s.K, d.scal != 0 || ext_scales));
+    }
     hipEvent_t ev_prologue = jch_ev(ctx);
 
     // ---- LV loop
@@ -241,14 +262,14 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (kern_like) {
-            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
+            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice, raw_mode ? s.mshift : nullptr));
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;   // rank-independent message size (a small shard may use 1 slice; the rest hold zeros)
             // ONE collective per LV: [zp (p), tt].  With the inbox transport and the fast small-state kernel it happens
             // INSIDE that kernel (no launch of its own); otherwise here (RCCL / inbox kernel / loopback).
             if (fuse_inbox && algo != ALGO_SIMP) {
                 JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast, true));
             } else {
-                JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1, nslice, ldz, &nslice));
+                JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + (raw_mode ? 1 : 0), nslice, ldz, &nslice));
                 if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
                 else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
             }

@@ -119,7 +119,10 @@ int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const do
                            double *out /*[p+q] device*/, bool do_sqrt = true);
 int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d,
                               int64_t n, int p, int q, const double *mom, const double *scl, bool writeback,
-                              double *Xr, int ldr, double *Yr, int qpad, double *K /*[p][qpad] device*/, bool scal);
+                              double *Xr, int ldr, double *Yr, int qpad, double *K /*[p][qpad] device*/, bool scal,
+                              double *means_out = nullptr /*raw mode: X is copied minus the pivot mom[0..p), its weighted means land here*/,
+                              double *mshift_out = nullptr /*means - pivot*/);
+int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n, int p, double *pivot /*[p] device, same on all ranks*/);
 int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n,
                                    int p, int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy,
                                    const double *sqrt_rowscale = nullptr /*rows scaled by sqrt(d_i): plswold! row metric*/);
@@ -127,7 +130,7 @@ int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, cons
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra /*0: plskern; q: also c_raw (plsnipals)*/,
                          double *tcol, double *zt /*[nslice][ldz] device, reduced over blocks*/, int ldz, int max_slices,
-                         int *nslice_out);
+                         int *nslice_out, const double *mu = nullptr /*raw mode: Xr is uncentred; t = x.r - mu.r, st at [ldr+1]*/);
 int32_t jch_launch_reduce_rows(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *out);
 int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *zt, int ldz, int *nslice_out);
 int32_t jch_launch_sweep_wide(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
@@ -146,8 +149,10 @@ struct jch_small {  // device-resident replicated small state of one fit
     double *zt;         // [JCH_ZT_SLICES][ldz]  reduced sweep output slices: zp, tt, (c_raw); ldz = ldr + 1 + qpad (+pad)
     double *zpc;        // [ldr + qpad]      plsnipals: zp/tt, c/tt
     double *mom, *scl;  // [p+q]
+    double *mshift;     // [ldr] raw mode: means - pivot (the stored rows are x - pivot); null otherwise
     double *hdr;        // [4]
-    int variant;        // 0: algorithm #1 (zt holds [zp, tt] from the sweep); 1: algorithm #2 (zt = G r, tt = r'zp computed here)
+    int variant;        // 0: algorithm #1 (zt holds [zp, tt] from the sweep); 1: algorithm #2 (zt = G r, tt = r'zp computed here);
+                        // 2: algorithm #1 in raw mode (uncentred row copy: zt holds [zp_raw, tt, st], zp = zp_raw - mom * st)
     double *dbg;        // [nlv + 1] diagnostics (JCH_LV_DEBUG): Jacobi sweeps per LV; may be null
     double *niter;      // [nlv] plswold: inner iterations per LV (src/plswold.jl:93); null otherwise
 };

@@ -14,6 +14,7 @@ struct lvf_args {
     p2p_dev px;   // fused inbox all-reduce of the sweep output (only read by the P2P instantiations)
     const double *bf_src;   // bf16 storage mode: raw slices [nslice][bf_ld] of [zp_raw (bf_ldr), tt, st]; null otherwise
     int bf_ld, bf_ldr;
+    int raw_mu;             // f64 raw mode: the sweep ran on uncentred rows; zp needs - mu * st (st at [ldr + 1])
 };
 
 __device__ __forceinline__ void wavesync()

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
                                                      int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                      const double *__restrict__ mom, const double *__restrict__ scl,
                                                      double *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
-                                                     double *__restrict__ Kpart, int kp_rows, int dbg_skip)
+                                                     double *__restrict__ Kpart, int kp_rows, int dbg_skip, int ones_col)
 {
     __shared__ double xt[64 * XT_LD];
     __shared__ double yt[64 * YT_LD];
@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
                 dv = d[i];
             }
             if (blockIdx.y == 0 && i < n) Yr[(size_t)i * qpad + yc] = v;
-            yt[row * YT_LD + col] = dv * v;
+            // raw mode (fit.hip): pad column `ones_col` of the y tile carries the weights themselves, so column ones_col
+            // of X'D[Yc | 1] is the vector of weighted column sums of X — the means come out of the same pass
+            yt[row * YT_LD + col] = (yc == ones_col && i < n) ? d[i] : dv * v;
         }
         // ---- X tile: centre/scale the prefetched registers into LDS (and back into the caller's array)
         if constexpr (V16) {
@@ -418,13 +420,48 @@ __global__ __launch_bounds__(256) void k_reduce_kpart(const double *__restrict__
     K[e] = s;
 }
 
+// raw mode: column `col` of K holds sum_i d_i (x_ij - pivot_j); means = pivot + that, and the sweeps need (means - pivot)
+__global__ __launch_bounds__(256) void k_extract_means(double *__restrict__ K, int qpad, int p, int col, const double *__restrict__ pivot,
+                                                       double *__restrict__ means, double *__restrict__ mshift)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < p) {
+        const double dm = K[(size_t)j * qpad + col];
+        means[j] = pivot[j] + dm;
+        mshift[j] = dm;
+        K[(size_t)j * qpad + col] = 0.0;
+    }
+}
+
+// Pivot of the raw mode: the plain mean of the first (up to) 64 rows of the root rank — any vector within a few standard
+// deviations of the column means will do; it only has to be the SAME on every rank (all-reduced by the caller).
+__global__ __launch_bounds__(256) void k_pivot_rows(const double *__restrict__ Xc, int64_t ldx, int64_t n, int p, int is_root,
+                                                    double *__restrict__ pivot)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    double s = 0.0;
+    const int m = (int)(n < 64 ? n : 64);
+    if (is_root)
+        for (int i = 0; i < m; ++i) s += Xc[(size_t)i + (size_t)j * (size_t)ldx];
+    pivot[j] = is_root ? s / m : 0.0;
+}
+
+int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n, int p, double *pivot)
+{
+    hipLaunchKernelGGL(k_pivot_rows, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, Xc, ldx, n, p, ctx->rank == 0 ? 1 : 0, pivot);
+    JCH_HIP(ctx, hipGetLastError());
+    return jch_allreduce_f64(ctx, pivot, (size_t)p);
+}
+
 int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d, int64_t n,
                               int p, int q, const double *mom, const double *scl, bool writeback, double *Xr, int ldr,
-                              double *Yr, int qpad, double *K, bool scal)
+                              double *Yr, int qpad, double *K, bool scal, double *means_out, double *mshift_out)
 {
+    const int ones_col = means_out ? q : -1;   // raw mode: needs a free pad column in y group 0 (q <= 15) and no v2 kernel
     // measured (cfg2): the 128x32 / 16-B tile is 1.1 ms SLOWER than the 64x64 / 8-B tile (its 256-B row segments are
     // mostly partial 128-B lines); kept behind JCH_K2_V2 for experiments only
-    const bool v2 = (ldx % 2 == 0) && (((uintptr_t)Xc) % 16 == 0) && getenv("JCH_K2_V2");
+    const bool v2 = (ldx % 2 == 0) && (((uintptr_t)Xc) % 16 == 0) && getenv("JCH_K2_V2") && !means_out;
     const int tw = v2 ? 32 : 64, th = v2 ? 128 : 64;   // tile width (columns) / height (rows)
     const int ptiles = (ldr + tw - 1) / tw;
     const int kp_rows = ptiles * tw;
@@ -453,7 +490,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
         // load); the kernel is bound by the LDS transpose + partial-line row stores, not by the load width
         const bool v16 = (ldx % 2 == 0) && (((uintptr_t)Xc) % 16 == 0) && getenv("JCH_K2_V16");
 #define JCH_K2(WB, SC, V) hipLaunchKernelGGL((k_center_xty<WB, SC, V>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
-                                             mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip)
+                                             mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip, ones_col)
 #define JCH_K2D(WB, SC) do { if (v16) JCH_K2(WB, SC, true); else JCH_K2(WB, SC, false); } while (0)
         if (wb_fused && scal) JCH_K2D(true, true);
         else if (wb_fused) JCH_K2D(true, false);
@@ -465,6 +502,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
     hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nslots, kp_rows, p, qpad,
                        K);
     JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
+    if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out);
     JCH_HIP(ctx, hipGetLastError());
     if (writeback)  // Y always, X only when it could not be fused above
         JCH_TRY(jch_launch_export_colmajor(ctx, wb_fused ? nullptr : Xr, ldr, Yr, qpad, n, p, q, Xc, ldx, Yc, ldy));

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     // [zp_raw (bf_ldr), tt, st] slices, turned into [zp, tt] below (zp_j = (zp_raw_j - m_j st) / s_j, bf16.hip header)
     const double *zsrc = g.bf_src ? g.bf_src : g.s.zt;
     const int zld = g.bf_src ? g.bf_ld : g.ldz;
-    const int mz = g.bf_src ? g.bf_ldr + 2 : ldr + 1 + (g.algo == 1 ? 16 : 0);
+    const int mz = g.bf_src ? g.bf_ldr + 2 : ldr + 1 + (g.algo == 1 ? 16 : (g.raw_mu ? 1 : 0));
     if (P2P && g.do_a) {
         const int par = (int)(g.px.epoch & 1ull);
         char *mine = g.px.peer[g.px.rank];
@@ -147,6 +147,10 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         __syncthreads();
         for (int j = tid; j < ldr; j += FT) ztl[j] = j < p ? (ztl[j] - g.s.mom[j] * st_) / g.s.scl[j] : 0.0;
         if (tid == 0) ztl[ldr] = tt_;
+    } else if (g.do_a && g.raw_mu) {   // f64 raw mode (uncentred row copy): zp = zp_raw - mu * st, st = sum_i d_i t_i at [ldr + 1]
+        __syncthreads();
+        const double st_ = ztl[ldr + 1];
+        for (int j = tid; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
     }
     __syncthreads();
     JCH_STAMP(1);
@@ -401,7 +405,7 @@ int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q
     g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.a = a; g.nlv = nlv; g.algo = algo;
     g.do_a = do_a; g.do_b = do_b; g.nslice = nslice; g.ldz = ldz; g.skip = 0; g.tt_from_r = s.variant == 1; g.maxit = 0; g.tol = 0.0;
     g.px = p2p_dev{};
-    g.bf_src = bf_src; g.bf_ld = bf_ld; g.bf_ldr = bf_ldr;
+    g.bf_src = bf_src; g.bf_ld = bf_ld; g.bf_ldr = bf_ldr; g.raw_mu = s.variant == 2;
     const bool fuse = fuse_p2p && do_a;
     if (fuse) jch_p2p_next(ctx, &g.px);
     const size_t lds = jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv);

@@ -25,9 +25,9 @@ template <int KC, int R, bool NIPALS, bool NT, bool PF>
 __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, int64_t n, int ldr,
                                                const double *__restrict__ dw, const double *__restrict__ rvec,
                                                const double *__restrict__ Yr, int qpad, double *__restrict__ tcol,
-                                               double *__restrict__ part, int ldpart)
+                                               double *__restrict__ part, int ldpart, const double *__restrict__ mu)
 {
-    extern __shared__ __attribute__((aligned(16))) double red[];  // [nw][KC*128] + [16] tt + [nw][64] c
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [nw][KC*128] + [16] tt, st + [nw][64] c
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     v2f64 rf[KC], zp[KC];
     bool in[KC];
@@ -38,7 +38,21 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
         rf[k] = in[k] ? *reinterpret_cast<const v2f64 *>(rvec + col) : v2f64{0.0, 0.0};
         zp[k] = v2f64{0.0, 0.0};
     }
-    double tt = 0.0, cacc = 0.0;
+    double tt = 0.0, cacc = 0.0, st = 0.0;
+    // raw mode (mu != null, plskern-shaped fits only): the rows are NOT centred; t = x.r - mu.r, and the caller turns
+    // zp_raw = sum_i d_i t_i x_i into zp = zp_raw - mu * st with st = sum_i d_i t_i (== 0 up to rounding).  Every wave
+    // derives the same offset from the replicated r and means.
+    double off = 0.0;
+    if (mu) {
+        double o = 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (in[k]) {
+                const v2f64 m2 = *reinterpret_cast<const v2f64 *>(mu + 2 * lane + 128 * k);
+                o += m2.x * rf[k].x + m2.y * rf[k].y;
+            }
+        off = jch_wave_sum(o);
+    }
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * nw;
     // PF: the rows (and weights) of the wave's next group are requested before the current group is reduced
@@ -75,10 +89,11 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < KC; ++k) s += x[rr][k].x * rf[k].x + x[rr][k].y * rf[k].y;
-            const double t = jch_wave_sum(s);
+            const double t = jch_wave_sum(s) - off;
             const bool live = row0 + rr < n;
             const double dt = live ? dwc[rr] * t : 0.0;
             tt += dt * t;
+            st += dt;
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 zp[k].x += dt * x[rr][k].x;
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
 #pragma unroll
     for (int k = 0; k < KC; ++k)
         *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * k) = zp[k];
-    if (lane == 0) tred[wv] = tt;
+    if (lane == 0) { tred[wv] = tt; tred[8 + wv] = st; }
     if (NIPALS) cred[wv * 64 + lane] = cacc;
     __syncthreads();
     double *prow = part + (size_t)blockIdx.x * ldpart;
@@ -110,9 +125,10 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
         prow[c] = s;
     }
     if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += tred[w];
+        double s = 0.0, s2 = 0.0;
+        for (int w = 0; w < nw; ++w) { s += tred[w]; s2 += tred[8 + w]; }
         prow[ldr] = s;
+        if (!NIPALS && mu) prow[ldr + 1] = s2;
     }
     if (NIPALS && threadIdx.x < qpad) {
         double s = 0.0;
@@ -187,7 +203,7 @@ int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ld
 template <int KC, int R, bool NT = true, bool PF = false>
 static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                               const double *Yr, int qpad, bool nipals, double *tcol, double *zt, int ldz, int max_slices,
-                              int *nslice_out, int m)
+                              int *nslice_out, int m, const double *mu)
 {
     const int64_t ngroups = (n + R - 1) / R;
     // persistent-style grid: exactly the 256-thread blocks the CUs can hold (register-limited: 146 VGPRs -> 3
@@ -213,10 +229,10 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
     if (nipals)
         hipLaunchKernelGGL((k_sweep<KC, R, true, NT, PF>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
-                           tcol, part, ldpart);
+                           tcol, part, ldpart, mu);
     else
         hipLaunchKernelGGL((k_sweep<KC, R, false, NT, PF>), dim3(nb), dim3(64 * wpb), lds, ctx->stream, Xr, n, ldr, d, rvec, Yr, qpad,
-                           tcol, part, ldpart);
+                           tcol, part, ldpart, mu);
     (void)jch_ev(ctx);  // (end)
     int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
     hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
@@ -232,11 +248,12 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
 
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra, double *tcol, double *zt, int ldz, int max_slices,
-                         int *nslice_out)
+                         int *nslice_out, const double *mu)
 {
     (void)p;
     const bool nip = q_extra > 0;
-    const int m = ldr + 1 + (nip ? qpad : 0);
+    if (mu && (nip || ldr > JCH_SWEEP_MAXP)) return jch_fail(ctx, JCH_EINVAL, "internal: raw-mode sweep is for plskern-shaped fits with p <= %d", JCH_SWEEP_MAXP);
+    const int m = ldr + 1 + (nip ? qpad : (mu ? 1 : 0));
     // Default: software-prefetched kernels with 8 rows x 4 KB (32 KB) per wave in flight ahead of the 32 KB being reduced
     // (measured at cfg2 on one box: R = 4 no prefetch 0.629 ms, R = 8 no prefetch 0.633, R = 8 prefetch 0.605).
     // JCH_SWEEP_PF=0 selects the previous kernels, JCH_SWEEP_R / JCH_SWEEP_NT keep working for the p <= 512 shape.
@@ -244,7 +261,7 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
     if (pfsel < 0) { const char *e = getenv("JCH_SWEEP_PF"); pfsel = e ? atoi(e) : 1; }
     if (rsel < 0) { const char *e = getenv("JCH_SWEEP_R"); rsel = e ? atoi(e) : 0; }
     if (ntsel < 0) { const char *e = getenv("JCH_SWEEP_NT"); ntsel = e ? atoi(e) : 1; }
-#define JCH_SWEEP_CASE(KC, R, NT, PF) return launch_sweep_t<KC, R, NT, PF>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m)
+#define JCH_SWEEP_CASE(KC, R, NT, PF) return launch_sweep_t<KC, R, NT, PF>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m, mu)
     // narrow rows keep the plain kernels: 16 rows per wave-iteration with prefetch were measured 1.5-1.8x SLOWER at
     // p = 100 / 200 (the per-row butterfly dominates); p = 1000: +6.8 % (7.06 TB/s), p = 2000: +1.7 %
     if (ldr <= 128) JCH_SWEEP_CASE(1, 4, true, false);
