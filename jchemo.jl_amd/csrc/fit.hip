@@ -212,8 +212,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     // in a spare pad column, the weighted column sums, i.e. the means (one read of X instead of two, one all-reduce
     // instead of two).  The sweeps then use t_i = x_i.r - mu.r and zp = zp_raw - mu * sum_i d_i t_i (sweep.hip,
     // smallstate_fast.hip); T, P, C, TT, xmeans are the same quantities as in the centred formulation.
-    const bool raw_mode = (algo == ALGO_KERN || algo == ALGO_ROSA) && fast && !d.scal && !ext_scales && !inplace && q <= 15 &&
-                          d.reserved == 0 && !getenv("JCH_CENTRED_COPY");
+    const bool raw_mode = (((algo == ALGO_KERN || algo == ALGO_ROSA) && fast) || algo == ALGO_SIMP) && !d.scal && !ext_scales && !inplace &&
+                          q <= 15 && d.reserved == 0 && !getenv("JCH_CENTRED_COPY");
     if (raw_mode) {
         s.mshift = cv.take((size_t)ldr + 2);
         JCH_HIP(ctx, hipMemsetAsync(s.mshift, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));

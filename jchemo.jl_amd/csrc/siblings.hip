@@ -130,7 +130,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_simp(lvf_args g)
     for (int e = tid; e < 5 * QP * lda; e += FT) G0[e] = 0.0;
     if (tid < 32) cl[tid] = 0.0;
     if (g.do_a) {
-        for (int c = tid; c < ldr + 1; c += FT) {
+        for (int c = tid; c < ldr + 1 + (g.raw_mu ? 1 : 0); c += FT) {
             double s = 0.0;
             if (g.nslice == 1) s = g.s.zt[c];
             else
@@ -140,6 +140,11 @@ __global__ __launch_bounds__(FT) void k_lv_update_simp(lvf_args g)
         for (int j = tid; j < ldr; j += FT) rl[j] = g.s.r[j];
     }
     __syncthreads();
+    if (g.do_a && g.raw_mu) {   // raw mode (fit.hip): the sweep ran on rows minus the pivot; zp = zp_raw - (mu - pivot) * st
+        const double st_ = ztl[ldr + 1];
+        for (int j = tid; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
+        __syncthreads();
+    }
     if (g.do_a) {
         const double tt = ztl[ldr];
         {
@@ -396,6 +401,7 @@ int32_t jch_launch_lv_update_simp(jch_ctx *ctx, const jch_small &s, int p, int q
 {
     lvf_args g{};
     g.s = s; g.p = p; g.q = q; g.qpad = 16; g.ldr = ldr; g.nlv = nlv; g.algo = 2; g.nslice = nslice; g.ldz = ldz;
+    g.raw_mu = s.variant == 2;
     if (a < 0) { g.a = 0; g.do_a = 0; g.do_b = 1; }
     else { g.a = a; g.do_a = 1; g.do_b = a + 1 < nlv ? 1 : 0; }
     const size_t lds = sib_lds_bytes(p, q, ldr, nlv);
