@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--algo", choices=["plskern", "plsnipals", "plskern2", "plssimp", "plsrosa", "plswold"], default="plskern",
                     help="plskern2 = opt-in kernel algorithm #2 (Gram once; not the reference's algorithm, never the headline)")
     ap.add_argument("--dtype", choices=["f64", "bf16"], default="f64", help="bf16 = storage mode of BASELINE configs[2]")
+    ap.add_argument("--scal", action="store_true", help="scale the columns by their stds (scal = true; not the headline configuration)")
     ap.add_argument("--cpu-sample-rows", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -170,7 +171,7 @@ def main():
     P = np.zeros((p, kmax), order="F"); R = np.zeros((p, kmax), order="F"); W = np.zeros((p, kmax), order="F")
     Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
     xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
-    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0,
+    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=int(args.scal), dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0,
                         reserved=1 if args.algo == "plskern2" else 0)
     got = C.c_int32(0)
     entry = {"plsnipals": lib.jch_plsnipals_fit, "plssimp": lib.jch_plssimp_fit, "plsrosa": lib.jch_plsrosa_fit}.get(args.algo, lib.jch_plskern_fit)
@@ -247,7 +248,7 @@ def main():
             "metric": f"latent-variables/sec ({args.algo} n={n_total:.0e} p={p} q={q} nlv={nlv})".replace("e+0", "e"),
             "value": value, "unit": "LV/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": value / README_PLSKERN_LVS if (args.algo == "plskern" and not bf16 and (n_total, p, q, nlv) == (1_000_000, 500, 10, 25)) else None,
+            "vs_baseline": value / README_PLSKERN_LVS if (args.algo == "plskern" and not bf16 and not args.scal and (n_total, p, q, nlv) == (1_000_000, 500, 10, 25)) else None,
             "dtype": "bf16 storage / f32 rows / f64 state" if bf16 else "f64", "data": "synthetic",
             "config": {"workload": f"{args.algo} n={n_total} p={p} q={q} nlv={nlv} {'bf16-stored' if bf16 else 'Float64'} "
                                    f"({'BASELINE.json configs[1]' if (args.algo, n_total, p, q, nlv, bf16) == ('plskern', 1000000, 500, 10, 25, False) else 'variant'}), "

@@ -123,7 +123,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
     const size_t small_bytes = 256 * 16 + sizeof(double) * ((size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
-                                                         (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + (size_t)ldr + 64);
+                                                         (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
@@ -133,7 +133,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap);
     s.mom = cv.take(p + q); s.scl = cv.take(p + q);
     double *niter_dev = cv.take(nlv_cap);
-    s.mshift = nullptr;
+    s.mshift = nullptr; s.rs = nullptr;
     const size_t out_bytes = (size_t)((char *)(niter_dev + nlv_cap) - (char *)s.P);
     s.Z = cv.take((size_t)nlv_cap * 16);
     const int ldz = (ldr + 1 + qpad + 7) & ~7;
@@ -212,8 +212,9 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     // in a spare pad column, the weighted column sums, i.e. the means (one read of X instead of two, one all-reduce
     // instead of two).  The sweeps then use t_i = x_i.r - mu.r and zp = zp_raw - mu * sum_i d_i t_i (sweep.hip,
     // smallstate_fast.hip); T, P, C, TT, xmeans are the same quantities as in the centred formulation.
-    const bool raw_mode = (((algo == ALGO_KERN || algo == ALGO_ROSA) && fast) || algo == ALGO_SIMP) && !d.scal && !ext_scales && !inplace &&
-                          q <= 15 && d.reserved == 0 && !getenv("JCH_CENTRED_COPY");
+    const bool raw_mode = (((algo == ALGO_KERN || algo == ALGO_ROSA) && fast) || algo == ALGO_SIMP) && !ext_scales && !inplace &&
+                          q <= 15 && d.reserved == 0 && p <= JCH_SWEEP_MAXP && !getenv("JCH_CENTRED_COPY") &&
+                          !(d.scal && getenv("JCH_CENTRED_COPY_SCAL"));
     if (raw_mode) {
         s.mshift = cv.take((size_t)ldr + 2);
         JCH_HIP(ctx, hipMemsetAsync(s.mshift, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));
@@ -224,6 +225,11 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
                                       /*means_out =*/s.mom, /*mshift_out =*/s.mshift));
         JCH_HIP(ctx, hipMemcpyAsync(s.mom + p, s.scl + p, sizeof(double) * (size_t)q, hipMemcpyDeviceToDevice, ctx->stream));
         hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
+        if (d.scal) {   // stds from ONE streaming pass over the row-major copy; the scaling itself is folded into r / s and zp / s
+            s.rs = cv.take((size_t)ldr + 2);
+            JCH_HIP(ctx, hipMemsetAsync(s.rs, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));
+            JCH_TRY(jch_launch_raw_scales(ctx, Xr, n, p, ldr, dn, s.mshift, Yr, qpad, q, s.zt, s.scl, s.K));
+        }
         s.variant = 2;
     } else {
     JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
@@ -262,7 +268,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (kern_like) {
-            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice, raw_mode ? s.mshift : nullptr));
+            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.rs ? s.rs : s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice, raw_mode ? s.mshift : nullptr));
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;   // rank-independent message size (a small shard may use 1 slice; the rest hold zeros)
             // ONE collective per LV: [zp (p), tt].  With the inbox transport and the fast small-state kernel it happens
             // INSIDE that kernel (no launch of its own); otherwise here (RCCL / inbox kernel / loopback).

@@ -132,6 +132,8 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
                          double *tcol, double *zt /*[nslice][ldz] device, reduced over blocks*/, int ldz, int max_slices,
                          int *nslice_out, const double *mu = nullptr /*raw mode: Xr is uncentred; t = x.r - mu.r, st at [ldr+1]*/);
 int32_t jch_launch_reduce_rows(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *out);
+int32_t jch_launch_raw_scales(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *mshift,
+                              const double *Yr, int qpad, int q, double *tmp, double *scl, double *K);
 int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *zt, int ldz, int *nslice_out);
 int32_t jch_launch_sweep_wide(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                               const double *Yr, int qpad, bool nipals, double *tcol, double *zt);
@@ -150,6 +152,7 @@ struct jch_small {  // device-resident replicated small state of one fit
     double *zpc;        // [ldr + qpad]      plsnipals: zp/tt, c/tt
     double *mom, *scl;  // [p+q]
     double *mshift;     // [ldr] raw mode: means - pivot (the stored rows are x - pivot); null otherwise
+    double *rs;         // [ldr] raw mode with scaling: r / xscales, the vector the sweep multiplies the unscaled rows with; null otherwise
     double *hdr;        // [4]
     int variant;        // 0: algorithm #1 (zt holds [zp, tt] from the sweep); 1: algorithm #2 (zt = G r, tt = r'zp computed here);
                         // 2: algorithm #1 in raw mode (uncentred row copy: zt holds [zp_raw, tt, st], zp = zp_raw - mom * st)

@@ -73,7 +73,7 @@ __device__ __forceinline__ void gram_lds(const double *Kl, int p, int q, double 
 // w = K v / ||K v|| for the QP-vector v in LDS; written to both s.w and s.r (no r-recursion in these algorithms)
 template <int QP>
 __device__ __forceinline__ void write_w_from_v(const double *Kl, const double *vl, int p, int ldr, double *scratch,
-                                               double *w_out, double *r_out)
+                                               double *w_out, double *r_out, double *rs_out = nullptr, const double *scl = nullptr)
 {
     constexpr int ldk = QP | 1;
     const int tid = threadIdx.x;
@@ -97,6 +97,7 @@ __device__ __forceinline__ void write_w_from_v(const double *Kl, const double *v
             const double wn = j < p ? wr[it] * inv : 0.0;
             w_out[j] = wn;
             r_out[j] = wn;
+            if (rs_out) rs_out[j] = j < p ? wn / scl[j] : 0.0;
         }
     }
 }
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(FT) void k_lv_update_simp(lvf_args g)
     __syncthreads();
     if (g.do_a && g.raw_mu) {   // raw mode (fit.hip): the sweep ran on rows minus the pivot; zp = zp_raw - (mu - pivot) * st
         const double st_ = ztl[ldr + 1];
-        for (int j = tid; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
+        if (g.s.rs) { for (int j = tid; j < p; j += FT) ztl[j] = (ztl[j] - g.s.mshift[j] * st_) / g.s.scl[j]; }
+        else for (int j = tid; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
         __syncthreads();
     }
     if (g.do_a) {
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_simp(lvf_args g)
         vl[0] = 1.0;
     }
     __syncthreads();
-    write_w_from_v<QP>(Kl, vl, p, ldr, scratch, g.s.w, g.s.r);
+    write_w_from_v<QP>(Kl, vl, p, ldr, scratch, g.s.w, g.s.r, g.s.rs, g.s.scl);
 }
 
 // ------------------------------------------------------------------------------------------- Wold NIPALS

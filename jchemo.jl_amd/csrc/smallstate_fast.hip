@@ -150,7 +150,8 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     } else if (g.do_a && g.raw_mu) {   // f64 raw mode (uncentred row copy): zp = zp_raw - mu * st, st = sum_i d_i t_i at [ldr + 1]
         __syncthreads();
         const double st_ = ztl[ldr + 1];
-        for (int j = tid; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
+        if (g.s.rs) { for (int j = tid; j < p; j += FT) ztl[j] = (ztl[j] - g.s.mshift[j] * st_) / g.s.scl[j]; }
+        else for (int j = tid; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
     }
     __syncthreads();
     JCH_STAMP(1);
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             }
             g.s.w[j] = wn;
             g.s.r[j] = rn;
+            if (g.s.rs) g.s.rs[j] = j < p ? rn / g.s.scl[j] : 0.0;
         }
     }
     JCH_STAMP(15);

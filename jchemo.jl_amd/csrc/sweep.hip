@@ -189,6 +189,112 @@ int32_t jch_launch_reduce_rows(jch_ctx *ctx, const double *part, int nb, int ldp
     return JCH_OK;
 }
 
+// Raw mode with scaling: weighted second moments about the means of the pivot-shifted row-major copy, one streaming
+// pass: out[j] = sum_i d_i (z_ij - m_j)^2 for j < ldr (m = means - pivot), out[ldr + k] = sum_i d_i yc_ik^2 for k < 16
+// (two-pass variance like utility.jl:314-323: the means are known).  Same wave/row layout as k_sweep.
+template <int KC, int R>
+__global__ __launch_bounds__(256) void k_rowvar(const double *__restrict__ Xr, int64_t n, int ldr, const double *__restrict__ dw,
+                                                const double *__restrict__ mshift, const double *__restrict__ Yr, int qpad,
+                                                double *__restrict__ part, int ldpart)
+{
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [4][KC*128] + [4][64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v2f64 mf[KC], acc[KC];
+    bool in[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 2 * lane + 128 * k;
+        in[k] = col < ldr;
+        mf[k] = in[k] ? *reinterpret_cast<const v2f64 *>(mshift + col) : v2f64{0.0, 0.0};
+        acc[k] = v2f64{0.0, 0.0};
+    }
+    double yacc = 0.0;
+    const int64_t ngroups = (n + R - 1) / R;
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wv; g < ngroups; g += gstride) {
+        const int64_t row0 = g * R;
+        v2f64 x[R][KC];
+        double dv[R], yv[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const bool live = row0 + rr < n;
+            const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xr + (size_t)(row0 + rr) * (size_t)ldr) + lane;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) x[rr][k] = (live && in[k]) ? __builtin_nontemporal_load(rp + 64 * k) : mf[k];
+            dv[rr] = live ? dw[row0 + rr] : 0.0;
+            yv[rr] = (live && lane < qpad && lane < 16) ? Yr[(size_t)(row0 + rr) * qpad + lane] : 0.0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const double a = x[rr][k].x - mf[k].x, b = x[rr][k].y - mf[k].y;
+                acc[k].x += dv[rr] * a * a;
+                acc[k].y += dv[rr] * b * b;
+            }
+            yacc += dv[rr] * yv[rr] * yv[rr];
+        }
+    }
+    double *zred = red, *yred = red + 4 * KC * 128;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * k) = acc[k];
+    yred[wv * 64 + lane] = yacc;
+    __syncthreads();
+    double *prow = part + (size_t)blockIdx.x * ldpart;
+    for (int c = threadIdx.x; c < ldr; c += 256)
+        prow[c] = ((zred[c] + zred[KC * 128 + c]) + zred[2 * KC * 128 + c]) + zred[3 * KC * 128 + c];
+    if (threadIdx.x < 16) prow[ldr + threadIdx.x] = ((yred[threadIdx.x] + yred[64 + threadIdx.x]) + yred[128 + threadIdx.x]) + yred[192 + threadIdx.x];
+}
+
+// sqrt of the reduced second moments -> divisors; out_scl[0..p) x, out_scl[p..p+q) y
+__global__ __launch_bounds__(256) void k_var_to_scale(const double *__restrict__ v, int ldr, int p, int q, double *__restrict__ scl)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < p) scl[j] = sqrt(v[j]);
+    else if (j < p + q) scl[j] = sqrt(v[ldr + (j - p)]);
+}
+
+// K[j][k] /= sx_j * sy_k
+__global__ __launch_bounds__(256) void k_scale_K(double *__restrict__ K, int qpad, int p, int q, const double *__restrict__ scl)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p * qpad) return;
+    const int j = e / qpad, k = e - j * qpad;
+    if (k < q) K[e] /= scl[j] * scl[p + k];
+}
+
+template <int KC, int R>
+static int32_t launch_rowvar_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *mshift,
+                               const double *Yr, int qpad, double *out /*[ldr + 16] device*/)
+{
+    const size_t lds = sizeof(double) * (4 * KC * 128 + 256);
+    const int64_t ngroups = (n + R - 1) / R;
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * 3));
+    const int m = ldr + 16, ldpart = (m + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
+    double *part = (double *)ctx->part.ptr;
+    hipLaunchKernelGGL((k_rowvar<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, mshift, Yr, qpad, part, ldpart);
+    JCH_HIP(ctx, hipGetLastError());
+    return jch_launch_reduce_rows(ctx, part, nb, ldpart, m, out);
+}
+
+// raw mode, scal = true: scl <- weighted uncorrected stds of X (about the means) and Y; K <- K / (sx sy')
+int32_t jch_launch_raw_scales(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *mshift,
+                              const double *Yr, int qpad, int q, double *tmp /*[ldr + 16] device*/, double *scl, double *K)
+{
+    if (ldr <= 128) JCH_TRY((launch_rowvar_t<1, 4>(ctx, Xr, n, ldr, d, mshift, Yr, qpad, tmp)));
+    else if (ldr <= 256) JCH_TRY((launch_rowvar_t<2, 4>(ctx, Xr, n, ldr, d, mshift, Yr, qpad, tmp)));
+    else if (ldr <= 512) JCH_TRY((launch_rowvar_t<4, 4>(ctx, Xr, n, ldr, d, mshift, Yr, qpad, tmp)));
+    else if (ldr <= 1024) JCH_TRY((launch_rowvar_t<8, 2>(ctx, Xr, n, ldr, d, mshift, Yr, qpad, tmp)));
+    else if (ldr <= 2048) JCH_TRY((launch_rowvar_t<16, 1>(ctx, Xr, n, ldr, d, mshift, Yr, qpad, tmp)));
+    else return jch_fail(ctx, JCH_EINVAL, "internal: raw-mode scales need p <= %d", JCH_SWEEP_MAXP);
+    JCH_TRY(jch_allreduce_f64(ctx, tmp, (size_t)ldr + 16));
+    hipLaunchKernelGGL(k_var_to_scale, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, tmp, ldr, p, q, scl);
+    hipLaunchKernelGGL(k_scale_K, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, q, scl);
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
 // Stage 1 of the fixed-order reduction for callers that keep the slices (bf16 path): always writes JCH_ZT_SLICES slices
 // (unused ones zero); *nslice_out = 1 when only slice 0 is populated.
 int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *zt, int ldz, int *nslice_out)

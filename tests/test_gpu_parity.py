@@ -859,8 +859,9 @@ def test_mbplsr(bscal, scal, J, ctx):
         J.mbplsr(Xbl, Y, nlv=2, bscal="mfa", ctx=ctx)
 
 
+@pytest.mark.parametrize("scal", [False, True])
 @pytest.mark.parametrize("offset", [0.0, 1e4])
-def test_raw_mode_matches_centred_copy(offset, J, ctx, monkeypatch):
+def test_raw_mode_matches_centred_copy(offset, scal, J, ctx, monkeypatch):
     """plskern without scaling keeps an UNCENTRED row-major copy and folds the centring into the sweeps (fit.hip, raw
     mode); JCH_CENTRED_COPY=1 selects the centred-copy formulation.  Both must agree with the oracle, also when the column
     means dwarf the spread (offset 1e4, spread 0.3: the input itself then carries only ~1e-12 relative precision)."""
@@ -870,12 +871,13 @@ def test_raw_mode_matches_centred_copy(offset, J, ctx, monkeypatch):
     X = np.asfortranarray(0.3 * (Lt @ rng.standard_normal((8, p))) + 0.1 * rng.standard_normal((n, p)) + offset)
     Y = np.asfortranarray(Lt[:, :3] @ rng.standard_normal((3, q)) + 0.1 * rng.standard_normal((n, q)) + offset / 7)
     w = rng.uniform(0.5, 1.5, n)
-    ref = O.plskern(X, Y, w, nlv=nlv)
+    X[:, 5] *= 40.0; X[:, 7] *= 0.01                       # very different column spreads (matters when scal = true)
+    ref = O.plskern(X, Y, w, nlv=nlv, scal=scal)
     tol = 1e-9 if offset == 0.0 else 1e-7
-    raw = J.plskern(X, Y, w, nlv=nlv, ctx=ctx)
+    raw = J.plskern(X, Y, w, nlv=nlv, scal=scal, ctx=ctx)
     _cmp(ref, raw, tol=tol)
     monkeypatch.setenv("JCH_CENTRED_COPY", "1")
-    cen = J.plskern(X, Y, w, nlv=nlv, ctx=ctx)
+    cen = J.plskern(X, Y, w, nlv=nlv, scal=scal, ctx=ctx)
     _cmp(ref, cen, tol=tol)
     s = O.sign_align(raw.W, cen.W)
     assert O.rel_fro(raw.T, cen.T * s) < tol and O.rel_fro(raw.xmeans, cen.xmeans) < 1e-13
