@@ -21,3 +21,6 @@ for a in plssimp plsrosa plswold; do python bench.py --algo $a --steps 5 --warmu
 python tools/p2p_cost.py 2>/dev/null | tail -1 > gpurun_out/final/p2p_cost.json
 python bench.py --rows 125000 --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/final/bench_rank_share_125k.json 2>/dev/null
 ls -la gpurun_out/final
+python bench.py --scal --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_scal.json 2>/dev/null
+python tools/raw_mode_error.py > gpurun_out/final/raw_mode_error.log 2>/dev/null
+python tools/small_fit_latency.py 2>/dev/null | tail -1 > gpurun_out/final/small_fit_latency.json
