@@ -58,8 +58,7 @@ __global__ __launch_bounds__(256) void k_moments_bf16(const bf16_t *__restrict__
 // 16-byte variant of K1: a thread owns 8 consecutive rows (one 16-B load per column, the 8 weights stay in registers)
 // and walks over MCG columns, so the weight vector is read once per MCG columns instead of once per column (it is 4x
 // the bytes of a bf16 column) and every global access is 16 B.  Needs 16-B aligned bases and leading dimensions % 8.
-#define MCG 16
-template <bool VAR>
+template <bool VAR, int MCG>
 __global__ __launch_bounds__(256) void k_moments_bf16_v8(const bf16_t *__restrict__ Xc, int64_t ldx, const bf16_t *__restrict__ Yc,
                                                           int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                           int64_t chunk, const double *__restrict__ means,
@@ -143,14 +142,19 @@ static int32_t launch_moments_bf16(jch_ctx *ctx, const bf16_t *Xc, int64_t ldx, 
     const bool v8 = ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && ((uintptr_t)Yc) % 16 == 0 && ((uintptr_t)d) % 16 == 0 &&
                     !getenv("JCH_BF16_SCALAR_PROLOGUE");
     if (v8) {
-        const int cg = (m + MCG - 1) / MCG;
+        static int mcg = -1;
+        if (mcg < 0) { const char *e = getenv("JCH_BF16_MCG"); mcg = e ? atoi(e) : 8; }   // measured: 16 / 8 / 4 columns per thread -> prologue 1.40 / 1.27 / 1.29 ms at n = 1e6, p = 500
+        const int MCGv = mcg == 4 ? 4 : (mcg == 16 ? 16 : 8);
+        const int cg = (m + MCGv - 1) / MCGv;
         int S = std::max(1, (ctx->cus * 8 + cg - 1) / cg);
         int64_t chunk = ((n + S - 1) / S + 2047) / 2048 * 2048;      // multiple of 8 rows x 256 threads
         S = (int)std::max<int64_t>(1, (n + chunk - 1) / chunk);
         JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * ((size_t)S * m + 4096)));
         double *colpart = (double *)ctx->colpart.ptr;
-        if (means) hipLaunchKernelGGL(k_moments_bf16_v8<true>, dim3(cg, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk, means, colpart);
-        else hipLaunchKernelGGL(k_moments_bf16_v8<false>, dim3(cg, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk, means, colpart);
+#define JCH_K1B(V, M) hipLaunchKernelGGL((k_moments_bf16_v8<V, M>), dim3(cg, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk, means, colpart)
+        if (means) { if (MCGv == 4) JCH_K1B(true, 4); else if (MCGv == 8) JCH_K1B(true, 8); else JCH_K1B(true, 16); }
+        else { if (MCGv == 4) JCH_K1B(false, 4); else if (MCGv == 8) JCH_K1B(false, 8); else JCH_K1B(false, 16); }
+#undef JCH_K1B
         hipLaunchKernelGGL(k_colreduce_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, colpart, S, m, out);
         JCH_TRY(jch_allreduce_f64(ctx, out, (size_t)m));
         if (means) hipLaunchKernelGGL(k_sqrt_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, out, m);
