@@ -41,7 +41,9 @@ def main():
         Xd = J.colmajor_empty(b - a, X.shape[1], dtype=torch.bfloat16); Xd.copy_(torch.from_numpy(Xs))
         Yd = J.colmajor_empty(b - a, Y.shape[1], dtype=torch.bfloat16); Yd.copy_(torch.from_numpy(Ys))
         Xs, Ys, ws = Xd, Yd, torch.from_numpy(ws).cuda()
-    fms = [getattr(J, name)(Xs, Ys, ws, nlv=nlv, scal=True, ctx=ctx, **kw) for _ in range(3)]   # repeated: epochs keep in step
+    reps = int(os.environ.get("JCH_P2P_TEST_REPS", "3"))
+    fms = [getattr(J, name)(Xs, Ys, ws, nlv=nlv, scal=True, ctx=ctx, **kw) for _ in range(reps)]   # repeated: epochs keep in step
+    assert all(np.array_equal(fms[0].P, f.P) and np.array_equal(fms[0].TT, f.TT) for f in fms[1:]), "fits differ from call to call"
     fm = fms[-1]
     T = fm.T.cpu().numpy() if hasattr(fm.T, "cpu") else fm.T
     wn = fm.weights.cpu().numpy() if hasattr(fm.weights, "cpu") else fm.weights

@@ -21,9 +21,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("alg", ["plskern", "plsnipals", "plskern_v2", "plskern_bf16"])
-def test_p2p_inbox_three_processes(alg, tmp_path):
-    world = 3
+@pytest.mark.parametrize("alg,world,reps", [("plskern", 3, 3), ("plsnipals", 3, 3), ("plskern_v2", 3, 3), ("plskern_bf16", 3, 3),
+                                            ("plskern", 4, 150)])   # last: stress of the epoch / parity protocol (~3000 all-reduces per rank)
+def test_p2p_inbox_three_processes(alg, world, reps, tmp_path):
     n, p, q, nlv = 5000, 150, 3, 6
     rng = np.random.default_rng(21)
     Lt = rng.standard_normal((n, 2 * nlv))
@@ -34,10 +34,10 @@ def test_p2p_inbox_three_processes(alg, tmp_path):
         import torch
         X = torch.from_numpy(X).to(torch.bfloat16).to(torch.float64).numpy()
         Y = torch.from_numpy(Y).to(torch.bfloat16).to(torch.float64).numpy()
-    edges = np.array([0, 1700, 1704, n])          # one shard smaller than nlv
+    edges = np.array([0, 1700, 1704, n]) if world == 3 else np.array([0, 1200, 1204, 3100, n])   # one shard smaller than nlv
     np.savez(tmp_path / "inputs.npz", X=X, Y=Y, w=w, edges=edges, nlv=nlv)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
-               JCH_P2P_TIMEOUT_MS="20000")
+               JCH_P2P_TIMEOUT_MS="20000", JCH_P2P_TEST_REPS=str(reps))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(tmp_path), alg],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
