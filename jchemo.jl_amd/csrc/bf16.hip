@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_center_xty_bf16_v8(const bf16_t *__rest
                                                              int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                              const double *__restrict__ mom, const double *__restrict__ scl,
                                                              bf16_t *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
-                                                             double *__restrict__ Kpart, int kp_rows)
+                                                             double *__restrict__ Kpart, int kp_rows, int ones_col)
 {
     __shared__ double xt[64 * XT_LD];
     __shared__ double yt[64 * YT_LD];
@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void k_center_xty_bf16_v8(const bf16_t *__rest
                 dv = dreg[k];
             }
             if (blockIdx.y == 0 && i < n) Yr[(size_t)i * qpad + yc] = v;
-            yt[row * YT_LD + col] = dv * v;
+            // raw mode: pad column `ones_col` carries the weights -> column ones_col of X'D[Yc | 1] = sum_i d_i (x_i - pivot)
+            yt[row * YT_LD + col] = (yc == ones_col && i < n) ? d[i] : dv * v;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -594,6 +595,25 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
     return JCH_OK;
 }
 
+// raw prologue helpers: pivot = plain mean of the root rank's first (<= 64) rows; means = pivot + K[:, col]
+__global__ __launch_bounds__(256) void k_pivot_rows_bf16(const bf16_t *__restrict__ Xc, int64_t ldx, int64_t n, int p, int is_root,
+                                                         double *__restrict__ pivot)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    double s = 0.0;
+    const int m = (int)(n < 64 ? n : 64);
+    if (is_root)
+        for (int i = 0; i < m; ++i) s += (double)bf2f(Xc[(size_t)i + (size_t)j * (size_t)ldx]);
+    pivot[j] = is_root ? s / m : 0.0;
+}
+__global__ __launch_bounds__(256) void k_extract_means_b(double *__restrict__ K, int qpad, int p, int col, const double *__restrict__ pivot,
+                                                         double *__restrict__ means)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < p) { means[j] = pivot[j] + K[(size_t)j * qpad + col]; K[(size_t)j * qpad + col] = 0.0; }
+}
+
 // ---------------------------------------------------------------- orchestration (called from fit.hip)
 int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv, int64_t ldx, const void *Yv, int64_t ldy,
                              const double *wdev, double *dn, double *Tdev, jch_small &s, int ldr_small, int qpad, int ldz,
@@ -620,9 +640,20 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         n_total = (int64_t)(hdr_h[1] + 0.5);
     }
     const int nlv = (int)std::min<int64_t>(std::min<int64_t>(n_total, p), d.nlv);
+    // RAW prologue (no scaling, 16-byte kernels, q <= 15): as in the f64 path (fit.hip) the means pass over X is dropped —
+    // K2 subtracts a pivot (mean of the root rank's first rows) instead of the means and multiplies against [Yc | 1], so
+    // the means come out of the XtY pass: mu = pivot + K[:, q].
+    const bool raw_b = !d.scal && q <= 15 && ldx % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && !getenv("JCH_BF16_SCALAR_PROLOGUE") &&
+                       !getenv("JCH_CENTRED_COPY");
+    if (raw_b) {
+        hipLaunchKernelGGL(k_pivot_rows_bf16, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, Xc, ldx, n, p, ctx->rank == 0 ? 1 : 0, s.scl);
+        JCH_TRY(jch_allreduce_f64(ctx, s.scl, (size_t)p));
+        JCH_TRY(launch_moments_bf16(ctx, Yc, ldy, Yc, ldy, dn, n, q, 0, nullptr, s.scl + p));   // Y means -> scl[p..p+q)
+    } else {
     JCH_TRY(launch_moments_bf16(ctx, Xc, ldx, Yc, ldy, dn, n, p, q, nullptr, s.mom));
     if (d.scal) JCH_TRY(launch_moments_bf16(ctx, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom, s.scl));
     else hipLaunchKernelGGL(k_fill_b, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
+    }
     {
         const int ptiles = (ldr_b + 63) / 64, kp_rows = ptiles * 64, ygroups = qpad / 16;
         const int64_t nchunks = (n + 63) / 64;
@@ -633,15 +664,20 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         dim3 grid(nbx, ptiles, ygroups);
         const bool v8 = ldx % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && !getenv("JCH_BF16_SCALAR_PROLOGUE");
         if (v8 && d.scal) hipLaunchKernelGGL(k_center_xty_bf16_v8<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
-                                             s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
-        else if (v8) hipLaunchKernelGGL(k_center_xty_bf16_v8<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
-                                        s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
+                                             s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows, -1);
+        else if (v8) hipLaunchKernelGGL(k_center_xty_bf16_v8<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q,
+                                        raw_b ? s.scl : s.mom, s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows, raw_b ? q : -1);
         else if (d.scal) hipLaunchKernelGGL(k_center_xty_bf16<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
                                        s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
         else hipLaunchKernelGGL(k_center_xty_bf16<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
                                 s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
         hipLaunchKernelGGL(k_reduce_kpart_b, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad, s.K);
         JCH_TRY(jch_allreduce_f64(ctx, s.K, (size_t)p * qpad));
+        if (raw_b) {   // means = pivot + K[:, q]; Y means next to them; divisors = 1
+            hipLaunchKernelGGL(k_extract_means_b, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, s.K, qpad, p, q, s.scl, s.mom);
+            JCH_HIP(ctx, hipMemcpyAsync(s.mom + p, s.scl + p, sizeof(double) * (size_t)q, hipMemcpyDeviceToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_fill_b, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
+        }
     }
     (void)jch_ev(ctx);  // end of prologue
     ctx->ev_mark = ctx->ev_used;  // (begin, end) event pairs of the sweeps start here
