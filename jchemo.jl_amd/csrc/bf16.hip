@@ -257,24 +257,21 @@ __global__ __launch_bounds__(256) void k_center_xty_bf16_v8(const bf16_t *__rest
                                                              int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                              const double *__restrict__ mom, const double *__restrict__ scl,
                                                              bf16_t *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
-                                                             double *__restrict__ Kpart, int kp_rows, int ones_col)
+                                                             double *__restrict__ Kpart, int kp_rows, int ones_col, int dbg_skip)
 {
-    __shared__ double xt[64 * XT_LD];
     __shared__ double yt[64 * YT_LD];
-    // raw bf16 tile, COLUMN-major [col][XR_LD rows]: a lane's 8 consecutive rows of one column go in with one 16-B store
-    // (row-major 2-B stores hit 8 banks with 64 lanes); the row-major output gathers 8 columns of one row, conflict-free
+    // The X tile lives in LDS as RAW bf16 only, COLUMN-major [col][XR_LD rows] (9 KB instead of a 33 KB fp64 tile: 8 blocks per
+    // CU instead of 3; a 256-row tile — 512-B column runs, 2 blocks per CU — was measured 0.11 ms SLOWER): a lane's 8 consecutive rows of one column go in with one 16-B store, the row-major output gathers 8
+    // columns of one row, and the MFMA A-operand is converted to fp64 and centred when it is read (all conflict-free).
     __shared__ __attribute__((aligned(16))) bf16_t xraw[64 * XR_LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j0 = blockIdx.y * 64, yg = blockIdx.z;
     const int64_t nchunks = (n + 63) / 64;
     const int rg = lane & 7, cl = lane >> 3;          // load role: rows 8 rg .. 8 rg + 7 of column (2 wv + k) * 8 + cl
-    double cm[2], cs[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int j = j0 + (2 * wv + k) * 8 + cl;
-        cm[k] = j < p ? mom[j] : 0.0;
-        cs[k] = (SCAL && j < p) ? scl[j] : 1.0;
-    }
+    // MFMA role of this lane: X column j0 + 16 wv + (lane & 15), rows 4 kk + (lane >> 4)
+    const int ja = j0 + 16 * wv + (lane & 15);
+    const double cma = ja < p ? mom[ja] : 0.0;
+    const double csa = (SCAL && ja < p) ? scl[ja] : 1.0;
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
     // software pipeline: the global loads of chunk c + gridDim.x are in flight while chunk c is transposed / multiplied
     v4u32 xw[2];
@@ -328,28 +325,12 @@ __global__ __launch_bounds__(256) void k_center_xty_bf16_v8(const bf16_t *__rest
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int col = (2 * wv + k) * 8 + cl, j = j0 + col;
-            const int64_t i = i0 + 8 * rg;
-            bf16_t raw[8];
-            {
-                const v4u32 w = xw[k];
-                raw[0] = (bf16_t)(w.x & 0xffffu); raw[1] = (bf16_t)(w.x >> 16); raw[2] = (bf16_t)(w.y & 0xffffu); raw[3] = (bf16_t)(w.y >> 16);
-                raw[4] = (bf16_t)(w.z & 0xffffu); raw[5] = (bf16_t)(w.z >> 16); raw[6] = (bf16_t)(w.w & 0xffffu); raw[7] = (bf16_t)(w.w >> 16);
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                double v = 0.0;
-                if (j < p && i + r < n) {
-                    v = (double)bf2f(raw[r]) - cm[k];
-                    if (SCAL) v /= cs[k];
-                }
-                xt[(8 * rg + r) * XT_LD + col] = v;
-            }
+            const int col = (2 * wv + k) * 8 + cl;
             *reinterpret_cast<v4u32 *>(xraw + col * XR_LD + 8 * rg) = xw[k];
         }
         __syncthreads();
         if (c + gridDim.x < nchunks) prefetch(c + gridDim.x);
-        if (yg == 0) {
+        if (yg == 0 && !(dbg_skip & 2)) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int row = (2 * wv + k) * 8 + (lane >> 3), cg = lane & 7;
@@ -367,8 +348,12 @@ __global__ __launch_bounds__(256) void k_center_xty_bf16_v8(const bf16_t *__rest
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int row = 4 * kk + (lane >> 4);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[row * XT_LD + 16 * wv + (lane & 15)], yt[row * YT_LD + (lane & 15)], acc,
-                                                       0, 0, 0);
+            double a = 0.0;
+            if (ja < p && i0 + row < n) {
+                a = (double)bf2f(xraw[(16 * wv + (lane & 15)) * XR_LD + row]) - cma;
+                if (SCAL) a /= csa;
+            }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, yt[row * YT_LD + (lane & 15)], acc, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -657,16 +642,20 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     {
         const int ptiles = (ldr_b + 63) / 64, kp_rows = ptiles * 64, ygroups = qpad / 16;
         const int64_t nchunks = (n + 63) / 64;
-        int nbx = std::max(1, (ctx->cus * 3 + ptiles * ygroups - 1) / (ptiles * ygroups));
+        static int k2skip = -1;
+        if (k2skip < 0) { const char *e = getenv("JCH_K2_SKIP"); k2skip = e ? atoi(e) : 0; }
+        static int k2bpc = -1;
+        if (k2bpc < 0) { const char *e = getenv("JCH_BF16_K2_BPC"); k2bpc = e ? atoi(e) : 3; }
+        int nbx = std::max(1, (ctx->cus * k2bpc + ptiles * ygroups - 1) / (ptiles * ygroups));
         if (nbx > nchunks) nbx = (int)std::max<int64_t>(nchunks, 1);
         JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * qpad));
         double *Kpart = (double *)ctx->kpart.ptr;
         dim3 grid(nbx, ptiles, ygroups);
         const bool v8 = ldx % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && !getenv("JCH_BF16_SCALAR_PROLOGUE");
         if (v8 && d.scal) hipLaunchKernelGGL(k_center_xty_bf16_v8<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
-                                             s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows, -1);
+                                             s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows, -1, k2skip);
         else if (v8) hipLaunchKernelGGL(k_center_xty_bf16_v8<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q,
-                                        raw_b ? s.scl : s.mom, s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows, raw_b ? q : -1);
+                                        raw_b ? s.scl : s.mom, s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows, raw_b ? q : -1, k2skip);
         else if (d.scal) hipLaunchKernelGGL(k_center_xty_bf16<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
                                        s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
         else hipLaunchKernelGGL(k_center_xty_bf16<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
