@@ -163,7 +163,7 @@ int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const do
 // WRITEBACK (plskern!/plsnipals! semantics) stores the centred X back into the caller's column-major
 // array; it is only legal when each X element is read by exactly one block (one y group).  Y is never
 // written here (every column tile re-reads the raw Y rows): the launcher exports Yr afterwards.
-template <bool WRITEBACK, bool SCAL, bool V16>
+template <bool WRITEBACK, bool SCAL>
 __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
                                                      int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
                                                      const double *__restrict__ mom, const double *__restrict__ scl,
@@ -176,17 +176,11 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
     const int j0 = blockIdx.y * 64;
     const int yg = blockIdx.z;
     const int64_t nchunks = (n + 63) / 64;
-    // per-thread column constants.  8-B path: lane = row, columns j0 + wv + 4k (k < 16).
-    // V16 path (even ld, 16-B aligned base): lane = (row pair lane&31, column parity lane>>5), columns
-    // j0 + 2 (wv + 4k) + (lane>>5) (k < 8): every global load is 16 B (two consecutive rows of one column) —
-    // 8-B accesses reach only ~0.55-0.7 of the 16-B rate on this part.
-    typedef double v2f64_ __attribute__((ext_vector_type(2)));
-    constexpr int NK = V16 ? 8 : 16;
-    const int lp = lane & 31, ch = lane >> 5;
-    double cm[NK], cs[NK];
+    // per-thread column constants: lane = row, columns j0 + wv + 4k (k < 16)
+    double cm[16], cs[16];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int j = V16 ? j0 + 2 * (wv + 4 * k) + ch : j0 + wv + 4 * k;
+    for (int k = 0; k < 16; ++k) {
+        const int j = j0 + wv + 4 * k;
         cm[k] = j < p ? mom[j] : 0.0;
         cs[k] = (SCAL && j < p) ? scl[j] : 1.0;  // divisor, used only when scaling (cscale!: (x - u) / v)
     }
@@ -194,25 +188,11 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
     // software pipeline: the global loads of chunk c+1 are in flight while chunk c is stored / multiplied
     double xr[16];
     auto prefetch = [&](int64_t cc) {
-        if constexpr (V16) {
-            const int64_t i = cc * 64 + 2 * lp;
+        const int64_t i = cc * 64 + lane;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int j = j0 + 2 * (wv + 4 * k) + ch;
-                v2f64_ v = {0.0, 0.0};
-                if (j < p) {
-                    if (i + 1 < n) v = __builtin_nontemporal_load(reinterpret_cast<const v2f64_ *>(Xc + (size_t)i + (size_t)j * (size_t)ldx));
-                    else if (i < n) v.x = Xc[(size_t)i + (size_t)j * (size_t)ldx];
-                }
-                xr[2 * k] = v.x; xr[2 * k + 1] = v.y;
-            }
-        } else {
-            const int64_t i = cc * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int j = j0 + wv + 4 * k;
-                xr[k] = (i < n && j < p) ? __builtin_nontemporal_load(Xc + (size_t)i + (size_t)j * (size_t)ldx) : 0.0;
-            }
+        for (int k = 0; k < 16; ++k) {
+            const int j = j0 + wv + 4 * k;
+            xr[k] = (i < n && j < p) ? __builtin_nontemporal_load(Xc + (size_t)i + (size_t)j * (size_t)ldx) : 0.0;
         }
     };
     int64_t c = blockIdx.x;
@@ -237,24 +217,7 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
             yt[row * YT_LD + col] = (yc == ones_col && i < n) ? d[i] : dv * v;
         }
         // ---- X tile: centre/scale the prefetched registers into LDS (and back into the caller's array)
-        if constexpr (V16) {
-            const int64_t i = i0 + 2 * lp;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int col = 2 * (wv + 4 * k) + ch, j = j0 + col;
-                v2f64_ v = {0.0, 0.0};
-                if (j < p) {
-                    if (i < n) v.x = SCAL ? (xr[2 * k] - cm[k]) / cs[k] : xr[2 * k] - cm[k];
-                    if (i + 1 < n) v.y = SCAL ? (xr[2 * k + 1] - cm[k]) / cs[k] : xr[2 * k + 1] - cm[k];
-                    if (WRITEBACK && yg == 0) {
-                        if (i + 1 < n) *reinterpret_cast<v2f64_ *>(Xc + (size_t)i + (size_t)j * (size_t)ldx) = v;
-                        else if (i < n) Xc[(size_t)i + (size_t)j * (size_t)ldx] = v.x;
-                    }
-                }
-                xt[(2 * lp) * XT_LD + col] = v.x;
-                xt[(2 * lp + 1) * XT_LD + col] = v.y;
-            }
-        } else {
+        {
             const int64_t i = i0 + lane;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -297,114 +260,6 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int j = j0 + 16 * wv + (lane >> 4) + 4 * reg;
-        if (j < kp_rows) kp[(size_t)j * qpad + yg * 16 + (lane & 15)] = acc[reg];
-    }
-}
-
-// ---- K2, 16-byte variant (used when the column-major input is 16-B aligned with an even ld): tile = 128 rows x 32
-// columns, every global access is 16 B per lane (8-B accesses reach only ~0.55-0.7 of the 16-B rate on this part;
-// the 64x64 / 8-B kernel above is the fallback for odd leading dimensions).
-typedef double v2f64 __attribute__((ext_vector_type(2)));
-#define X2_LD 34
-template <bool WRITEBACK, bool SCAL>
-__global__ __launch_bounds__(256) void k_center_xty_v2(double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
-                                                        int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
-                                                        const double *__restrict__ mom, const double *__restrict__ scl,
-                                                        double *__restrict__ Xr, int ldr, double *__restrict__ Yr, int qpad,
-                                                        double *__restrict__ Kpart, int kp_rows)
-{
-    __shared__ __attribute__((aligned(16))) double xt[128 * X2_LD];
-    __shared__ double yt[128 * YT_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int j0 = blockIdx.y * 32;
-    const int yg = blockIdx.z;
-    const int64_t nchunks = (n + 127) / 128;
-    double cm[8], cs[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int j = j0 + wv + 4 * k;
-        cm[k] = j < p ? mom[j] : 0.0;
-        cs[k] = (SCAL && j < p) ? scl[j] : 1.0;
-    }
-    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-    v2f64 xr[8];
-    int64_t c = blockIdx.x;
-    auto prefetch = [&](int64_t cc) {
-        const int64_t i = cc * 128 + 2 * lane;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = j0 + wv + 4 * k;
-            if (j < p && i + 1 < n) xr[k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(Xc + (size_t)i + (size_t)j * (size_t)ldx));
-            else if (j < p && i < n) xr[k] = v2f64{Xc[(size_t)i + (size_t)j * (size_t)ldx], 0.0};
-            else xr[k] = v2f64{0.0, 0.0};
-        }
-    };
-    if (c < nchunks) prefetch(c);
-    for (; c < nchunks; c += gridDim.x) {
-        const int64_t i0 = c * 128;
-        // ---- Y tile: 128 rows x 16 cols
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = tid + 256 * k, row = e & 127, col = e >> 7;
-            const int yc = yg * 16 + col;
-            const int64_t i = i0 + row;
-            double v = 0.0, dv = 0.0;
-            if (i < n && yc < q) {
-                v = Yc[(size_t)i + (size_t)yc * (size_t)ldy] - mom[p + yc];
-                if (SCAL) v /= scl[p + yc];
-                dv = d[i];
-            }
-            if (blockIdx.y == 0 && i < n) Yr[(size_t)i * qpad + yc] = v;
-            yt[row * YT_LD + col] = dv * v;
-        }
-        // ---- X tile: centre/scale the prefetched registers into LDS (and back into the caller's array)
-        {
-            const int64_t i = i0 + 2 * lane;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int col = wv + 4 * k, j = j0 + col;
-                v2f64 v = v2f64{0.0, 0.0};
-                if (j < p) {
-                    if (i < n) v.x = SCAL ? (xr[k].x - cm[k]) / cs[k] : xr[k].x - cm[k];
-                    if (i + 1 < n) v.y = SCAL ? (xr[k].y - cm[k]) / cs[k] : xr[k].y - cm[k];
-                    if (WRITEBACK && yg == 0) {
-                        if (i + 1 < n) *reinterpret_cast<v2f64 *>(Xc + (size_t)i + (size_t)j * (size_t)ldx) = v;
-                        else if (i < n) Xc[(size_t)i + (size_t)j * (size_t)ldx] = v.x;
-                    }
-                }
-                xt[(2 * lane) * X2_LD + col] = v.x;
-                xt[(2 * lane + 1) * X2_LD + col] = v.y;
-            }
-        }
-        __syncthreads();
-        if (c + gridDim.x < nchunks) prefetch(c + gridDim.x);
-        // ---- row-major store (y group 0 only): 16 lanes x 16 B per row, 4 rows per wave-instruction
-        if (yg == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int row = 16 * k + 4 * wv + (lane >> 4), cp = 2 * (lane & 15), j = j0 + cp;
-                const int64_t i = i0 + row;
-                if (i < n && j < ldr)
-                    __builtin_nontemporal_store(*reinterpret_cast<const v2f64 *>(xt + row * X2_LD + cp),
-                                                reinterpret_cast<v2f64 *>(Xr + (size_t)i * ldr + j));
-            }
-        }
-        // ---- XtY: wave wv owns column group (wv & 1) over the row half (wv >> 1)
-        {
-            const int cg = wv & 1, rh = wv >> 1;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const int row = 64 * rh + 4 * kk + (lane >> 4);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[row * X2_LD + 16 * cg + (lane & 15)], yt[row * YT_LD + (lane & 15)], acc,
-                                                           0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    double *kp = Kpart + ((size_t)(blockIdx.x * 2 + (wv >> 1)) * kp_rows) * qpad;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int j = j0 + 16 * (wv & 1) + (lane >> 4) + 4 * reg;
         if (j < kp_rows) kp[(size_t)j * qpad + yg * 16 + (lane & 15)] = acc[reg];
     }
 }
@@ -458,11 +313,12 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                               int p, int q, const double *mom, const double *scl, bool writeback, double *Xr, int ldr,
                               double *Yr, int qpad, double *K, bool scal, double *means_out, double *mshift_out)
 {
-    const int ones_col = means_out ? q : -1;   // raw mode: needs a free pad column in y group 0 (q <= 15) and no v2 kernel
-    // measured (cfg2): the 128x32 / 16-B tile is 1.1 ms SLOWER than the 64x64 / 8-B tile (its 256-B row segments are
-    // mostly partial 128-B lines); kept behind JCH_K2_V2 for experiments only
-    const bool v2 = (ldx % 2 == 0) && (((uintptr_t)Xc) % 16 == 0) && getenv("JCH_K2_V2") && !means_out;
-    const int tw = v2 ? 32 : 64, th = v2 ? 128 : 64;   // tile width (columns) / height (rows)
+    const int ones_col = means_out ? q : -1;   // raw mode: needs a free pad column in y group 0 (q <= 15)
+    // Tile 64 rows x 64 columns, 8-B loads.  Measured and dropped (cfg2): a 128 x 32 tile with 16-B loads (+1.1 ms: its 256-B row
+    // segments are mostly partial 128-B lines), 16-B loads into this tile (no gain), a second prefetch stage, a Y / weight
+    // prefetch, a 64-column panel layout of the copy (K2 -0.24 ms, sweeps +0.33 ms): the kernel is bound by its 512-B
+    // column-major reads (3.5 TB/s with or without the stores).
+    const int tw = 64, th = 64;
     const int ptiles = (ldr + tw - 1) / tw;
     const int kp_rows = ptiles * tw;
     const int ygroups = qpad / 16;
@@ -470,35 +326,20 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
     int nbx = (ctx->cus * 3 + ptiles * ygroups - 1) / (ptiles * ygroups);
     if (nbx < 1) nbx = 1;
     if (nbx > nchunks) nbx = (int)(nchunks > 0 ? nchunks : 1);
-    const int nslots = v2 ? 2 * nbx : nbx;             // v2: two row halves per block accumulate separately
+    const int nslots = nbx;
     JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nslots * kp_rows * qpad));
     double *Kpart = (double *)ctx->kpart.ptr;
     dim3 grid(nbx, ptiles, ygroups);
     const bool wb_fused = writeback && ygroups == 1;
     static int dbg_skip = -1;
     if (dbg_skip < 0) { const char *e = getenv("JCH_K2_SKIP"); dbg_skip = e ? atoi(e) : 0; }
-    if (v2) {
-#define JCH_K2V2(WB, SC) hipLaunchKernelGGL((k_center_xty_v2<WB, SC>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
-                                            mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows)
-        if (wb_fused && scal) JCH_K2V2(true, true);
-        else if (wb_fused) JCH_K2V2(true, false);
-        else if (scal) JCH_K2V2(false, true);
-        else JCH_K2V2(false, false);
-#undef JCH_K2V2
-    } else {
-        // measured (cfg2): 16-B column loads into this tile are 0.1 ms SLOWER than 8-B ones (two strided LDS writes per
-        // load); the kernel is bound by the LDS transpose + partial-line row stores, not by the load width
-        const bool v16 = (ldx % 2 == 0) && (((uintptr_t)Xc) % 16 == 0) && getenv("JCH_K2_V16");
-#define JCH_K2(WB, SC, V) hipLaunchKernelGGL((k_center_xty<WB, SC, V>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
-                                             mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip, ones_col)
-#define JCH_K2D(WB, SC) do { if (v16) JCH_K2(WB, SC, true); else JCH_K2(WB, SC, false); } while (0)
-        if (wb_fused && scal) JCH_K2D(true, true);
-        else if (wb_fused) JCH_K2D(true, false);
-        else if (scal) JCH_K2D(false, true);
-        else JCH_K2D(false, false);
-#undef JCH_K2D
+#define JCH_K2(WB, SC) hipLaunchKernelGGL((k_center_xty<WB, SC>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
+                                          mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip, ones_col)
+    if (wb_fused && scal) JCH_K2(true, true);
+    else if (wb_fused) JCH_K2(true, false);
+    else if (scal) JCH_K2(false, true);
+    else JCH_K2(false, false);
 #undef JCH_K2
-    }
     hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nslots, kp_rows, p, qpad,
                        K);
     JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
