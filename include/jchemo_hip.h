@@ -161,7 +161,8 @@ JCH_API int32_t jch_col_stats(jch_ctx *ctx, int32_t loc, const double *X, int64_
  *   can never pass; that check is skipped here.  Rows with zero weight get finite scores here (the reference divides
  *   by sqrt(w) = 0 at :107 and returns NaN for them).  inplace = 1 hands back X, Y deflated AND carrying the row
  *   metric sqrt(w) (:57-58).
- * plssimp / plswold need q <= 16, p <= 2048 and the p x q state inside LDS (JCH_EINVAL otherwise); Float64 only. */
+ * plssimp / plswold run their LDS-resident small-state kernels when q <= 16, p <= 2048 and the p x q state fits in LDS,
+ * and a generic kernel (state in global memory, q <= 64, any p) otherwise; Float64 only. */
 JCH_API int32_t jch_plssimp_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
                         const double *weights, double *T, double *P, double *R, double *W, double *C,
                         double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,

@@ -200,10 +200,14 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     const bool fast = q <= 16 && nlv <= 1024 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
     // the fast small-state kernel sums the second-stage slices itself; with several GPUs the [slices][ldz] block is
     // all-reduced as one message (still latency-bound at 32 KB) instead of being collapsed by an extra launch
-    const int max_slices = fast ? JCH_ZT_SLICES : 1;
-    const bool fuse_inbox = fast && ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
-    if ((algo == ALGO_SIMP || algo == ALGO_WOLD) && !jch_sibling_supported(p, q, ldr, nlv))
-        return jch_fail(ctx, JCH_EINVAL, "%s: needs q <= 16, p <= %d and the p x q state inside LDS (p=%d q=%d nlv=%d)", who, JCH_SWEEP_MAXP, p, q, nlv);
+    // plssimp / plswold: their fast kernels (siblings.hip) need the p x q state in LDS; outside that envelope the generic
+    // small-state kernel (K in global memory, q <= 64, any p) takes over
+    const bool sib = algo == ALGO_SIMP || algo == ALGO_WOLD;
+    const bool sib_fast = sib && jch_sibling_supported(p, q, ldr, nlv) && !getenv("JCH_SMALLSTATE_GENERIC");
+    const bool all_fast = sib ? (sib_fast && (algo == ALGO_SIMP || fast)) : fast;   // every small-state kernel of this fit is a fast one
+    const int max_slices = all_fast ? JCH_ZT_SLICES : 1;
+    const bool fuse_inbox = all_fast && ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
+    if (sib && !all_fast && nlv > 256) return jch_fail(ctx, JCH_EINVAL, "%s: nlv > 256 outside the LDS-resident envelope is not supported", who);
     int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
     const bool ext_scales = io.xscales_in != nullptr;
@@ -212,7 +216,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     // in a spare pad column, the weighted column sums, i.e. the means (one read of X instead of two, one all-reduce
     // instead of two).  The sweeps then use t_i = x_i.r - mu.r and zp = zp_raw - mu * sum_i d_i t_i (sweep.hip,
     // smallstate_fast.hip); T, P, C, TT, xmeans are the same quantities as in the centred formulation.
-    const bool raw_mode = (((algo == ALGO_KERN || algo == ALGO_ROSA) && fast) || algo == ALGO_SIMP) && !ext_scales && !inplace &&
+    const bool raw_mode = (((algo == ALGO_KERN || algo == ALGO_ROSA) && fast) || (algo == ALGO_SIMP && all_fast)) && !ext_scales && !inplace &&
                           q <= 15 && d.reserved == 0 && p <= JCH_SWEEP_MAXP && !getenv("JCH_CENTRED_COPY") &&
                           !(d.scal && getenv("JCH_CENTRED_COPY_SCAL"));
     if (raw_mode) {
@@ -262,8 +266,10 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         }
         JCH_TRY(jch_launch_scores(ctx, Xr, n, p, ldr, s.R, nlv, Tdev));
     } else {
-    if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, -1, nlv, 1, ldz));
-    else if (algo == ALGO_WOLD) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, 0, nlv, io.tol, io.maxit));
+    if (algo == ALGO_SIMP && all_fast) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, -1, nlv, 1, ldz));
+    else if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, 2, 1, ldz, false));
+    else if (algo == ALGO_WOLD && all_fast) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, 0, nlv, io.tol, io.maxit));
+    else if (algo == ALGO_WOLD) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, 0 | 0x20000000, nlv, 4, 1, ldz, false, false, nullptr, 0, 0, io.tol, io.maxit));
     else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, kern_like ? 0 : 1, 1, ldz, fast));
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
@@ -276,7 +282,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
                 JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast, true));
             } else {
                 JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + (raw_mode ? 1 : 0), nslice, ldz, &nslice));
-                if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
+                if (algo == ALGO_SIMP && all_fast) JCH_TRY(jch_launch_lv_update_simp(ctx, s, p, q, ldr, a, nlv, nslice, ldz));
+                else if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 2, nslice, ldz, false));
                 else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
             }
         } else {
@@ -294,7 +301,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
                 JCH_TRY(jch_launch_deflate(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, tcol, s.zpc, last ? nullptr : s.K));
             }
             if (!last) {
-                if (algo == ALGO_WOLD) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, a + 1, nlv, io.tol, io.maxit));
+                if (algo == ALGO_WOLD && all_fast) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, a + 1, nlv, io.tol, io.maxit));
+                else if (algo == ALGO_WOLD) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 4, 1, ldz, false, false, nullptr, 0, 0, io.tol, io.maxit));
                 else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, (a + 1) | 0x20000000, nlv, 1, 1, ldz, fast));
             }
         }

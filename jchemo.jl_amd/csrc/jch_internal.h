@@ -161,7 +161,7 @@ struct jch_small {  // device-resident replicated small state of one fit
 };
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a /*-1: init*/,
                              int nlv, int algo /*0 plskern, 1 plsnipals*/, int nslice, int ldz, bool fast, bool fuse_p2p = false,
-                             const double *bf_src = nullptr, int bf_ld = 0, int bf_ldr = 0);
+                             const double *bf_src = nullptr, int bf_ld = 0, int bf_ldr = 0, double tol = 0.0, int maxit = 0);
 size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv);
 int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
                                   int do_a, int do_b, int nslice, int ldz, bool fuse_p2p = false, const double *bf_src = nullptr,

@@ -101,7 +101,9 @@ __device__ static void jacobi_eig(int q, int lda, double *&A0, double *&A1, doub
 
 struct lv_args {
     jch_small s;
-    int p, q, qpad, ldr, a, nlv, algo, do_a, do_b;
+    int p, q, qpad, ldr, a, nlv, algo, do_a, do_b;   // algo: 0 plskern, 1 plsnipals, 2 plssimp, 4 plswold (phase B only)
+    int maxit;      // plswold
+    double tol;
 };
 
 __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
@@ -122,7 +124,49 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
     // ------------------------------------------------------------------ phase A
     if (g.do_a) {
         const double tt = zt[ldr];
-        if (g.algo == 0) {
+        if (g.algo == 2) {
+            // SIMPLS (src/plssimp.jl:64-83; state as in siblings.hip: K = XtY projected on the complement of the loadings,
+            // V = s.W an orthonormal basis of their span).  s.w serves as the work vector (phase B rewrites it).
+            block_matTvec(K, qpad, p, q, g.s.r, vec, scratch);  // vec[k] = (K' r)_k  (== XtY' r: r is orthogonal to V)
+            if (tid < q) g.s.C[(size_t)a * q + tid] = vec[tid] / tt;
+            double *tv = g.s.w, *V = g.s.W;
+            for (int j = tid; j < p; j += NT) {
+                const double pj = zt[j] / tt;
+                g.s.P[(size_t)a * p + j] = pj;
+                g.s.R[(size_t)a * p + j] = g.s.r[j];
+                tv[j] = pj;
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int pass = 0; pass < 2; ++pass) {   // v = P_a - V (V'P_a), twice
+                const int lane = tid & 63, wv = tid >> 6;
+                for (int i = wv; i < a; i += NT / 64) {
+                    double s3 = 0.0;
+                    for (int j = lane; j < p; j += 64) s3 += V[(size_t)i * p + j] * tv[j];
+                    s3 = jch_wave_sum(s3);
+                    if (lane == 0) dots[i] = s3;
+                }
+                __syncthreads();
+                for (int j = tid; j < p; j += NT) {
+                    double acc = 0.0;
+                    for (int i = 0; i < a; ++i) acc += dots[i] * V[(size_t)i * p + j];
+                    tv[j] -= acc;
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            double ss = 0.0;
+            for (int j = tid; j < p; j += NT) ss += tv[j] * tv[j];
+            const double inv = 1.0 / sqrt(jch_block_sum<NT>(ss, scratch));
+            for (int j = tid; j < p; j += NT) V[(size_t)a * p + j] = tv[j] * inv;
+            __threadfence_block();
+            __syncthreads();
+            block_matTvec(K, qpad, p, q, V + (size_t)a * p, vec, scratch);   // vec = K'v
+            for (int e = tid; e < p * q; e += NT) {
+                const int j = e / q, k = e % q;
+                K[(size_t)j * qpad + k] -= V[(size_t)a * p + j] * vec[k];
+            }
+        } else if (g.algo == 0) {
             block_matTvec(K, qpad, p, q, g.s.r, vec, scratch);  // vec[k] = (K' r)_k
             if (tid < q) {
                 vec[tid] = vec[tid] / tt;
@@ -163,6 +207,7 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
     const int anext = g.do_a ? a + 1 : a;  // number of finished LVs (columns of P/R valid)
     double ssq = 0.0;
     if (q == 1) {
+        if (g.algo == 4 && tid == 0 && g.s.niter) g.s.niter[a] = g.maxit >= 2 ? (0.0 < g.tol ? 2.0 : (double)g.maxit) : 1.0;
         for (int j = tid; j < p; j += NT) {
             const double v = K[(size_t)j * qpad];
             g.s.w[j] = v;
@@ -194,6 +239,46 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
             }
         }
         __syncthreads();
+        if (g.algo == 4) {
+            // plswold: the inner loop of src/plswold.jl:79-92 as a power iteration on G = K'K (see k_wold_b, siblings.hip);
+            // one wave, lane j < q owns component j (q <= 64)
+            if (tid < 64) {
+                const int lane = tid;
+                double b = lane == 0 ? 1.0 : 0.0, aprev = 0.0;
+                int k = 1;
+                for (;;) {
+                    if (lane < q) vec[lane] = b;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    double gb = 0.0;
+                    if (lane < q)
+                        for (int kk = 0; kk < q; ++kk) gb += A0[lane * lda + kk] * vec[kk];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    const double n2 = jch_wave_sum(lane < q ? b * gb : 0.0), g2 = jch_wave_sum(lane < q ? gb * gb : 0.0);
+                    const double acur = b / sqrt(n2);
+                    bool stop = k >= g.maxit;
+                    if (k >= 2) {
+                        const double dlt = lane < q ? acur - aprev : 0.0;
+                        if (lane < q) vec[lane] = dlt;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        double gd = 0.0;
+                        if (lane < q)
+                            for (int kk = 0; kk < q; ++kk) gd += A0[lane * lda + kk] * vec[kk];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        const double dif = jch_wave_sum(lane < q ? dlt * gd : 0.0);
+                        if (dif < g.tol) stop = true;
+                    }
+                    if (stop) {
+                        if (lane < q) vec[lane] = acur;
+                        break;
+                    }
+                    aprev = acur;
+                    b = gb / sqrt(g2);
+                    ++k;
+                }
+                if (lane == 0 && g.s.niter) g.s.niter[a] = (double)k;
+            }
+            __syncthreads();
+        } else {
         jacobi_eig(q, lda, A0, A1, V0, V1, cs, partner, flag);
         if (tid == 0) {
             int best = 0;
@@ -206,6 +291,7 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
             for (int k = 0; k < q; ++k) vec[k] = sg * V0[k * lda + best];
         }
         __syncthreads();
+        }
         for (int j = tid; j < p; j += NT) {
             double wv = 0.0;
             for (int k = 0; k < q; ++k) wv += K[(size_t)j * qpad + k] * vec[k];
@@ -214,7 +300,7 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
         }
     }
     const double nrm = sqrt(jch_block_sum<NT>(ssq, scratch));
-    const bool plain = (g.algo == 1 || anext == 0);
+    const bool plain = (g.algo != 0 || anext == 0);
     for (int j = tid; j < ldr; j += NT) {  // each thread re-reads only its own stores
         const double wv = j < p ? g.s.w[j] / nrm : 0.0;
         g.s.w[j] = wv;
@@ -245,20 +331,21 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
 }
 
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
-                             int nslice, int ldz, bool fast, bool fuse_p2p, const double *bf_src, int bf_ld, int bf_ldr)
+                             int nslice, int ldz, bool fast, bool fuse_p2p, const double *bf_src, int bf_ld, int bf_ldr, double tol, int maxit)
 {
     // a encodes the phase:  a == -1           -> phase B only (first w, r)
     //                       a >= 0, a < nlv   -> phase A for LV a, then phase B unless it was the last LV
     // plsnipals splits A and B around the deflation pass: a |= 0x40000000 -> phase A only,
     //                                                      a |= 0x20000000 -> phase B only with `a` LVs finished.
     lv_args g;
-    g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.nlv = nlv; g.algo = algo;
+    g.s = s; g.p = p; g.q = q; g.qpad = qpad; g.ldr = ldr; g.nlv = nlv; g.algo = algo; g.tol = tol; g.maxit = maxit < 1 ? 1 : maxit;
     const int flags = a < 0 ? 0 : (a & 0x60000000);
     const int aa = a < 0 ? -1 : (a & 0x1fffffff);
     if (aa < 0) { g.a = 0; g.do_a = 0; g.do_b = 1; }
     else if (flags & 0x40000000) { g.a = aa; g.do_a = 1; g.do_b = 0; }
     else if (flags & 0x20000000) { g.a = aa; g.do_a = 0; g.do_b = 1; }
     else { g.a = aa; g.do_a = 1; g.do_b = (aa + 1 < nlv) ? 1 : 0; }
+    if (fast && algo >= 2) return jch_fail(ctx, JCH_EINVAL, "internal: plssimp / plswold use their own fast kernels (siblings.hip)");
     if (fast) return jch_launch_lv_update_fast(ctx, s, p, q, qpad, ldr, g.a, nlv, algo, g.do_a, g.do_b, nslice, ldz, fuse_p2p, bf_src, bf_ld, bf_ldr);
     if (fuse_p2p || bf_src) return jch_fail(ctx, JCH_EINVAL, "internal: the fused inbox all-reduce / bf16 fix-up need the fast small-state kernel");
     if (nslice != 1) return jch_fail(ctx, JCH_EINVAL, "internal: generic small-state kernel needs a single zt slice");

@@ -550,11 +550,17 @@ def test_sibling_seeded_shapes(shape, alg, J, ctx):
 def test_sibling_limits_and_wold_options(J, ctx):
     rng = np.random.default_rng(3)
     X = np.asfortranarray(rng.standard_normal((400, 30))); Y = np.asfortranarray(rng.standard_normal((400, 20)))
-    for fn in (J.plssimp, J.plswold):                       # q > 16: outside the LDS-resident envelope -> loud error
-        with pytest.raises(J.JchError):
-            fn(X, Y, nlv=3, ctx=ctx)
-    fr = J.plsrosa(X, Y, nlv=3, ctx=ctx)                    # plsrosa is plskern-shaped: any q <= 64
-    _sib_cmp(O.plsrosa(X, Y, nlv=3), fr, tol=1e-8)
+    for name in ("plssimp", "plswold", "plsrosa"):          # q = 20 > 16: the generic small-state kernel (K in global memory)
+        fm = getattr(J, name)(X, Y, nlv=3, ctx=ctx)
+        ref = getattr(O, name)(X, Y, nlv=3)
+        _sib_cmp(ref, fm, tol=1e-8)
+        if name == "plswold":
+            assert np.array_equal(ref.niter, fm.niter)
+    Xw = np.asfortranarray(rng.standard_normal((300, 2300))); Yw = np.asfortranarray(Xw[:, :3] @ rng.standard_normal((3, 2)) + 0.1 * rng.standard_normal((300, 2)))
+    for name in ("plssimp", "plswold"):                     # p > 2048: two-pass wide sweep + generic small-state kernel
+        _sib_cmp(getattr(O, name)(Xw, Yw, nlv=4, scal=True), getattr(J, name)(Xw, Yw, nlv=4, scal=True, ctx=ctx), tol=1e-8)
+    with pytest.raises(J.JchError):
+        J.plssimp(X, np.asfortranarray(rng.standard_normal((400, 65))), nlv=2, ctx=ctx)      # q > 64: loud error
     Y4 = np.asfortranarray(Y[:, :4])
     for maxit in (1, 2, 5):
         ref = O.plswold(X, Y4, nlv=3, maxit=maxit)
