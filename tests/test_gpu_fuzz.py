@@ -34,7 +34,7 @@ def ctx(J):
     c.close()
 
 
-@pytest.mark.parametrize("case", _cases(20250112, 48), ids=lambda c: "n%d_p%d_q%d_a%d_%s%s" % (c[1], c[2], c[3], c[4], "s" if c[5] else "", "w" if c[6] else ""))
+@pytest.mark.parametrize("case", _cases(int(__import__("os").environ.get("JCH_FUZZ_SEED", "20250112")), int(__import__("os").environ.get("JCH_FUZZ_COUNT", "48"))), ids=lambda c: "n%d_p%d_q%d_a%d_%s%s" % (c[1], c[2], c[3], c[4], "s" if c[5] else "", "w" if c[6] else ""))
 def test_random_shapes_all_algorithms(case, J, ctx):
     i, n, p, q, nlv, scal, weighted = case
     rng = np.random.default_rng(1000 + i)
