@@ -236,7 +236,8 @@ function predict(object::Lwplsr, X; nlv = nothing, ctx = default_ctx())
         Zt = _affine(Zt, nothing, nothing, Uinv, nothing, ctx); Zq = _affine(Zq, nothing, nothing, Uinv, nothing, ctx)
     end
     k = min(object.k, n); le = length(rng)
-    pred = zeros(le, m); ind = zeros(Int32, k, m); dist = zeros(k, m); w = zeros(k, m)   # row-major per query == Julia columns
+    q <= 8 || error("predict(::Lwplsr): the batched kernel handles q <= 8 responses")
+    pred = zeros(q, le, m); ind = zeros(Int32, k, m); dist = zeros(k, m); w = zeros(k, m)   # C layout [m][le][q] == Julia (q, le, m)
     Xt = object.X; Yt = object.Y
     GC.@preserve Xt Yt Zt Zq X check(ctx, ccall((:jch_lwplsr_predict, LIB), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
@@ -244,9 +245,45 @@ function predict(object::Lwplsr, X; nlv = nothing, ctx = default_ctx())
         ctx.h, _loc(Xt), pointer(Xt), n, p, stride(Xt, 2), pointer(Yt), q, max(stride(Yt, 2), n), pointer(Zt), stride(Zt, 2),
         pointer(Zq), stride(Zq, 2), size(Zt, 2), pointer(X), m, stride(X, 2), k, object.h, object.tol, object.scal ? 1 : 0,
         first(rng), last(rng), pred, ind, dist, w))
-    preds = [reshape(pred[i, :], m, 1) for i in 1:le]
+    preds = [permutedims(pred[:, i, :]) for i in 1:le]                                      # m x q per nlv
     (pred = le == 1 ? preds[1] : preds, listnn = [Int.(ind[:, i]) .+ 1 for i in 1:m], listd = [dist[:, i] for i in 1:m],
      listw = [w[:, i] for i in 1:m])
 end
+
+# ---- caller-supplied column scales (multiblock PLSR, src/mbplsr.jl:77-113) and column statistics
+"Weighted column means and uncorrected stds from the device (`colmean`, `colstd`: src/utility.jl:193-195,312-323)."
+function col_stats(X, weights = nothing; ctx = default_ctx())
+    X = ensure_mat(X); n, p = size(X); m = zeros(p); s = zeros(p)
+    w = weights === nothing ? C_NULL : pointer(weights)
+    GC.@preserve X weights check(ctx, ccall((:jch_col_stats, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, _loc(X), pointer(X), n, p, stride(X, 2), w, m, s))
+    (means = m, stds = s)
+end
+
+"`plskern` with column divisors handed in (X centred by its weighted means, divided by `xscales`; Y by `yscales`)."
+function plskern_scaled(X, Y, xscales::Vector{Float64}, yscales = nothing, weights = nothing; nlv, ctx = default_ctx())
+    X = ensure_mat(X); Y = ensure_mat(Y); n, p = size(X); q = size(Y, 2); kmax = max(1, min(p, nlv))
+    T = _similar(X, n, kmax); wn = _similar(X, n)
+    P = zeros(p, kmax); R = zeros(p, kmax); W = zeros(p, kmax); C = zeros(q, kmax); TT = zeros(kmax)
+    xm = zeros(p); xs = zeros(p); ym = zeros(q); ys = zeros(q); got = Ref{Int32}(0)
+    desc = Ref(PlsDesc(n, p, q, nlv, 0, 0, _loc(X), 0, 0))
+    w = weights === nothing ? C_NULL : pointer(weights)
+    GC.@preserve X Y weights T wn check(ctx, ccall((:jch_plskern_fit_scaled, LIB), Int32,
+        (Ptr{Cvoid}, Ref{PlsDesc}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+        ctx.h, desc, pointer(X), stride(X, 2), pointer(Y), max(stride(Y, 2), n), w, xscales,
+        yscales === nothing ? C_NULL : pointer(yscales), pointer(T), P, R, W, C, TT, xm, xs, ym, ys, pointer(wn), got))
+    k = Int(got[])
+    Plsr(T[:, 1:k], P[:, 1:k], R[:, 1:k], W[:, 1:k], C[:, 1:k], TT[1:k], xm, xs, ym, ys, wn, nothing)
+end
+
+# ---- P2P inbox transport (include/jchemo_hip.h): export -> all-gather the handles (MPI) -> import -> agree -> enable
+p2p_export(ctx::JchCtx, nranks::Integer) = (h = zeros(UInt8, 64); check(ctx, ccall((:jch_ctx_p2p_export, LIB), Int32,
+    (Ptr{Cvoid}, Int32, Ptr{UInt8}), ctx.h, nranks, h)); h)
+p2p_import(ctx::JchCtx, handles::Vector{UInt8}, rank::Integer, nranks::Integer) =
+    ccall((:jch_ctx_p2p_import, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, UInt32), ctx.h, handles, rank, nranks, 0) == 0
+p2p_enable!(ctx::JchCtx, on::Bool) = check(ctx, ccall((:jch_ctx_p2p_enable, LIB), Int32, (Ptr{Cvoid}, Int32), ctx.h, on ? 1 : 0))
 
 end # module
