@@ -292,7 +292,12 @@ int32_t jch_launch_deflate(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, 
         if (ldr <= 512) JCH_DS(4, 2);
         if (ldr <= 1024) JCH_DS(8, 1);
         if (ldr <= 2048) {   // Q x KC accumulators: keep registers in check at the widest rows
-            if (q == 1) return launch_deflate_stream<16, 1, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
+            if (q == 1) {
+                static int r2 = -1;
+                if (r2 < 0) { const char *e = getenv("JCH_DEFLATE_R2"); r2 = e ? atoi(e) : 1; }   // two rows per wave-iteration: 77.85 -> 77.2 ms per 10 LVs at cfg4 shape
+                if (r2) return launch_deflate_stream<16, 2, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
+                return launch_deflate_stream<16, 1, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
+            }
             if (q == 2) return launch_deflate_stream<16, 1, 2>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
         }
 #undef JCH_DS
