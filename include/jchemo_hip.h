@@ -262,6 +262,12 @@ typedef struct jch_profile {
 JCH_API int32_t jch_ctx_set_profiling(jch_ctx *ctx, int32_t enable);
 JCH_API int32_t jch_ctx_get_profile(const jch_ctx *ctx, jch_profile *out);
 
+/* Diagnostic counters of a ctx (cumulative since jch_ctx_create).  which = JCH_COUNTER_PIVOT_REFITS: fits whose one-pass
+ * ("raw") prologue was repeated on the centred working copy because the sampled pivot turned out to be further than 64
+ * sample standard deviations from a column mean (results are those of the centred formulation). */
+#define JCH_COUNTER_PIVOT_REFITS 0
+JCH_API int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -580,17 +580,20 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
     return JCH_OK;
 }
 
-// raw prologue helpers: pivot = plain mean of the root rank's first (<= 64) rows; means = pivot + K[:, col]
-__global__ __launch_bounds__(256) void k_pivot_rows_bf16(const bf16_t *__restrict__ Xc, int64_t ldx, int64_t n, int p, int is_root,
-                                                         double *__restrict__ pivot)
+// raw prologue helpers: pivot = mean of a strided sample of (up to) 256 rows per shard, the ranks' sample means weighted by
+// n_r / n_total (hdr[1]) — the same rule as the f64 path (prologue.hip k_pivot_rows); means = pivot + K[:, col].  Here the
+// pivot only conditions K = (X - c)'D Yc (f64 arithmetic on the exact bf16 values); the sweeps use the exact means.
+__global__ __launch_bounds__(256) void k_pivot_rows_bf16(const bf16_t *__restrict__ Xc, int64_t ldx, int64_t n, int p,
+                                                         const double *__restrict__ hdr, double *__restrict__ pivot)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= p) return;
+    const int m = (int)(n < 256 ? n : 256);
+    const int64_t stride = n / m;
     double s = 0.0;
-    const int m = (int)(n < 64 ? n : 64);
-    if (is_root)
-        for (int i = 0; i < m; ++i) s += (double)bf2f(Xc[(size_t)i + (size_t)j * (size_t)ldx]);
-    pivot[j] = is_root ? s / m : 0.0;
+    for (int i = lane; i < m; i += 64) s += (double)bf2f(Xc[(size_t)i * (size_t)stride + (size_t)j * (size_t)ldx]);
+    s = jch_wave_sum(s);
+    if (lane == 0) pivot[j] = s / m * ((double)n / hdr[1]);
 }
 __global__ __launch_bounds__(256) void k_extract_means_b(double *__restrict__ K, int qpad, int p, int col, const double *__restrict__ pivot,
                                                          double *__restrict__ means)
@@ -626,12 +629,12 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     }
     const int nlv = (int)std::min<int64_t>(std::min<int64_t>(n_total, p), d.nlv);
     // RAW prologue (no scaling, 16-byte kernels, q <= 15): as in the f64 path (fit.hip) the means pass over X is dropped —
-    // K2 subtracts a pivot (mean of the root rank's first rows) instead of the means and multiplies against [Yc | 1], so
+    // K2 subtracts a pivot (mean of a strided row sample) instead of the means and multiplies against [Yc | 1], so
     // the means come out of the XtY pass: mu = pivot + K[:, q].
     const bool raw_b = !d.scal && q <= 15 && ldx % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && !getenv("JCH_BF16_SCALAR_PROLOGUE") &&
                        !getenv("JCH_CENTRED_COPY");
     if (raw_b) {
-        hipLaunchKernelGGL(k_pivot_rows_bf16, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, Xc, ldx, n, p, ctx->rank == 0 ? 1 : 0, s.scl);
+        hipLaunchKernelGGL(k_pivot_rows_bf16, dim3((p + 3) / 4), dim3(256), 0, ctx->stream, Xc, ldx, n, p, s.hdr, s.scl);
         JCH_TRY(jch_allreduce_f64(ctx, s.scl, (size_t)p));
         JCH_TRY(launch_moments_bf16(ctx, Yc, ldy, Yc, ldy, dn, n, q, 0, nullptr, s.scl + p));   // Y means -> scl[p..p+q)
     } else {
@@ -692,7 +695,7 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         // ONE collective per LV: [zp_raw, tt, st].  Fast small-state kernel: it adds the slices, (with the inbox transport)
         // all-reduces them and applies the centring / scaling fix-up itself; generic kernel: separate steps.
         if (fast) {
-            const bool fuse = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
+            const bool fuse = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED") && (size_t)(ldr_b + 2) <= ctx->p2p.cap;
             if (!fuse) JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, nslice, ldz, true, fuse, zt8, ldzb, ldr_b));
         } else {

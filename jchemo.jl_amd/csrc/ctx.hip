@@ -303,6 +303,13 @@ extern "C" int32_t jch_ctx_get_profile(const jch_ctx *ctx, jch_profile *out)
     return JCH_OK;
 }
 
+extern "C" int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_t *out)
+{
+    if (!ctx || !out) return JCH_EINVAL;
+    if (which == JCH_COUNTER_PIVOT_REFITS) { *out = ctx->pivot_refits; return JCH_OK; }
+    return JCH_EINVAL;
+}
+
 int32_t jch_allreduce_slices(jch_ctx *ctx, double *zt, int m, int nslice, int ldz, int *nslice_out)
 {
     *nslice_out = nslice;

@@ -74,7 +74,10 @@ float ev_ms(hipEvent_t a, hipEvent_t b)
     return 0.f;
 }
 
-int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
+// raw-mode pivot check: |means - pivot| / spread above this sends the fit to the centred copy (error ~ ratio^2 * eps)
+constexpr double JCH_PIVOT_MAX_RATIO = 64.0;
+
+int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true)
 {
     static const char *const names[] = {"jch_plskern_fit", "jch_plsnipals_fit", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit"};
     const char *who = names[algo];
@@ -122,7 +125,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     if (!host && io.T) Tdev = io.T;
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
-    const size_t small_bytes = 256 * 16 + sizeof(double) * ((size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
+    const size_t small_bytes = 256 * 20 + sizeof(double) * (64 + (size_t)p + (size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
                                                          (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
@@ -133,8 +136,10 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     s.C = cv.take((size_t)nlv_cap * q); s.TT = cv.take(nlv_cap);
     s.mom = cv.take(p + q); s.scl = cv.take(p + q);
     double *niter_dev = cv.take(nlv_cap);
+    double *qual_dev = cv.take(8);   // [0]: pivot quality of the raw mode (fetched with the results)
     s.mshift = nullptr; s.rs = nullptr;
-    const size_t out_bytes = (size_t)((char *)(niter_dev + nlv_cap) - (char *)s.P);
+    const size_t out_bytes = (size_t)((char *)(qual_dev + 8) - (char *)s.P);
+    double qual_host = 0.0;
     s.Z = cv.take((size_t)nlv_cap * 16);
     const int ldz = (ldr + 1 + qpad + 7) & ~7;
     s.zt = cv.take((size_t)JCH_ZT_SLICES * ldz); s.zpc = cv.take((size_t)ldr + qpad);
@@ -155,11 +160,13 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
         put(io.C, s.C, (size_t)k * q); put(io.TT, s.TT, k);
         put(io.xmeans, s.mom, p); put(io.ymeans, s.mom + p, q); put(io.xscales, s.scl, p); put(io.yscales, s.scl + p, q);
         if (algo == ALGO_WOLD) put(io.niter, niter_dev, k);
+        memcpy(&qual_host, h + ((const char *)qual_dev - (const char *)s.P), sizeof(double));
         return JCH_OK;
     };
     s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
 
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
+    JCH_HIP(ctx, hipMemsetAsync(qual_dev, 0, sizeof(double) * 8, ctx->stream));
     if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
         if (algo != ALGO_KERN) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
         const bool fastb = q <= 16 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
@@ -206,7 +213,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     const bool sib_fast = sib && jch_sibling_supported(p, q, ldr, nlv) && !getenv("JCH_SMALLSTATE_GENERIC");
     const bool all_fast = sib ? (sib_fast && (algo == ALGO_SIMP || fast)) : fast;   // every small-state kernel of this fit is a fast one
     const int max_slices = all_fast ? JCH_ZT_SLICES : 1;
-    const bool fuse_inbox = all_fast && ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
+    const bool fuse_inbox = all_fast && ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED") &&
+                            (size_t)(ldr + 1 + qpad) <= ctx->p2p.cap;   // the fused kernel writes one whole message into one inbox slot
     if (sib && !all_fast && nlv > 256) return jch_fail(ctx, JCH_EINVAL, "%s: nlv > 256 outside the LDS-resident envelope is not supported", who);
     int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
@@ -217,16 +225,17 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     // instead of two).  The sweeps then use t_i = x_i.r - mu.r and zp = zp_raw - mu * sum_i d_i t_i (sweep.hip,
     // smallstate_fast.hip); T, P, C, TT, xmeans are the same quantities as in the centred formulation.
     const bool raw_mode = (((algo == ALGO_KERN || algo == ALGO_ROSA) && fast) || (algo == ALGO_SIMP && all_fast)) && !ext_scales && !inplace &&
-                          q <= 15 && d.reserved == 0 && p <= JCH_SWEEP_MAXP && !getenv("JCH_CENTRED_COPY") &&
+                          q <= 15 && d.reserved == 0 && p <= JCH_SWEEP_MAXP && allow_raw && !getenv("JCH_CENTRED_COPY") &&
                           !(d.scal && getenv("JCH_CENTRED_COPY_SCAL"));
     if (raw_mode) {
         s.mshift = cv.take((size_t)ldr + 2);
         JCH_HIP(ctx, hipMemsetAsync(s.mshift, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));
-        JCH_TRY(jch_launch_pivot(ctx, Xc, ldxc, n, p, s.scl));                                      // scl[0..p): the pivot K2 subtracts
+        double *spread2 = cv.take(p);
+        JCH_TRY(jch_launch_pivot(ctx, Xc, ldxc, n, p, s.hdr, s.scl, spread2));                      // scl[0..p): the pivot K2 subtracts
         JCH_TRY(jch_launch_moments(ctx, Yc, ldyc, nullptr, 0, dn, n, q, 0, nullptr, s.scl + p));  // Y means -> scl[p..p+q)
         hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.mom, p + q, 1.0);   // divisors (unused: SCAL = false)
         JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, /*mom =*/s.scl, /*scl =*/s.mom, false, Xr, ldr, Yr, qpad, s.K, false,
-                                      /*means_out =*/s.mom, /*mshift_out =*/s.mshift));
+                                      /*means_out =*/s.mom, /*mshift_out =*/s.mshift, spread2, qual_dev));
         JCH_HIP(ctx, hipMemcpyAsync(s.mom + p, s.scl + p, sizeof(double) * (size_t)q, hipMemcpyDeviceToDevice, ctx->stream));
         hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
         if (d.scal) {   // stds from ONE streaming pass over the row-major copy; the scaling itself is folded into r / s and zp / s
@@ -333,6 +342,13 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo)
     }
     JCH_TRY(fetch_small(nlv));   // (ends with the stream sync of the whole fit)
     JCH_TRY(jch_p2p_check(ctx));
+    if (raw_mode && !(qual_host <= JCH_PIVOT_MAX_RATIO)) {
+        // the sampled pivot was far from the means (sorted / trending / blank leading rows): the raw formulation would
+        // lose ~ratio^2 * eps.  Inputs are untouched in raw mode, so simply fit again on the centred copy (every rank
+        // takes the same decision: qual comes from all-reduced, bit-identical state).
+        ctx->pivot_refits++;
+        return fit_impl(ctx, io, algo, false);
+    }
     if (io.nlv_out) *io.nlv_out = nlv;
     if (s.dbg) {
         std::vector<double> h(nlv + 1);

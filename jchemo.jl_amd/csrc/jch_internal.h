@@ -68,6 +68,8 @@ struct jch_ctx {
     size_t ev_mark = 0;
     // tuning knobs (env JCH_SWEEP_BLOCKS_PER_CU etc.)
     int sweep_blocks_per_cu = 0;
+    // diagnostics
+    long long pivot_refits = 0;      // raw-mode fits repeated on the centred copy because the sampled pivot was poor
 };
 
 // One-time initialisation per (call site, device): hipFuncSetAttribute and occupancy queries are per device, and a
@@ -121,8 +123,11 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                               int64_t n, int p, int q, const double *mom, const double *scl, bool writeback,
                               double *Xr, int ldr, double *Yr, int qpad, double *K /*[p][qpad] device*/, bool scal,
                               double *means_out = nullptr /*raw mode: X is copied minus the pivot mom[0..p), its weighted means land here*/,
-                              double *mshift_out = nullptr /*means - pivot*/);
-int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n, int p, double *pivot /*[p] device, same on all ranks*/);
+                              double *mshift_out = nullptr /*means - pivot*/,
+                              const double *spread2 = nullptr /*[p] sample variances from jch_launch_pivot*/,
+                              double *qual = nullptr /*[1] max_j |means - pivot| / spread (atomicMax; zeroed by the caller)*/);
+int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n, int p, const double *hdr /*[1] = n_total*/,
+                         double *pivot /*[p] device, same on all ranks*/, double *spread2 /*[p]*/);
 int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n,
                                    int p, int q, double *Xc, int64_t ldx, double *Yc, int64_t ldy,
                                    const double *sqrt_rowscale = nullptr /*rows scaled by sqrt(d_i): plswold! row metric*/);

@@ -68,7 +68,9 @@ extern "C" int32_t jch_ctx_p2p_export(jch_ctx *ctx, int32_t nranks, void *handle
     if (t.local) return jch_fail(ctx, JCH_EINVAL, "jch_ctx_p2p_export: inbox already allocated");
     JCH_HIP(ctx, hipSetDevice(ctx->device));
     t.cap = 16384;
-    if (const char *e = getenv("JCH_P2P_CAP")) t.cap = (size_t)std::max(1024, atoi(e));
+    // never below the widest fused per-LV message (the fused kernels of smallstate_fast.hip / bf16.hip write ldr + 1 + 16
+    // resp. bf_ldr + 2 doubles into one slot without chunking; jch_p2p_allreduce chunks by cap)
+    if (const char *e = getenv("JCH_P2P_CAP")) t.cap = (size_t)std::max(JCH_SWEEP_MAXP + 64, atoi(e));
     t.nranks = nranks;
     const size_t bytes = p2p_bytes(nranks, t.cap);
     JCH_HIP(ctx, hipExtMallocWithFlags(&t.local, bytes, hipDeviceMallocFinegrained));

@@ -275,9 +275,13 @@ __global__ __launch_bounds__(256) void k_reduce_kpart(const double *__restrict__
     K[e] = s;
 }
 
-// raw mode: column `col` of K holds sum_i d_i (x_ij - pivot_j); means = pivot + that, and the sweeps need (means - pivot)
+// raw mode: column `col` of K holds sum_i d_i (x_ij - pivot_j); means = pivot + that, and the sweeps need (means - pivot).
+// Pivot quality: qual <- max_j |means_j - pivot_j| / spread_j (spread = the sample standard deviation k_pivot_rows saw);
+// the rounding error of the raw formulation grows with the square of that ratio, so the fit checks it when it fetches
+// its results and falls back to the centred copy when the pivot turned out to be far from the means (fit.hip).
 __global__ __launch_bounds__(256) void k_extract_means(double *__restrict__ K, int qpad, int p, int col, const double *__restrict__ pivot,
-                                                       double *__restrict__ means, double *__restrict__ mshift)
+                                                       double *__restrict__ means, double *__restrict__ mshift,
+                                                       const double *__restrict__ spread2, double *__restrict__ qual)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < p) {
@@ -285,33 +289,58 @@ __global__ __launch_bounds__(256) void k_extract_means(double *__restrict__ K, i
         means[j] = pivot[j] + dm;
         mshift[j] = dm;
         K[(size_t)j * qpad + col] = 0.0;
+        if (qual) {
+            const double a = fabs(dm);
+            const double ratio = a > 0.0 ? a / sqrt(spread2[j]) : 0.0;   // (NaN data: comparison false -> 0, NaN propagates through the fit itself)
+            // non-negative doubles order like their bit patterns
+            atomicMax(reinterpret_cast<unsigned long long *>(qual), (unsigned long long)__double_as_longlong(ratio));
+        }
     }
 }
 
-// Pivot of the raw mode: the plain mean of the first (up to) 64 rows of the root rank — any vector within a few standard
-// deviations of the column means will do; it only has to be the SAME on every rank (all-reduced by the caller).
-__global__ __launch_bounds__(256) void k_pivot_rows(const double *__restrict__ Xc, int64_t ldx, int64_t n, int p, int is_root,
-                                                    double *__restrict__ pivot)
+// Pivot of the raw mode: the plain mean of a STRIDED sample of (up to) 256 rows of every rank's shard — rows 0, s, 2s, ...
+// with s = n / 256 —, the ranks' sample means combined with weights n_r / n_total (hdr[1] = n_total).  Any vector within a
+// few standard deviations of the column means will do; it only has to be the SAME on every rank (all-reduced by the
+// caller).  spread2 receives the sample variances combined the same way.  One wave per column.
+__global__ __launch_bounds__(256) void k_pivot_rows(const double *__restrict__ Xc, int64_t ldx, int64_t n, int p,
+                                                    const double *__restrict__ hdr, double *__restrict__ pivot,
+                                                    double *__restrict__ spread2)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= p) return;
-    double s = 0.0;
-    const int m = (int)(n < 64 ? n : 64);
-    if (is_root)
-        for (int i = 0; i < m; ++i) s += Xc[(size_t)i + (size_t)j * (size_t)ldx];
-    pivot[j] = is_root ? s / m : 0.0;
+    const int m = (int)(n < 256 ? n : 256);
+    const int64_t stride = n / m;
+    double v[4], s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = i < m ? Xc[(size_t)i * (size_t)stride + (size_t)j * (size_t)ldx] : 0.0;
+        s += v[k];
+    }
+    const double mean = jch_wave_sum(s) / m;
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double e = lane + 64 * k < m ? v[k] - mean : 0.0;
+        s2 += e * e;
+    }
+    s2 = jch_wave_sum(s2) / m;
+    const double f = (double)n / hdr[1];
+    if (lane == 0) { pivot[j] = mean * f; spread2[j] = s2 * f; }
 }
 
-int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n, int p, double *pivot)
+int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n, int p, const double *hdr, double *pivot, double *spread2)
 {
-    hipLaunchKernelGGL(k_pivot_rows, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, Xc, ldx, n, p, ctx->rank == 0 ? 1 : 0, pivot);
+    hipLaunchKernelGGL(k_pivot_rows, dim3((p + 3) / 4), dim3(256), 0, ctx->stream, Xc, ldx, n, p, hdr, pivot, spread2);
     JCH_HIP(ctx, hipGetLastError());
-    return jch_allreduce_f64(ctx, pivot, (size_t)p);
+    JCH_TRY(jch_allreduce_f64(ctx, pivot, (size_t)p));
+    return jch_allreduce_f64(ctx, spread2, (size_t)p);
 }
 
 int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d, int64_t n,
                               int p, int q, const double *mom, const double *scl, bool writeback, double *Xr, int ldr,
-                              double *Yr, int qpad, double *K, bool scal, double *means_out, double *mshift_out)
+                              double *Yr, int qpad, double *K, bool scal, double *means_out, double *mshift_out,
+                              const double *spread2, double *qual)
 {
     const int ones_col = means_out ? q : -1;   // raw mode: needs a free pad column in y group 0 (q <= 15)
     // Tile 64 rows x 64 columns, 8-B loads.  Measured and dropped (cfg2): a 128 x 32 tile with 16-B loads (+1.1 ms: its 256-B row
@@ -343,7 +372,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
     hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nslots, kp_rows, p, qpad,
                        K);
     JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
-    if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out);
+    if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out, spread2, qual);
     JCH_HIP(ctx, hipGetLastError());
     if (writeback)  // Y always, X only when it could not be fused above
         JCH_TRY(jch_launch_export_colmajor(ctx, wb_fused ? nullptr : Xr, ldr, Yr, qpad, n, p, q, Xc, ldx, Yc, ldy));

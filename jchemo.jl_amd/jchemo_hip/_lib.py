@@ -27,6 +27,7 @@ SYMBOLS = (
     "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
     "jch_predict", "jch_loopback_group_create", "jch_loopback_group_destroy", "jch_ctx_comm_init_loopback",
     "jch_ctx_p2p_export", "jch_ctx_p2p_import", "jch_ctx_p2p_enable", "jch_plskern_fit_scaled", "jch_col_stats",
+    "jch_ctx_get_counter",
 )
 
 
@@ -92,6 +93,7 @@ def load():
     L.jch_fill_uniform.argtypes = [vp, dp, i64, i64, i64, i64, i64, C.c_uint64]
     L.jch_ctx_set_profiling.argtypes = [vp, i32]
     L.jch_ctx_get_profile.argtypes = [vp, C.POINTER(Profile)]
+    L.jch_ctx_get_counter.argtypes = [vp, i32, C.POINTER(i64)]
     for name in SYMBOLS:
         if name != "jch_last_error":
             getattr(L, name).restype = i32
@@ -165,6 +167,12 @@ class Context:
 
     def set_profiling(self, on: bool):
         self.check(load().jch_ctx_set_profiling(self._h, int(on)))
+
+    def counter(self, which: int = 0) -> int:
+        """Diagnostic counter (0 = raw-mode fits repeated on the centred copy, include/jchemo_hip.h)."""
+        v = C.c_int64(0)
+        self.check(load().jch_ctx_get_counter(self._h, which, C.byref(v)))
+        return int(v.value)
 
     def profile(self) -> Profile:
         pr = Profile()

@@ -510,7 +510,10 @@ def getknn(Xtrain, X, *, k: int = 1, metric: str = "eucl"):
     dist = np.empty((X.shape[0], k))
     for i in range(X.shape[0]):
         d2 = np.sum((Xtrain - X[i]) ** 2, axis=1)
-        order = np.lexsort((np.arange(n), d2))[:k]
+        # the k smallest by (distance, index): candidates = everything not beyond the k-th smallest distance, ordered
+        # by the same two keys — identical to lexsort over all n rows, without sorting all n
+        cand = np.nonzero(d2 <= np.partition(d2, k - 1)[k - 1])[0]
+        order = cand[np.lexsort((cand, d2[cand]))][:k]
         ind[i] = order
         dist[i] = np.sqrt(d2[order])
     return ind, dist

@@ -887,3 +887,61 @@ def test_raw_mode_matches_centred_copy(offset, scal, J, ctx, monkeypatch):
     _cmp(ref, cen, tol=tol)
     s = O.sign_align(raw.W, cen.W)
     assert O.rel_fro(raw.T, cen.T * s) < tol and O.rel_fro(raw.xmeans, cen.xmeans) < 1e-13
+
+
+def _offset_design(n, p, q, seed, offset):
+    rng = np.random.default_rng(seed)
+    Lt = rng.standard_normal((n, 6))
+    X = np.asfortranarray(Lt @ rng.standard_normal((6, p)) / np.sqrt(6.0) + 0.2 * rng.standard_normal((n, p)) + offset)
+    Y = np.asfortranarray(Lt[:, :3] @ rng.standard_normal((3, q)) + 0.1 * rng.standard_normal((n, q)))
+    return X, Y
+
+
+def test_raw_mode_pivot_unrepresentative_leading_rows(J, ctx, monkeypatch):
+    """the raw-mode pivot used to be the mean of the FIRST 64 rows.  Here those rows are blanks
+    (zeros) while every other row has mean 1e4 and spread ~1: the strided 256-row sample (prologue.hip k_pivot_rows)
+    sees one blank row, lands within ~40 spreads of the means, and the raw fit equals the centred-copy fit to <= 1e-9
+    (the old pivot was 1e4 spreads off: error ~1e-8 * 1e8)."""
+    n, p, q, nlv = 30000, 150, 3, 6
+    X, Y = _offset_design(n, p, q, 11, 1e4)
+    X[:64, :] = 0.0
+    before = ctx.counter(0)
+    raw = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    assert ctx.counter(0) == before                     # the sampled pivot was good enough: no fallback needed
+    monkeypatch.setenv("JCH_CENTRED_COPY", "1")
+    cen = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    s = O.sign_align(cen.W, raw.W)
+    for f in FIELDS:
+        assert O.rel_fro(getattr(cen, f), getattr(raw, f) * s) < 1e-9, f
+    _cmp(O.plskern(X, Y, nlv=nlv), raw, tol=1e-9)
+
+
+@pytest.mark.parametrize("pattern", ["periodic_blanks", "row_drift"])
+def test_raw_mode_falls_back_to_centred_copy_when_the_pivot_is_poor(pattern, J, ctx, monkeypatch):
+    """ADVICE r1 (fit.hip:219): no automatic fallback existed.  periodic_blanks: every row the strided sample looks at
+    is a blank while the data sit at 1e4 -> pivot 0, sample spread 0 -> the fit notices |mean - pivot| / spread > 64 when
+    it fetches its results and repeats itself on the centred copy (jch_ctx_get_counter counts it); the answer is then the
+    centred formulation's, bit for bit.  row_drift: sorted / trending rows, per-column offsets — the strided sample
+    spans the drift, so no refit and agreement to 1e-9."""
+    n, p, q, nlv = 25600, 96, 2, 5
+    X, Y = _offset_design(n, p, q, 12, 0.0)
+    if pattern == "periodic_blanks":
+        X += 1e4
+        X[:: n // 256, :] = 0.0                         # exactly the rows k_pivot_rows samples
+    else:
+        X += np.linspace(0.0, 300.0, n)[:, None] + np.linspace(-1e3, 1e3, p)[None, :]
+    before = ctx.counter(0)
+    raw = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    refits = ctx.counter(0) - before
+    monkeypatch.setenv("JCH_CENTRED_COPY", "1")
+    cen = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    if pattern == "periodic_blanks":
+        assert refits == 1
+        for f in FIELDS + ("TT", "xmeans"):
+            assert np.array_equal(getattr(cen, f), getattr(raw, f)), f
+    else:
+        assert refits == 0
+        s = O.sign_align(cen.W, raw.W)
+        for f in FIELDS:
+            assert O.rel_fro(getattr(cen, f), getattr(raw, f) * s) < 1e-9, f
+    _cmp(O.plskern(X, Y, nlv=nlv), raw, tol=1e-8)
