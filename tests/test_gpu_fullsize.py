@@ -105,10 +105,14 @@ def test_cfg5_full_size_lwplsr(J, tctx):
     """BASELINE.json configs[4] as stated: n = 1e5, p = 500, 1000 queries, k = 200 (nlvdis = 20, mahal, h = 1, nlv = 0..15;
     src/lwplsr.jl:134-166).  Neighbours, distances and weights are checked against the oracle for ALL 1000 queries, the
     local-fit predictions (src/locwlv.jl:18-39) on every 16th query (63 queries x 16 nlv values)."""
-    n, p, m, k, nlvdis, nlv = 100_000, 500, 1000, 200, 20, 15
-    X = CO.fill_uniform(20250112, n, p)
+    n, p, m, k, nlvdis, nlv, r = 100_000, 500, 1000, 200, 20, 15, 30
+    # spectra-like inputs (30 latent sources + noise) so that the 20 global and the 15 local LVs are numerically
+    # meaningful: on iid-uniform columns PLS1 exhausts its Krylov space after ~10 LVs and the later global scores — hence
+    # the neighbour distances — of ANY two fp64 implementations differ by conditioning alone (measured 5e-8 at this n).
+    Lo = CO.fill_uniform(777, r, p)
+    X = np.asfortranarray(CO.fill_uniform(20250112, n, r) @ Lo + 0.1 * CO.fill_uniform(20250212, n, p))
+    Xq = np.asfortranarray(CO.fill_uniform(20250115, m, r) @ Lo + 0.1 * CO.fill_uniform(20250215, m, p))
     y = (X[:, :5] @ np.array([1.0, -2.0, 0.5, 3.0, 1.5]) + np.sin(3 * X[:, 5]) + 0.05 * CO.fill_uniform(20250113, n, 1)[:, 0])
-    Xq = CO.fill_uniform(20250115, m, p)
     kw = dict(nlvdis=nlvdis, metric="mahal", h=1.0, k=k, nlv=nlv)
     fm = J.lwplsr(X, y, ctx=tctx, **kw)
     t0 = time.perf_counter()
