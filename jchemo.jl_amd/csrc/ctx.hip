@@ -108,6 +108,8 @@ int32_t jch_reserve(jch_ctx *ctx, jch_buf &b, size_t bytes)
         return jch_fail(ctx, JCH_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     b.bytes = bytes;
+    static const bool trace = getenv("JCH_TRACE_ALLOC") != nullptr;
+    if (trace && bytes >= (1u << 20)) fprintf(stderr, "[jch] workspace %p  %zu bytes\n", b.ptr, bytes);
     return JCH_OK;
 }
 

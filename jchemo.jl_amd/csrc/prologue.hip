@@ -8,6 +8,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "jch_internal.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -264,6 +266,215 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
     }
 }
 
+// ---------------------------------------------------------------- K2p: row-panel version of K2 (q <= 16, 16-B aligned columns)
+// Same outputs as k_center_xty (row-major copy, Yr, XtY partials).  What round 2 measured about this pass
+// (profiles/r02_k2_notes.md; tools/k2_modes.py compares variants inside one process, on the same buffers):
+//   * the tile kernel below is NOT short of TLB reach (99.9 % UTCL1 hits) or starved by latency (1.2 k cycles per read
+//     request, like the sweep); its 8.4 GB move at 3.9 TB/s;
+//   * reading alone (stores compiled out) runs at 5 TB/s whatever the block mapping; the stores add ~1.05 ms for their 4 GB
+//     with 512-B or 1-KiB row pieces, temporal or non-temporal, 1-3 blocks per CU — the write stream of a transposition is
+//     what the memory system dislikes, and a float4 copy (6.3 TB/s, MI355X_MICROARCH.md) bounds this pass at 1.33 ms;
+//   * fewer, fatter streams are better: ONE 256-thread block per CU beat two (1.90 vs 1.97 ms) and three (2.13); blocks
+//     that each own a private row range are faster or slower by 8 % depending on where hipMalloc put the buffers, row tiles
+//     interleaved over the blocks are not; a mapping that wrote 512-B strips from 512 scattered ranges fell to 2.9 TB/s.
+// So: a block walks row tiles b, b + G, b + 2G, ... (G = blocks = CUs); each tile is TH rows x all columns, worked through
+// in TW-column pieces: every row tile leaves the block as TH complete rows of the copy.  The next piece's loads are
+// issued right after the barrier that publishes the current one.  The B operand of the XtY product (d .* yc, plus the
+// weights in the ones column) is built ONCE per row tile, directly in the MFMA lane layout, from the column-major Y (no Y
+// tile in LDS, no re-read per column tile); the eight 64-column tiles of a 512-column group keep their accumulators in
+// registers (8 x 4 doubles per lane) — the column loop is a runtime loop, only the MFMA section names its accumulator
+// statically (a fully unrolled loop spilled 2 300 registers).  v_mfma_f64_16x16x4 runs at 64 cycles on gfx950 (f64 matrix
+// rate == f64 vector rate): 0.21 ms of matrix-pipe time per cfg2 prologue, 3 % of the pass when compiled out.
+typedef double v2f64p __attribute__((ext_vector_type(2)));
+// TH rows x TW columns per LDS tile (TW = 64 or 128: the row pieces written to the copy are TW * 8 bytes); the tile is
+// filled and multiplied in 64-column halves, stored as whole TW-wide rows.
+template <int TH, int TW, bool WRITEBACK, bool SCAL>
+__global__ __launch_bounds__(256, 2) void k_center_xty_panel(double *__restrict__ Xc, int64_t ldx, const double *__restrict__ Yc,
+                                                             int64_t ldy, const double *__restrict__ d, int64_t n, int p, int q,
+                                                             const double *__restrict__ mom, const double *__restrict__ scl,
+                                                             double *__restrict__ Xr, int ldr, double *__restrict__ Yr,
+                                                             double *__restrict__ Kpart, int kp_rows, int ones_col, int dbg_skip)
+{
+    extern __shared__ __attribute__((aligned(16))) double xp_lds[];
+    constexpr int PT = TW + 2;           // LDS row pitch in doubles (even: 16-B aligned rows for b128 reads; 2-way conflicts on the column-wise fill)
+    constexpr int NSUB = TW / 64;        // 64-column halves per tile
+    double *xt = xp_lds;                 // [TH][PT]
+    double *cm_s = xt + TH * PT;         // [512] column shifts of this column group
+    double *cs_s = cm_s + 512;           // [512] column divisors (SCAL)
+    constexpr int NL = TH / 8;           // 16-B loads per thread and 64-column half
+    constexpr int HALF = TH / 2;         // row pairs per column
+    constexpr int CPI = 128 / TH;        // columns per wave-instruction (1: TH = 128, 2: TH = 64)
+    typedef double v4f64p __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cg0 = blockIdx.y * 512;
+    const int ntile = min(8, (ldr - cg0 + 63) / 64);   // 64-column tiles of this column group
+    // Row tiles of a block.  Interleaved (default): block b takes tiles b, b + G, b + 2G, ... — at any moment the G blocks
+    // work on G consecutive row tiles, so for every column they consume one contiguous run of the input (G * TH * 8 B) and
+    // together they write one contiguous region of the copy; the run time then does not depend on where the buffers live.
+    // Contiguous (dbg_skip & 16): one balanced row range per block — faster or slower by 8 % depending on the placement.
+    int64_t rbeg, rend, istep;
+    if (dbg_skip & 16) {
+        const int64_t nunits = (n + 31) / 32;
+        rbeg = 32 * ((nunits * blockIdx.x) / gridDim.x);
+        rend = 32 * ((nunits * (blockIdx.x + 1)) / gridDim.x);
+        if (rend > n) rend = n;
+        istep = TH;
+    } else {
+        rbeg = (int64_t)blockIdx.x * TH;
+        rend = n;
+        istep = (int64_t)gridDim.x * TH;
+    }
+    for (int c = tid; c < 512; c += 256) {
+        const int j = cg0 + c;
+        cm_s[c] = j < p ? mom[j] : 0.0;
+        cs_s[c] = (SCAL && j < p) ? scl[j] : 1.0;
+    }
+    const int rp = lane % HALF, csub = lane / HALF;
+    const int ycol = lane & 15;
+    const double ym = ycol < q ? mom[p + ycol] : 0.0;
+    const double ysd = (SCAL && ycol < q) ? scl[p + ycol] : 1.0;
+    v4f64p acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = v4f64p{0.0, 0.0, 0.0, 0.0};
+    v2f64p R[NL];
+    auto fetch = [&](int64_t i0, int ct) {   // ct: 64-column tile
+        const int64_t i = i0 + 2 * rp;
+        const bool rowok = i < rend;
+        const int jb = cg0 + 64 * ct + CPI * wv + csub;
+        const double *base = Xc + (size_t)i + (size_t)jb * (size_t)ldx;
+        const size_t step = (size_t)(4 * CPI) * (size_t)ldx;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const bool ok = rowok && jb + 4 * CPI * k < p;
+            R[k] = ok ? __builtin_nontemporal_load(reinterpret_cast<const v2f64p *>(base + k * step)) : v2f64p{0.0, 0.0};
+        }
+    };
+    int64_t i0 = rbeg;
+    if (i0 < rend) fetch(i0, 0);
+    __syncthreads();   // cm_s / cs_s
+    for (; i0 < rend; i0 += istep) {
+        // ---- B operand of this row range in the MFMA layout: lane l -> (k = row 4 kk + (l >> 4), n = y column l & 15)
+        double breg[TH / 4];
+#pragma unroll
+        for (int kk = 0; kk < TH / 4; ++kk) {
+            const int64_t row = i0 + 4 * kk + (lane >> 4);
+            const bool ok = row < rend;
+            double yv = 0.0, dv = 0.0;
+            if (ok) {
+                dv = d[row];
+                if (ycol < q) {
+                    yv = Yc[(size_t)row + (size_t)ycol * (size_t)ldy] - ym;
+                    if (SCAL) yv /= ysd;
+                }
+                if (wv == 0 && blockIdx.y == 0) Yr[(size_t)row * 16 + ycol] = yv;
+            }
+            // raw mode: the pad column `ones_col` carries the weights themselves -> that column of X'D[Yc | 1] is the vector
+            // of weighted column sums of X (the means come out of the same pass, fit.hip)
+            breg[kk] = ycol == ones_col ? dv : dv * yv;
+        }
+        // (runtime loop over the tiles: only the MFMA section below names its accumulator statically)
+#pragma unroll 1
+        for (int ct0 = 0; ct0 < ntile; ct0 += NSUB) {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int ct = ct0 + sub;   // (ct may equal ntile for the last half of an odd tile count: an all-zero half)
+                // ---- registers -> LDS half tile [row][64 sub + col], centred / scaled (and back into the caller's array: plskern!)
+                {
+                    const int64_t i = i0 + 2 * rp;
+                    const bool ok0 = i < rend, ok1 = i + 1 < rend;
+                    const int cb = CPI * wv + csub;
+#pragma unroll
+                    for (int k = 0; k < NL; ++k) {
+                        const int c = cb + 4 * CPI * k;
+                        const int j = cg0 + 64 * ct + c;
+                        const bool live = ct < ntile && j < p;
+                        const double m = cm_s[(64 * ct + c) & 511];
+                        v2f64p v = R[k];
+                        if (SCAL) { const double sdv = cs_s[(64 * ct + c) & 511]; v.x = (v.x - m) / sdv; v.y = (v.y - m) / sdv; }
+                        else { v.x -= m; v.y -= m; }
+                        if (!(ok0 && live)) v.x = 0.0;
+                        if (!(ok1 && live)) v.y = 0.0;
+                        if (WRITEBACK && ok0 && live) {
+                            if (ok1) *reinterpret_cast<v2f64p *>(Xc + (size_t)i + (size_t)j * (size_t)ldx) = v;
+                            else Xc[(size_t)i + (size_t)j * (size_t)ldx] = v.x;
+                        }
+                        xt[(2 * rp) * PT + 64 * sub + c] = v.x;
+                        xt[(2 * rp + 1) * PT + 64 * sub + c] = v.y;
+                    }
+                }
+                __syncthreads();
+                // ---- the next (non-empty) half tile's loads fly while this one is multiplied (and the tile stored); an empty
+                //      trailing half (odd tile count, TW = 128) leaves R alone: it already holds the next row tile's first half
+                if (ct + 1 < ntile) fetch(i0, ct + 1);
+                else if (ct + 1 == ntile && i0 + istep < rend) fetch(i0 + istep, 0);
+                // ---- XtY on the matrix cores: wave wv owns x columns 16 wv .. 16 wv + 15 of the half tile
+                if (!(dbg_skip & 1) && ct < ntile) {
+                    const double *ap = xt + (lane >> 4) * PT + 64 * sub + 16 * wv + (lane & 15);
+#define JCH_XP_MM(T) case T: _Pragma("unroll") for (int kk = 0; kk < TH / 4; ++kk) \
+                             acc[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk * PT], breg[kk], acc[T], 0, 0, 0); break;
+                    switch (ct) { JCH_XP_MM(0) JCH_XP_MM(1) JCH_XP_MM(2) JCH_XP_MM(3) JCH_XP_MM(4) JCH_XP_MM(5) JCH_XP_MM(6) JCH_XP_MM(7) default: break; }
+#undef JCH_XP_MM
+                }
+                if (sub + 1 == NSUB) {
+                    // ---- row-major store of the whole tile: one wave-instruction = 1 KiB (TW = 128: one row; TW = 64: two rows)
+                    if (!(dbg_skip & 2)) {
+                        constexpr int LPR = TW / 2;                  // lanes per row (16 B each)
+                        constexpr int RPI = 64 / LPR;                // rows per wave-instruction
+                        const int col = 2 * (lane % LPR);
+                        const int j = cg0 + 64 * ct0 + col;
+                        const int64_t ibase = i0 + wv * (TH / 4) + lane / LPR;
+                        double *dst = Xr + (size_t)ibase * (size_t)ldr + j;
+                        const double *src = xt + (wv * (TH / 4) + lane / LPR) * PT + col;
+#pragma unroll
+                        for (int sidx = 0; sidx < TH / (4 * RPI); ++sidx) {
+                            const v2f64p v = *reinterpret_cast<const v2f64p *>(src + RPI * sidx * PT);
+                            if (ibase + RPI * sidx < rend && j < ldr) {
+                                if (dbg_skip & 4) *reinterpret_cast<v2f64p *>(dst + (size_t)(RPI * sidx) * (size_t)ldr) = v;
+                                else __builtin_nontemporal_store(v, reinterpret_cast<v2f64p *>(dst + (size_t)(RPI * sidx) * (size_t)ldr));
+                            }
+                        }
+                    }
+                    __syncthreads();   // the tile may be overwritten
+                }
+            }
+        }
+    }
+    // D[m][n]: n = lane & 15 (y column), m = (lane >> 4) + 4 reg (x column within the wave's 16)
+    double *kp = Kpart + ((size_t)blockIdx.x * kp_rows) * 16;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+        if (ct < ntile) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = cg0 + 64 * ct + 16 * wv + (lane >> 4) + 4 * reg;
+                if (j < kp_rows) kp[(size_t)j * 16 + (lane & 15)] = acc[ct][reg];
+            }
+        }
+}
+
+// Fixed-order sum of the per-block XtY partials [nbx][kp_rows][qpad] -> K [p][qpad]: 4 groups of blocks per entry summed
+// with 4 independent chains each, combined in group order (bit-reproducible; nbx may be several hundred).
+__global__ __launch_bounds__(256) void k_reduce_kpart_wide(const double *__restrict__ Kpart, int nbx, int kp_rows, int p, int qpad,
+                                                           double *__restrict__ K)
+{
+    __shared__ double sc[4][64];
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const size_t stride = (size_t)kp_rows * qpad;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (e < p * qpad) {
+        int b = g;
+        for (; b + 12 < nbx; b += 16) {
+            s0 += Kpart[(size_t)b * stride + e]; s1 += Kpart[(size_t)(b + 4) * stride + e];
+            s2 += Kpart[(size_t)(b + 8) * stride + e]; s3 += Kpart[(size_t)(b + 12) * stride + e];
+        }
+        for (; b < nbx; b += 4) s0 += Kpart[(size_t)b * stride + e];
+    }
+    sc[g][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < p * qpad) K[e] = (sc[0][el] + sc[1][el]) + (sc[2][el] + sc[3][el]);
+}
+
 __global__ __launch_bounds__(256) void k_reduce_kpart(const double *__restrict__ Kpart, int nbx, int kp_rows, int p, int qpad,
                                                       double *__restrict__ K)
 {
@@ -343,6 +554,52 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                               const double *spread2, double *qual)
 {
     const int ones_col = means_out ? q : -1;   // raw mode: needs a free pad column in y group 0 (q <= 15)
+    // Row-panel kernel (k_center_xty_panel): q <= 16 and 16-B aligned columns; defaults (64-row x 128-column pieces, one block
+    // per CU) are the measured best.  JCH_K2_PANEL=0 keeps the tile kernel below; JCH_K2_TH / JCH_K2_TW / JCH_K2_BPC / JCH_K2_NB
+    // select tile height / piece width / blocks per CU / block count, JCH_K2_SKIP bits compile parts out for timing.
+    // (read on every call, not cached: tools/k2_modes.py compares the variants inside one process, on the same buffers —
+    // the run time of this pass depends on where the buffers happen to live)
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    const int dbg_skip = env_int("JCH_K2_SKIP", 0);
+    const int panel_sel = env_int("JCH_K2_PANEL", 1), th_sel = env_int("JCH_K2_TH", 64);
+    if (panel_sel && qpad == 16 && ldx % 2 == 0 && ((uintptr_t)Xc) % 16 == 0) {
+        const int groups = (ldr + 511) / 512;
+        const int kp_rows = groups * 512;
+        const int64_t nunits = (n + 31) / 32;
+        const int bpc_sel = env_int("JCH_K2_BPC", 1);
+        int nbx = std::max(1, (ctx->cus * bpc_sel) / groups);
+        if (env_int("JCH_K2_NB", 0) > 0) nbx = env_int("JCH_K2_NB", 0);
+        if (nbx > nunits) nbx = (int)nunits;
+        JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * 16));
+        double *Kpart = (double *)ctx->kpart.ptr;
+        dim3 grid(nbx, groups);
+        const int th = th_sel == 128 ? 128 : 64;
+        const int tw = (th == 64 && env_int("JCH_K2_TW", 128) == 128) ? 128 : 64;
+        const size_t lds = sizeof(double) * ((size_t)th * (tw + 2) + 1024);
+        static jch_per_device_once attr_once;
+        if (!attr_once.done(ctx->device)) {
+#define JCH_K2P_ATTR(TH, TW, WB, SC) JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_center_xty_panel<TH, TW, WB, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024))
+#define JCH_K2P_ATTR4(TH, TW) JCH_K2P_ATTR(TH, TW, false, false); JCH_K2P_ATTR(TH, TW, false, true); JCH_K2P_ATTR(TH, TW, true, false); JCH_K2P_ATTR(TH, TW, true, true)
+            JCH_K2P_ATTR4(128, 64); JCH_K2P_ATTR4(64, 64); JCH_K2P_ATTR4(64, 128);
+#undef JCH_K2P_ATTR4
+#undef JCH_K2P_ATTR
+            attr_once.mark(ctx->device);
+        }
+#define JCH_K2P(TH, TW, WB, SC) hipLaunchKernelGGL((k_center_xty_panel<TH, TW, WB, SC>), grid, dim3(256), lds, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
+                                                   mom, scl, Xr, ldr, Yr, Kpart, kp_rows, ones_col, dbg_skip)
+#define JCH_K2P_TH(TH, TW) do { if (writeback && scal) JCH_K2P(TH, TW, true, true); else if (writeback) JCH_K2P(TH, TW, true, false); \
+                                else if (scal) JCH_K2P(TH, TW, false, true); else JCH_K2P(TH, TW, false, false); } while (0)
+        if (th == 128) JCH_K2P_TH(128, 64); else if (tw == 128) JCH_K2P_TH(64, 128); else JCH_K2P_TH(64, 64);
+#undef JCH_K2P_TH
+#undef JCH_K2P
+        hipLaunchKernelGGL(k_reduce_kpart_wide, dim3((p * 16 + 63) / 64), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, 16, K);
+        JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
+        if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out, spread2, qual);
+        JCH_HIP(ctx, hipGetLastError());
+        if (writeback)  // X went back inside the kernel; Y from the row-major copy
+            JCH_TRY(jch_launch_export_colmajor(ctx, nullptr, ldr, Yr, qpad, n, p, q, Xc, ldx, Yc, ldy));
+        return JCH_OK;
+    }
     // Tile 64 rows x 64 columns, 8-B loads.  Measured and dropped (cfg2): a 128 x 32 tile with 16-B loads (+1.1 ms: its 256-B row
     // segments are mostly partial 128-B lines), 16-B loads into this tile (no gain), a second prefetch stage, a Y / weight
     // prefetch, a 64-column panel layout of the copy (K2 -0.24 ms, sweeps +0.33 ms): the kernel is bound by its 512-B
@@ -360,8 +617,6 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
     double *Kpart = (double *)ctx->kpart.ptr;
     dim3 grid(nbx, ptiles, ygroups);
     const bool wb_fused = writeback && ygroups == 1;
-    static int dbg_skip = -1;
-    if (dbg_skip < 0) { const char *e = getenv("JCH_K2_SKIP"); dbg_skip = e ? atoi(e) : 0; }
 #define JCH_K2(WB, SC) hipLaunchKernelGGL((k_center_xty<WB, SC>), grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, \
                                           mom, scl, Xr, ldr, Yr, qpad, Kpart, kp_rows, dbg_skip, ones_col)
     if (wb_fused && scal) JCH_K2(true, true);
