@@ -120,7 +120,7 @@ template <int KC, int R, int Q, bool PF>
 __global__ __launch_bounds__(256) void k_deflate_stream(double *__restrict__ Xr, int64_t n, int ldr, double *__restrict__ Yr,
                                                          int qpad, const double *__restrict__ dw,
                                                          const double *__restrict__ tcol, const double *__restrict__ zpc,
-                                                         double *__restrict__ part, int ldpart)
+                                                         double *__restrict__ part, int ldpart, int plain_stores)
 {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [4][Q][KC*128]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_deflate_stream(double *__restrict__ Xr,
                 for (int k = 0; k < KC; ++k) {
                     x[rr][k].x -= t * zpf[k].x;
                     x[rr][k].y -= t * zpf[k].y;
-                    if (in[k]) __builtin_nontemporal_store(x[rr][k], wp + 64 * k);
+                    if (in[k]) { if (plain_stores) wp[64 * k] = x[rr][k]; else __builtin_nontemporal_store(x[rr][k], wp + 64 * k); }
                 }
 #pragma unroll
                 for (int y = 0; y < Q; ++y) {
@@ -250,14 +250,18 @@ static int32_t launch_deflate_stream_pf(jch_ctx *ctx, double *Xr, int64_t n, int
         occ_once.mark(ctx->device);
     }
     const int64_t ngroups = (n + R - 1) / R;
-    int64_t nb64 = std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * bpc);
+    // (measurement knobs, read per call: JCH_DEFLATE_BPC blocks per CU instead of the occupancy maximum, JCH_DEFLATE_NT=0 plain stores)
+    const char *e_bpc = getenv("JCH_DEFLATE_BPC"), *e_nt = getenv("JCH_DEFLATE_NT");
+    const int use_bpc = (e_bpc && atoi(e_bpc) > 0) ? std::min(atoi(e_bpc), bpc) : bpc;
+    const int plain_stores = (e_nt && atoi(e_nt) == 0) ? 1 : 0;
+    int64_t nb64 = std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * use_bpc);
     const int nb = (int)std::max<int64_t>(nb64, 1);
     const int ldpart = (Q * ldr + 7) & ~7;
     JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->kpart.ptr;
     (void)jch_ev(ctx);
     hipLaunchKernelGGL((k_deflate_stream<KC, R, Q, PF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, Yr, qpad, d, tcol, zpc,
-                       part, ldpart);
+                       part, ldpart, plain_stores);
     (void)jch_ev(ctx);
     if (Knext) {
         // pad columns of K (y >= q) must stay zero: they are never written here and were zeroed by the prologue

@@ -89,7 +89,10 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     const jch_pls_desc &d = *io.d;
     const int64_t n = d.n;
     const int p = (int)d.p, q = (int)d.q;
-    const int ldr = (p + 1) & ~1, qpad = ((q + 15) / 16) * 16;
+    // row pitch of the row-major working copy: a multiple of `ralign` doubles (pad columns are zero)
+    const char *e_al = getenv("JCH_LDR_ALIGN");
+    const int ralign = e_al ? std::max(2, atoi(e_al) & ~1) : 2;
+    const int ldr = std::min(((p + ralign - 1) / ralign) * ralign, std::max(JCH_SWEEP_MAXP, (p + 1) & ~1)), qpad = ((q + 15) / 16) * 16;
     const bool host = d.loc == JCH_LOC_HOST;
     const bool inplace = d.inplace != 0;
     ctx->ev_used = 0;

@@ -137,6 +137,183 @@ __global__ __launch_bounds__(256) void k_sweep(const double *__restrict__ Xr, in
     }
 }
 
+// ---------------------------------------------------------------- K4 v2: the same sweep with a cheaper instruction stream
+// Round 2: k_sweep<4, 8> runs ONE block per CU (256 VGPRs + 131 AGPRs: 1 wave per SIMD), so nothing hides its own
+// instruction latencies; per 32 KB wave-iteration it issued 96 ds_bpermute + 48 dependent adds for the eight 64-lane
+// row sums, 508 v_accvgpr moves for the prefetch buffer and a saveexec/branch pair around every load (ISA listing in
+// profiles/r02_sweep_isa.md) — at p = 500 its compute time per iteration was within 20 % of the memory time, which is
+// why p = 1000 (half the row sums per byte) streamed 6 % faster.  This version
+//   * sums R rows at once by transposing while reducing: v_permlane32_swap / v_permlane16_swap fold two rows per
+//     instruction pair (lanes 0-31 keep row a, lanes 32-63 row b; then 16-lane rows), DPP row_ror / half_mirror / quad_perm
+//     finish inside 16 lanes — ~32 VALU ops per 8 rows, no LDS crossbar;
+//   * reads every row with unconditional loads (lanes past the row end re-read its last pair against a zero coefficient,
+//     rows past n re-read row n - 1 with weight zero): straight-line load issue;
+//   * rotates NBUF register buffers (loop unrolled NBUF times) instead of copying the prefetch buffer.
+// Same partial-row output, same fixed-order combine, bit-reproducible; the row sums associate differently from k_sweep.
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void jch_fold32(double &a, double &b)   // a += other half of a (lanes 0-31), b's halves folded into lanes 32-63
+{
+    const v2u32 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const v2u32 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void jch_fold16(double &a, double &b)
+{
+    const v2u32 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const v2u32 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL>
+__device__ __forceinline__ double jch_dpp(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double jch_readlane(double v, int srclane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srclane), __builtin_amdgcn_readlane(__double2loint(v), srclane));
+}
+// Sums of R (4 or 8) per-lane partials over the 64 lanes.  On return every lane of the 8-lane group g = lane >> 3 holds
+// the total of row jch_rowsum_row(g); jch_rowsum_lane(rr) names a lane that holds row rr.
+template <int R>
+__device__ __forceinline__ double jch_rowsums(double (&s)[R], int lane)
+{
+    static_assert(R == 4 || R == 8, "R");
+#pragma unroll
+    for (int i = 0; i < R; i += 2) jch_fold32(s[i], s[i + 1]);          // s[i]: lanes 0-31 row i, lanes 32-63 row i+1
+#pragma unroll
+    for (int i = 0; i < R; i += 4) jch_fold16(s[i], s[i + 2]);          // s[i]: 16-lane rows hold rows i, i+2, i+1, i+3
+    double h;
+    if (R == 8) {
+        const bool up = (lane & 8) != 0;
+        const double w = up ? s[4] : s[0], z = up ? s[0] : s[4];
+        h = w + jch_dpp<0x128>(z);                                      // row_ror:8 : lanes with bit 3 clear keep s[0], set keep s[4]
+    } else {
+        h = s[0] + jch_dpp<0x128>(s[0]);
+    }
+    h += jch_dpp<0x141>(h);                                             // row_half_mirror
+    h += jch_dpp<0xB1>(h);                                              // quad_perm [1,0,3,2]
+    h += jch_dpp<0x4E>(h);                                              // quad_perm [2,3,0,1]
+    return h;
+}
+template <int R>
+__device__ __forceinline__ constexpr int jch_rowsum_lane(int rr)
+{
+    // 16-lane row order after the two folds: rows (i, i+2, i+1, i+3); R == 8: bit 3 selects rows 4..7
+    return 16 * (((rr & 3) == 1) ? 2 : ((rr & 3) == 2) ? 1 : (rr & 3)) + (R == 8 ? 8 * (rr >> 2) : 0);
+}
+
+template <int KC, int R, int NBUF>
+__global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr, int64_t n, int ldr,
+                                                  const double *__restrict__ dw, const double *__restrict__ rvec,
+                                                  double *__restrict__ tcol, double *__restrict__ part, int ldpart,
+                                                  const double *__restrict__ mu)
+{
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [nw][KC*128] + [16] tt, st
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v2f64 rf[KC], zp[KC];
+    int coff[KC];   // element offset of this lane's pair in chunk k (clamped to the row's last pair)
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 2 * lane + 128 * k;
+        const bool in = col < ldr;
+        coff[k] = in ? col : ldr - 2;
+        rf[k] = in ? *reinterpret_cast<const v2f64 *>(rvec + col) : v2f64{0.0, 0.0};
+        zp[k] = v2f64{0.0, 0.0};
+    }
+    double tt = 0.0, st = 0.0, off = 0.0;
+    if (mu) {   // raw mode: t = x.r - mu.r (see k_sweep)
+        double o = 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const v2f64 m2 = *reinterpret_cast<const v2f64 *>(mu + coff[k]);
+            o += m2.x * rf[k].x + m2.y * rf[k].y;                       // rf is zero past the row end
+        }
+        off = jch_wave_sum(o);
+    }
+    const int64_t ngroups = (n + R - 1) / R;
+    const int64_t gstride = (int64_t)gridDim.x * nw;
+    v2f64 X[NBUF][R][KC];
+    double D[NBUF][R];
+    auto fetch = [&](v2f64 (&xb)[R][KC], double (&db)[R], int64_t gg) {
+        const int64_t r0 = gg * R;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int64_t row = r0 + rr < n ? r0 + rr : n - 1;         // wave-uniform clamp
+            const double *rp = Xr + (size_t)row * (size_t)ldr;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) xb[rr][k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(rp + coff[k]));
+            db[rr] = dw[row];
+        }
+    };
+    auto process = [&](v2f64 (&x)[R][KC], double (&dv)[R], int64_t gg) {
+        const int64_t row0 = gg * R;
+        double s[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) a += x[rr][k].x * rf[k].x + x[rr][k].y * rf[k].y;
+            s[rr] = a;
+        }
+        const double h = jch_rowsums<R>(s, lane) - off;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const double t = jch_readlane(h, jch_rowsum_lane<R>(rr));
+            const double dt = row0 + rr < n ? dv[rr] * t : 0.0;
+            tt += dt * t;
+            st += dt;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                zp[k].x += dt * x[rr][k].x;
+                zp[k].y += dt * x[rr][k].y;
+            }
+        }
+        // T column: lane l < R stores row row0 + l; it fetches that row's total from a lane that holds it
+        {
+            const int src = 16 * (((lane & 3) == 1) ? 2 : ((lane & 3) == 2) ? 1 : (lane & 3)) + (R == 8 ? 8 * ((lane >> 2) & 1) : 0);
+            const double tl = __shfl(h, src, 64);
+            if (lane < R && row0 + lane < n) tcol[row0 + lane] = tl;
+        }
+    };
+    int64_t g = (int64_t)blockIdx.x * nw + wv;
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (g + b * gstride < ngroups) fetch(X[b], D[b], g + b * gstride);
+    while (g < ngroups) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            if (g < ngroups) {   // wave-uniform
+                const int64_t ahead = g + (NBUF - 1) * gstride;
+                if (ahead < ngroups) fetch(X[(b + NBUF - 1) % NBUF], D[(b + NBUF - 1) % NBUF], ahead);
+                process(X[b], D[b], g);
+                g += gstride;
+            }
+        }
+    }
+    // ---- combine the waves of the block in wave order, then one partial row per block
+    double *zred = red;                     // [nw][KC*128]
+    double *tred = red + nw * KC * 128;     // [16]
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * k) = zp[k];
+    if (lane == 0) { tred[wv] = tt; tred[8 + wv] = st; }
+    __syncthreads();
+    double *prow = part + (size_t)blockIdx.x * ldpart;
+    for (int c = threadIdx.x; c < ldr; c += blockDim.x) {
+        double a = 0.0;
+        for (int w = 0; w < nw; ++w) a += zred[w * (KC * 128) + c];
+        prow[c] = a;
+    }
+    if (threadIdx.x == 0) {
+        double a = 0.0, a2 = 0.0;
+        for (int w = 0; w < nw; ++w) { a += tred[w]; a2 += tred[8 + w]; }
+        prow[ldr] = a;
+        if (mu) prow[ldr + 1] = a2;
+    }
+}
+
 // Stage 1: slice s (blockIdx.y) sums its contiguous range of per-block partial rows -> zt[s][c].  Fixed order:
 // 16 interleaved row streams per column (threadIdx.x >> 6), combined in stream order.
 __global__ __launch_bounds__(1024) void k_reduce_part(const double *__restrict__ part, int nb, int ldpart, int m, int nslice,
@@ -352,6 +529,41 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     return JCH_OK;
 }
 
+template <int KC, int R, int NBUF>
+static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
+                                 double *tcol, double *zt, int ldz, int max_slices, int *nslice_out, int m, const double *mu)
+{
+    const int64_t ngroups = (n + R - 1) / R;
+    const size_t lds = sizeof(double) * (4 * KC * 128 + 16);
+    static int bpc_cache = 0;
+    if (bpc_cache == 0) {
+        int nblk = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_v2<KC, R, NBUF>, 256, lds);
+        bpc_cache = (e == hipSuccess && nblk > 0) ? nblk : 1;
+    }
+    const int bpc = ctx->sweep_blocks_per_cu > 0 ? ctx->sweep_blocks_per_cu : bpc_cache;
+    int64_t nb64 = (ngroups + 3) / 4;
+    if (nb64 > (int64_t)ctx->cus * bpc) nb64 = (int64_t)ctx->cus * bpc;
+    if (nb64 < 1) nb64 = 1;
+    const int nb = (int)nb64;
+    const int ldpart = (m + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
+    double *part = (double *)ctx->part.ptr;
+    (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
+    hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu);
+    (void)jch_ev(ctx);  // (end)
+    int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
+    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
+    if (nslice > 1) nslice = JCH_ZT_SLICES;
+    if (max_slices == 1 && nslice > 1) {
+        hipLaunchKernelGGL(k_reduce_slices, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, zt, ldz, m, nslice);
+        nslice = 1;
+    }
+    *nslice_out = nslice;
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra, double *tcol, double *zt, int ldz, int max_slices,
                          int *nslice_out, const double *mu)
@@ -367,6 +579,20 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
     if (pfsel < 0) { const char *e = getenv("JCH_SWEEP_PF"); pfsel = e ? atoi(e) : 1; }
     if (rsel < 0) { const char *e = getenv("JCH_SWEEP_R"); rsel = e ? atoi(e) : 0; }
     if (ntsel < 0) { const char *e = getenv("JCH_SWEEP_NT"); ntsel = e ? atoi(e) : 1; }
+    // v2 kernels (k_sweep_v2: permlane/DPP row sums, branch-free loads, rotating buffers) for the plskern-shaped sweep;
+    // JCH_SWEEP_V2=0 selects the round-1 kernels below, JCH_SWEEP_NBUF=3 a three-buffer rotation (read per call: A/B runs)
+    {
+        const char *e2 = getenv("JCH_SWEEP_V2"), *eb = getenv("JCH_SWEEP_NBUF");
+        const int v2 = e2 ? atoi(e2) : 1, nbuf = eb ? atoi(eb) : 2;
+        if (v2 && !nip && ldr >= 2) {
+#define JCH_SWEEP_V2_CASE(KC, R, NB) return launch_sweep_v2_t<KC, R, NB>(ctx, Xr, n, ldr, d, rvec, tcol, zt, ldz, max_slices, nslice_out, m, mu)
+            if (ldr <= 128) JCH_SWEEP_V2_CASE(1, 8, 2);
+            if (ldr <= 256) JCH_SWEEP_V2_CASE(2, 8, 2);
+            if (ldr <= 512) { if (nbuf == 3) JCH_SWEEP_V2_CASE(4, 4, 3); if (v2 == 4) JCH_SWEEP_V2_CASE(4, 4, 2); JCH_SWEEP_V2_CASE(4, 8, 2); }
+            if (ldr <= 1024) { if (nbuf == 3) JCH_SWEEP_V2_CASE(8, 4, 3); JCH_SWEEP_V2_CASE(8, 4, 2); }
+#undef JCH_SWEEP_V2_CASE
+        }
+    }
 #define JCH_SWEEP_CASE(KC, R, NT, PF) return launch_sweep_t<KC, R, NT, PF>(ctx, Xr, n, ldr, d, rvec, Yr, qpad, nip, tcol, zt, ldz, max_slices, nslice_out, m, mu)
     // narrow rows keep the plain kernels: 16 rows per wave-iteration with prefetch were measured 1.5-1.8x SLOWER at
     // p = 100 / 200 (the per-row butterfly dominates); p = 1000: +6.8 % (7.06 TB/s), p = 2000: +1.7 %
