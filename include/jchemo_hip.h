@@ -218,7 +218,8 @@ JCH_API int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int6
  *   k neighbours (clamped to n), h / tol: weight shape and floor; scal; nlv range nlv_lo..nlv_hi (contiguous)
  *   pred  m x le x q (le = nlv_hi - nlv_lo + 1), query-major: pred[(i*le + a)*q + y]              [HOST]
  *   ind_out (m x k, 0-based, row-major), dist_out, w_out (m x k): optional                       [HOST]
- * 1 <= q <= 8 (one workgroup per query holds the k x p slab, the p x q kernel matrix and its q x q eigen-solver);
+ * 1 <= q <= 16 (one workgroup per query holds the k x p slab, the p x q kernel matrix and its q x q eigen-solver; the
+ * call fails with JCH_EINVAL when k, p and q together exceed the 150 KB of LDS that workgroup may use);
  * the constant-y shortcut of src/locwlv.jl:25-28 applies to q == 1 only, as in the reference.
  */
 JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,

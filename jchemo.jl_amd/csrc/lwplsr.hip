@@ -202,7 +202,7 @@ __device__ __forceinline__ void locw_block_sums(double (&v)[NV], double *scratch
     for (int i = 0; i < NV; ++i) v[i] = ((scratch[i] + scratch[NV + i]) + scratch[2 * NV + i]) + scratch[3 * NV + i];
 }
 
-// Q = number of responses padded to {1, 2, 4, 8}; the actual q = g.q <= Q (pad responses are all-zero columns).
+// Q = number of responses padded to {1, 2, 4, 8, 16}; the actual q = g.q <= Q (pad responses are all-zero columns).
 template <int KC, int Q>
 __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
 {
@@ -331,26 +331,47 @@ __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
             // global fit: lv_device.h)
             if constexpr (Q > 1) {
                 constexpr int NE = Q * (Q + 1) / 2;
-                double ge[NE];
+                if constexpr (Q <= 8) {   // Gram entries as per-thread partial sums (36 registers at Q = 8), block-reduced
+                    double ge[NE];
 #pragma unroll
-                for (int e = 0; e < NE; ++e) ge[e] = 0.0;
-                for (int j = tid; j < p; j += 256) {
-                    double kr[Q];
+                    for (int e = 0; e < NE; ++e) ge[e] = 0.0;
+                    for (int j = tid; j < p; j += 256) {
+                        double kr[Q];
 #pragma unroll
-                    for (int y = 0; y < Q; ++y) kr[y] = Kv[(size_t)y * ldr + j];
-                    int e = 0;
+                        for (int y = 0; y < Q; ++y) kr[y] = Kv[(size_t)y * ldr + j];
+                        int e = 0;
 #pragma unroll
-                    for (int y1 = 0; y1 < Q; ++y1)
+                        for (int y1 = 0; y1 < Q; ++y1)
 #pragma unroll
-                        for (int y2 = y1; y2 < Q; ++y2) ge[e++] += kr[y1] * kr[y2];
-                }
-                locw_block_sums<NE>(ge, red);
-                for (int e = tid; e < 5 * Q * lda; e += 256) G0[e] = 0.0;
-                __syncthreads();
-                if (tid == 0) {
-                    int e = 0;
-                    for (int y1 = 0; y1 < Q; ++y1)
-                        for (int y2 = y1; y2 < Q; ++y2) { G0[y1 * lda + y2] = ge[e]; G0[y2 * lda + y1] = ge[e]; ++e; }
+                            for (int y2 = y1; y2 < Q; ++y2) ge[e++] += kr[y1] * kr[y2];
+                    }
+                    locw_block_sums<NE>(ge, red);
+                    for (int e = tid; e < 5 * Q * lda; e += 256) G0[e] = 0.0;
+                    __syncthreads();
+                    if (tid == 0) {
+                        int e = 0;
+                        for (int y1 = 0; y1 < Q; ++y1)
+                            for (int y2 = y1; y2 < Q; ++y2) { G0[y1 * lda + y2] = ge[e]; G0[y2 * lda + y1] = ge[e]; ++e; }
+                    }
+                } else {                  // Q = 16: 136 entries x 2 column halves = 272 work items over the 256 threads, rows of K from LDS
+                    for (int e = tid; e < 5 * Q * lda; e += 256) G0[e] = 0.0;
+                    for (int item = tid; item < 2 * NE; item += 256) {
+                        int e = item >> 1, y1 = 0;
+                        while (e >= Q - y1) { e -= Q - y1; ++y1; }
+                        const double *ka = Kv + (size_t)y1 * ldr, *kb = Kv + (size_t)(y1 + e) * ldr;
+                        double g0 = 0.0, g1 = 0.0;
+                        int j = item & 1;
+                        for (; j + 2 < p; j += 4) { g0 += ka[j] * kb[j]; g1 += ka[j + 2] * kb[j + 2]; }
+                        for (; j < p; j += 2) g0 += ka[j] * kb[j];
+                        red[item] = g0 + g1;
+                    }
+                    __syncthreads();      // G0 zeroed, partial sums published
+                    for (int ent = tid; ent < NE; ent += 256) {
+                        int e = ent, y1 = 0;
+                        while (e >= Q - y1) { e -= Q - y1; ++y1; }
+                        const double v = red[2 * ent] + red[2 * ent + 1];
+                        G0[y1 * lda + y1 + e] = v; G0[(y1 + e) * lda + y1] = v;
+                    }
                 }
                 __syncthreads();
                 if (wv == 0) {
@@ -480,7 +501,8 @@ static int32_t launch_locw(jch_ctx *ctx, locw_args &g)
     if (g.q <= 1) return launch_locw_q<KC, 1>(ctx, g);
     if (g.q <= 2) return launch_locw_q<KC, 2>(ctx, g);
     if (g.q <= 4) return launch_locw_q<KC, 4>(ctx, g);
-    return launch_locw_q<KC, 8>(ctx, g);
+    if (g.q <= 8) return launch_locw_q<KC, 8>(ctx, g);
+    return launch_locw_q<KC, 16>(ctx, g);
 }
 
 // ---------------------------------------------------------------- C ABI
@@ -494,7 +516,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     if (!Xtrain || !Ytrain || !Ztrain || !Zq || !Xq || !pred || n < 1 || p < 1 || m < 1 || dd < 1 || k < 1 || nlv_lo < 0 ||
         nlv_hi < nlv_lo || ldx < n || ldy < n || ldzt < n || ldzq < m || ldxq < m)
         return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad arguments");
-    if (q < 1 || q > 8) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: the batched local-PLS kernel handles 1 <= q <= 8 (got q=%lld)", (long long)q);
+    if (q < 1 || q > 16) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: the batched local-PLS kernel handles 1 <= q <= 16 (got q=%lld)", (long long)q);
     if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad loc");
     if (p > JCH_SWEEP_MAXP) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: p > %d not supported", JCH_SWEEP_MAXP);
     if (k > n) k = (int32_t)n;                                    // src/getknn.jl:33

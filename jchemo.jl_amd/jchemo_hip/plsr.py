@@ -599,13 +599,13 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None) -
     le = hi - lo + 1
     k = min(obj.k, n)
     Zt, Zq = _knn_space(obj, X, ctx)
-    batched = q <= 8                                           # the batched kernel's envelope (include/jchemo_hip.h)
+    batched = q <= 16                                          # the batched kernel's envelope (include/jchemo_hip.h)
     pred = np.empty((m, le, q if batched else 1))
     ind = np.empty((m, k), dtype=np.int32); dist = np.empty((m, k)); w = np.empty((m, k))
     xa, ldx = _addr_ld(Xt); ya, ldy = _addr_ld(Yt); za, ldz = _addr_ld(Zt); qa, ldq = _addr_ld(Zq); xqa, ldxq = _addr_ld(X)
     if dev:
         torch.cuda.current_stream(X.device).synchronize()
-    # q > 8: the kernel is still used (on the first y column) for neighbours + weights
+    # q > 16: the kernel is still used (on the first y column) for neighbours + weights
     ctx.check(_lib.load().jch_lwplsr_predict(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, ya, q if batched else 1, ldy,
                                              za, ldz, qa, ldq, Zt.shape[1], xqa, m, ldxq, k, float(obj.h), float(obj.tol), int(obj.scal),
                                              lo, hi, pred.ctypes.data, ind.ctypes.data, dist.ctypes.data, w.ctypes.data))

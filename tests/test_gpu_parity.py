@@ -352,10 +352,13 @@ def test_gridcvlv_zero_weight_folds(scal, J, ctx):
 
 
 @pytest.mark.parametrize("case", [dict(q=3, p=25, scal=False, metric="mahal"), dict(q=2, p=140, scal=True, metric="eucl"),
-                                  dict(q=8, p=300, scal=False, metric="mahal"), dict(q=10, p=25, scal=False, metric="mahal")])
+                                  dict(q=8, p=300, scal=False, metric="mahal"), dict(q=10, p=25, scal=False, metric="mahal"),
+                                  dict(q=16, p=260, scal=True, metric="mahal"), dict(q=13, p=500, scal=False, metric="eucl"),
+                                  dict(q=20, p=25, scal=False, metric="mahal")])
 def test_lwplsr_multiresponse(case, J, ctx):
-    """q > 1: the batched local-fit kernel (q <= 8: kernel matrix p x q and its q x q eigen-solver inside the query's
-    workgroup); q > 8 falls back to one device plskern per query.  Host and device-resident inputs."""
+    """q > 1: the batched local-fit kernel (q <= 16: kernel matrix p x q and its q x q eigen-solver inside the query's
+    workgroup; src/locwlv.jl:18-39 has no limit on q); q > 16 falls back to one device plskern per query.  Host and
+    device-resident inputs."""
     import torch
     q, p = case["q"], case["p"]
     n, m = 800, 6
@@ -369,7 +372,7 @@ def test_lwplsr_multiresponse(case, J, ctx):
     assert O.rel_fro(ref["pred"], np.stack(res.pred, axis=2)) < 1e-8
     one = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=3, ctx=ctx)              # a single nlv -> one matrix (m x q)
     assert one.pred.shape == (m, q) and O.rel_fro(ref["pred"][:, :, 3], one.pred) < 1e-8
-    if q <= 8:
+    if q <= 16:
         Xd = J.colmajor_empty(n, p); Xd.copy_(torch.from_numpy(X)); Yd = J.colmajor_empty(n, q); Yd.copy_(torch.from_numpy(Y))
         Xqd = J.colmajor_empty(m, p); Xqd.copy_(torch.from_numpy(Xq))
         rd = J.predict(J.lwplsr(Xd, Yd, ctx=ctx, **kw), Xqd, nlv=range(0, 6), ctx=ctx)
