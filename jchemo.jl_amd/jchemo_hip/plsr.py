@@ -380,11 +380,13 @@ def _pred_matrix(fm: "Plsr", X, rng, ctx):
     return _predict_range(fm, X, rng[0], rng[-1], ctx)   # rng is contiguous (src/plskern.jl:228)
 
 
-def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Optional[Context] = None):
+def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Optional[Context] = None, rank: Optional[int] = None,
+            world: Optional[int] = None):
     """src/plskern.jl:226-238: a collection of nlv becomes the contiguous range max(0,min):min(a,max); one
-    value -> matrix, several -> list of matrices.  All values are computed in ONE pass over X."""
+    value -> matrix, several -> list of matrices.  All values are computed in ONE pass over X.
+    `rank` / `world` (kNN-LWPLSR only): split the queries over `world` replicas, see lwplsr_predict."""
     if isinstance(fm, Lwplsr):
-        return lwplsr_predict(fm, X, nlv=nlv, ctx=ctx)
+        return lwplsr_predict(fm, X, nlv=nlv, ctx=ctx, rank=rank, world=world)
     if isinstance(fm, Plsrda):
         return plsrda_predict(fm, X, nlv=nlv, ctx=ctx)
     if isinstance(fm, Plslda):
@@ -571,8 +573,52 @@ def _knn_space(obj: Lwplsr, Xq, ctx):
     return Zt, Zq
 
 
-def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None) -> LwplsrPred:
-    """`predict(object::Lwplsr, X; nlv)` — src/lwplsr.jl:134-166."""
+def query_shard(m: int, rank: int, world: int):
+    """Rows [lo, hi) of the m queries that replica `rank` of `world` predicts (the queries of
+    `predict(::Lwplsr)` are independent — src/locwlv.jl:18 runs them under `Threads.@threads` —, so every GPU holds a
+    replica of the training data and takes a contiguous slice of the queries; nothing crosses GPUs but the results)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return (m * rank) // world, (m * (rank + 1)) // world
+
+
+def _merge_lwplsr_parts(parts) -> "LwplsrPred":
+    """Re-assemble the per-replica results (in rank order) into the result of the unsplit call."""
+    parts = [p_ for p_ in parts if p_ is not None]
+    single = not isinstance(parts[0].pred, list)
+    if single:
+        pred = np.concatenate([p_.pred for p_ in parts], axis=0)
+    else:
+        pred = [np.concatenate([p_.pred[a] for p_ in parts], axis=0) for a in range(len(parts[0].pred))]
+    return LwplsrPred(pred, np.concatenate([p_.listnn for p_ in parts], axis=0), np.concatenate([p_.listd for p_ in parts], axis=0),
+                      np.concatenate([p_.listw for p_ in parts], axis=0))
+
+
+def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, rank: Optional[int] = None,
+                   world: Optional[int] = None, gather=None) -> LwplsrPred:
+    """`predict(object::Lwplsr, X; nlv)` — src/lwplsr.jl:134-166.
+
+    Multi-GPU ("replicas", one process per GPU holding the whole training set): pass this process' `rank` and the
+    `world` size; the call predicts the slice `query_shard(m, rank, world)` on its GPU and returns the FULL result on
+    every rank, gathered in rank order with `gather` (default: torch.distributed.all_gather_object on the default
+    process group; any callable part -> list of parts will do, e.g. an MPI allgather)."""
+    if world is not None and world > 1:
+        X = ensure_mat(X)
+        lo, hi = query_shard(X.shape[0], int(rank), int(world))
+        part = None
+        if hi > lo:
+            part = lwplsr_predict(obj, X[lo:hi], nlv=nlv, ctx=ctx)
+            if _is_torch(part.pred) or (isinstance(part.pred, list) and part.pred and _is_torch(part.pred[0])):  # pragma: no cover
+                part = LwplsrPred([t.cpu().numpy() for t in part.pred] if isinstance(part.pred, list) else part.pred.cpu().numpy(),
+                                  part.listnn, part.listd, part.listw)
+        if gather is None:
+            import torch.distributed as dist
+
+            def gather(x):
+                out = [None] * dist.get_world_size()
+                dist.all_gather_object(out, x)
+                return out
+        return _merge_lwplsr_parts(gather(part))
     X = ensure_mat(X)
     try:
         _addr_ld(X)
