@@ -277,6 +277,9 @@ __global__ __launch_bounds__(256) void k_center_xty(double *__restrict__ Xc, int
 //   * fewer, fatter streams are better: ONE 256-thread block per CU beat two (1.90 vs 1.97 ms) and three (2.13); blocks
 //     that each own a private row range are faster or slower by 8 % depending on where hipMalloc put the buffers, row tiles
 //     interleaved over the blocks are not; a mapping that wrote 512-B strips from 512 scattered ranges fell to 2.9 TB/s.
+//   * with one block per CU, 64-column pieces beat 128-column ones (1.68-1.75 vs 1.80-1.84 ms); cutting the 1-KiB pieces at
+//     128-B aligned addresses (a carry strip in LDS for the rows that start mid-line) or padding the row pitch to 128 B
+//     changed nothing once the kernel was free of register spills.
 // So: a block walks row tiles b, b + G, b + 2G, ... (G = blocks = CUs); each tile is TH rows x all columns, worked through
 // in TW-column pieces: every row tile leaves the block as TH complete rows of the copy.  The next piece's loads are
 // issued right after the barrier that publishes the current one.  The B operand of the XtY product (d .* yc, plus the
@@ -554,7 +557,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                               const double *spread2, double *qual)
 {
     const int ones_col = means_out ? q : -1;   // raw mode: needs a free pad column in y group 0 (q <= 15)
-    // Row-panel kernel (k_center_xty_panel): q <= 16 and 16-B aligned columns; defaults (64-row x 128-column pieces, one block
+    // Row-panel kernel (k_center_xty_panel): q <= 16 and 16-B aligned columns; defaults (64-row x 64-column pieces, one block
     // per CU) are the measured best.  JCH_K2_PANEL=0 keeps the tile kernel below; JCH_K2_TH / JCH_K2_TW / JCH_K2_BPC / JCH_K2_NB
     // select tile height / piece width / blocks per CU / block count, JCH_K2_SKIP bits compile parts out for timing.
     // (read on every call, not cached: tools/k2_modes.py compares the variants inside one process, on the same buffers —
@@ -574,7 +577,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
         double *Kpart = (double *)ctx->kpart.ptr;
         dim3 grid(nbx, groups);
         const int th = th_sel == 128 ? 128 : 64;
-        const int tw = (th == 64 && env_int("JCH_K2_TW", 128) == 128) ? 128 : 64;
+        const int tw = (th == 64 && env_int("JCH_K2_TW", 64) == 128) ? 128 : 64;
         const size_t lds = sizeof(double) * ((size_t)th * (tw + 2) + 1024);
         static jch_per_device_once attr_once;
         if (!attr_once.done(ctx->device)) {
