@@ -439,21 +439,6 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
 #pragma unroll
         for (int e = 0; e < 8; ++e) { rf[k][e] = 0.f; zp[k][e] = 0.f; }
     }
-    // rt_j = r_j / s_j (fp32) and off = sum_j m_j * rt_j (fp64, from the fp32-rounded rt so that the row sums and the offset
-    // use the same coefficients): every wave derives them from the replicated fp64 r — identical bits in all waves
-    double offd = 0.0;
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-        const int col = 8 * lane + 512 * k;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (col + e < p) {
-                const float v = (float)(rvec[col + e] / scl[col + e]);
-                rf[k][e] = v;
-                offd += mom[col + e] * (double)v;
-            }
-    }
-    const float off = (float)jch_wave_sum(offd);
     double tt = 0.0, st = 0.0;
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * 4;
@@ -473,7 +458,22 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
         }
     };
     int64_t g = (int64_t)blockIdx.x * 4 + wv;
-    if (g < ngroups) fetch(g);
+    if (g < ngroups) fetch(g);   // (requested before the coefficients below: one memory latency at the head of a launch, not two)
+    // rt_j = r_j / s_j (fp32) and off = sum_j m_j * rt_j (fp64, from the fp32-rounded rt so that the row sums and the offset
+    // use the same coefficients): every wave derives them from the replicated fp64 r — identical bits in all waves
+    double offd = 0.0;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 8 * lane + 512 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (col + e < p) {
+                const float v = (float)(rvec[col + e] / scl[col + e]);
+                rf[k][e] = v;
+                offd += mom[col + e] * (double)v;
+            }
+    }
+    const float off = (float)jch_wave_sum(offd);
     for (; g < ngroups; g += gstride) {
         const int64_t row0 = g * R;
         v4u32 x[R][KC];

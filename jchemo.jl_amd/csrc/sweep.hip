@@ -217,20 +217,8 @@ __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr,
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
         const int col = 2 * lane + 128 * k;
-        const bool in = col < ldr;
-        coff[k] = in ? col : ldr - 2;
-        rf[k] = in ? *reinterpret_cast<const v2f64 *>(rvec + col) : v2f64{0.0, 0.0};
+        coff[k] = col < ldr ? col : ldr - 2;
         zp[k] = v2f64{0.0, 0.0};
-    }
-    double tt = 0.0, st = 0.0, off = 0.0;
-    if (mu) {   // raw mode: t = x.r - mu.r (see k_sweep)
-        double o = 0.0;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const v2f64 m2 = *reinterpret_cast<const v2f64 *>(mu + coff[k]);
-            o += m2.x * rf[k].x + m2.y * rf[k].y;                       // rf is zero past the row end
-        }
-        off = jch_wave_sum(o);
     }
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * nw;
@@ -247,6 +235,24 @@ __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr,
             db[rr] = dw[row];
         }
     };
+    // the first row groups are requested BEFORE the coefficients (r, mu): one memory latency at the head of every launch
+    // instead of two (the head and tail of a launch are what does not shrink with the rows per GPU)
+    int64_t g = (int64_t)blockIdx.x * nw + wv;
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (g + b * gstride < ngroups) fetch(X[b], D[b], g + b * gstride);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) rf[k] = 2 * lane + 128 * k < ldr ? *reinterpret_cast<const v2f64 *>(rvec + 2 * lane + 128 * k) : v2f64{0.0, 0.0};
+    double tt = 0.0, st = 0.0, off = 0.0;
+    if (mu) {   // raw mode: t = x.r - mu.r (see k_sweep)
+        double o = 0.0;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const v2f64 m2 = *reinterpret_cast<const v2f64 *>(mu + coff[k]);
+            o += m2.x * rf[k].x + m2.y * rf[k].y;                       // rf is zero past the row end
+        }
+        off = jch_wave_sum(o);
+    }
     auto process = [&](v2f64 (&x)[R][KC], double (&dv)[R], int64_t gg) {
         const int64_t row0 = gg * R;
         double s[R];
@@ -277,10 +283,6 @@ __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr,
             if (lane < R && row0 + lane < n) tcol[row0 + lane] = tl;
         }
     };
-    int64_t g = (int64_t)blockIdx.x * nw + wv;
-#pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b)
-        if (g + b * gstride < ngroups) fetch(X[b], D[b], g + b * gstride);
     while (g < ngroups) {
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) {
