@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--scal", action="store_true", help="scale the columns by their stds (scal = true; not the headline configuration)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU baseline run (0 = all n: no extrapolation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the secondary host-arrays-in / host-Plsr-out timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -305,6 +306,23 @@ def main():
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
                                    "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps},
         }
+        if world == 1 and not args.no_host_path and args.algo == "plskern" and not bf16:
+            # SURVEY §8(d) "secondary, also reported": host arrays in -> host Plsr out (H2D of X, Y + D2H of T and the small
+            # matrices inside the timed call).  PCIe-bound; never `value`.
+            try:
+                from oracle import c_oracle as CO
+                Xh = CO.fill_uniform(20250112, n_total, p); Yh = CO.fill_uniform(20250113, n_total, q)
+                J.plskern(Xh, Yh, nlv=nlv, scal=bool(args.scal), ctx=ctx)              # staging buffers, page faults
+                ts = []
+                for _ in range(2):
+                    t0 = time.perf_counter(); J.plskern(Xh, Yh, nlv=nlv, scal=bool(args.scal), ctx=ctx); ts.append(time.perf_counter() - t0)
+                th = min(ts)
+                gb = (n_total * (p + q) * 8 + n_total * (k + 1) * 8) / 1e9
+                out["host_arrays"] = {"ms_per_fit": th * 1e3, "value": k / th, "unit": "LV/s", "bytes_over_pcie_gb": gb,
+                                      "effective_gb_per_s": gb / th, "note": "pageable numpy arrays in, host Plsr out; the generator of the host inputs is oracle/ (test data only)"}
+                del Xh, Yh
+            except Exception as e:  # noqa: BLE001
+                out["host_arrays"] = {"value": None, "note": f"failed: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n_total, p, q, nlv, args.cpu_sample_rows or n_total)

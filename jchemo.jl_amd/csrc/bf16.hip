@@ -533,6 +533,169 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(const bf16_t *__restrict__ X
     }
 }
 
+// ---------------------------------------------------------------- K4 v2 (bf16 storage): lighter instruction stream
+// k_sweep_bf16<1, 4> issues ~400 instructions per 4 KB wave-iteration (177 register copies of the prefetch buffer, a
+// branch pair around every load, 19 ds_bpermute, per-row f32 <-> f64 conversions): at 3 waves per SIMD that is as long as
+// the memory time of those bytes — the bf16 sweep was issue-bound at 5.8 TB/s.  Same recipe as k_sweep_v2 (sweep.hip):
+// R = 8 rows per wave-iteration in two rotating register buffers, unconditional clamped loads, row sums folded with
+// v_permlane32_swap / v_permlane16_swap + DPP (one dword per value in fp32), tt / st accumulated in fp32 inside an
+// iteration and in fp64 across iterations, first rows requested before the coefficients.
+typedef unsigned v2u32b __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bf_fold32(float &a, float b)
+{
+    const v2u32b r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ void bf_fold16(float &a, float b)
+{
+    const v2u32b r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+template <int CTRL>
+__device__ __forceinline__ float bf_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// every lane of the 8-lane group g = lane >> 3 ends up with the 64-lane total of row rowmap(g) (see jch_rowsums, sweep.hip)
+template <int R>
+__device__ __forceinline__ float bf_rowsums(float (&s)[R], int lane)
+{
+    static_assert(R == 4 || R == 8, "R");
+#pragma unroll
+    for (int i = 0; i < R; i += 2) bf_fold32(s[i], s[i + 1]);
+#pragma unroll
+    for (int i = 0; i < R; i += 4) bf_fold16(s[i], s[i + 2]);
+    float h;
+    if (R == 8) {
+        const bool up = (lane & 8) != 0;
+        const float w = up ? s[4] : s[0], z = up ? s[0] : s[4];
+        h = w + bf_dpp<0x128>(z);
+    } else {
+        h = s[0] + bf_dpp<0x128>(s[0]);
+    }
+    h += bf_dpp<0x141>(h);
+    h += bf_dpp<0xB1>(h);
+    h += bf_dpp<0x4E>(h);
+    return h;
+}
+template <int R>
+__device__ __forceinline__ constexpr int bf_rowsum_lane(int rr)
+{
+    return 16 * (((rr & 3) == 1) ? 2 : ((rr & 3) == 2) ? 1 : (rr & 3)) + (R == 8 ? 8 * (rr >> 2) : 0);
+}
+
+template <int KC, int R>
+__global__ __launch_bounds__(256) void k_sweep_bf16_v2(const bf16_t *__restrict__ Xr, int64_t n, int ldr, const double *__restrict__ dw,
+                                                       const double *__restrict__ rvec, const double *__restrict__ mom,
+                                                       const double *__restrict__ scl, int p,
+                                                       double *__restrict__ tcol, double *__restrict__ part, int ldpart)
+{
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [4][KC*512] + [8]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int coff[KC];   // element offset of this lane's 8 columns in chunk k, clamped to the row's last 16 bytes
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 8 * lane + 512 * k;
+        coff[k] = col < ldr ? col : ldr - 8;
+    }
+    const int64_t ngroups = (n + R - 1) / R;
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    v4u32 X[2][R][KC];
+    double D[2][R];   // (kept as loaded: converting here would make the prefetch wait for its own loads)
+    auto fetch = [&](v4u32 (&xb)[R][KC], double (&db)[R], int64_t gg) {
+        const int64_t r0 = gg * R;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int64_t row = r0 + rr < n ? r0 + rr : n - 1;   // wave-uniform clamp; the row gets weight 0 below
+            const bf16_t *rp = Xr + (size_t)row * (size_t)ldr;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) xb[rr][k] = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(rp + coff[k]));
+            db[rr] = dw[row];
+        }
+    };
+    int64_t g = (int64_t)blockIdx.x * 4 + wv;
+    if (g < ngroups) fetch(X[0], D[0], g);
+    // rt_j = r_j / s_j (fp32) and off = sum_j m_j * rt_j (fp64, from the fp32-rounded rt): see k_sweep_bf16
+    float rf[KC][8], zp[KC][8];
+    double offd = 0.0;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 8 * lane + 512 * k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            rf[k][e] = 0.f; zp[k][e] = 0.f;
+            if (col + e < p) {
+                const float v = (float)(rvec[col + e] / scl[col + e]);
+                rf[k][e] = v;
+                offd += mom[col + e] * (double)v;
+            }
+        }
+    }
+    const float off = (float)jch_wave_sum(offd);
+    double tt = 0.0, st = 0.0;
+    auto process = [&](v4u32 (&x)[R][KC], double (&dv)[R], int64_t gg) {
+        const int64_t row0 = gg * R;
+        float sp[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += bflo(x[rr][k][e]) * rf[k][2 * e] + bfhi(x[rr][k][e]) * rf[k][2 * e + 1];
+            sp[rr] = a;
+        }
+        const float h = bf_rowsums<R>(sp, lane) - off;
+        float ttg = 0.f, stg = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), bf_rowsum_lane<R>(rr)));
+            const float dtf = row0 + rr < n ? (float)dv[rr] * t : 0.f;
+            ttg += dtf * t;
+            stg += dtf;
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    zp[k][2 * e] += dtf * bflo(x[rr][k][e]);
+                    zp[k][2 * e + 1] += dtf * bfhi(x[rr][k][e]);
+                }
+        }
+        tt += (double)ttg;
+        st += (double)stg;
+        {
+            const int src = 16 * (((lane & 3) == 1) ? 2 : ((lane & 3) == 2) ? 1 : (lane & 3)) + (R == 8 ? 8 * ((lane >> 2) & 1) : 0);
+            const float tl = __shfl(h, src, 64);
+            if (lane < R && row0 + lane < n) tcol[row0 + lane] = (double)tl;
+        }
+    };
+    while (g < ngroups) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (g < ngroups) {
+                if (g + gstride < ngroups) fetch(X[b ^ 1], D[b ^ 1], g + gstride);
+                process(X[b], D[b], g);
+                g += gstride;
+            }
+        }
+    }
+    double *zred = red;                 // [4][KC*512]
+    double *tred = red + 4 * KC * 512;  // [8]
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zred[wv * (KC * 512) + 8 * lane + 512 * k + e] = (double)zp[k][e];
+    if (lane == 0) { tred[wv] = tt; tred[4 + wv] = st; }
+    __syncthreads();
+    double *prow = part + (size_t)blockIdx.x * ldpart;
+    for (int c = threadIdx.x; c < ldr; c += 256)
+        prow[c] = ((zred[c] + zred[KC * 512 + c]) + zred[2 * KC * 512 + c]) + zred[3 * KC * 512 + c];
+    if (threadIdx.x == 0) {
+        prow[ldr] = ((tred[0] + tred[1]) + tred[2]) + tred[3];
+        prow[ldr + 1] = ((tred[4] + tred[5]) + tred[6]) + tred[7];
+    }
+}
+
 // zp_j <- (zp_raw_j - m_j * st) / s_j ;  slot [ldz_tt] <- tt      (after the cross-GPU all-reduce)
 // (zt holds nslice partial slices of [zp_raw (ldr_b), tt, st], ld ldzb: summed here in fixed order)
 __global__ __launch_bounds__(256) void k_bf16_fix_zt(const double *__restrict__ zt, int nslice, int ldzb, int ldr_b, int p, int ldr_small,
@@ -574,6 +737,36 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
     double *part = (double *)ctx->part.ptr;
     (void)jch_ev(ctx);
     hipLaunchKernelGGL((k_sweep_bf16<KC, R, PF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
+    (void)jch_ev(ctx);
+    JCH_TRY(jch_launch_reduce_part8(ctx, part, nb, ldpart, m, zt8, ldzb, nslice));
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+template <int KC, int R>
+static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, int ldr_b, const double *d, const double *rvec,
+                                      const double *mom, const double *scl, int p, double *tcol, double *zt8, int ldzb, int *nslice)
+{
+    const size_t lds = sizeof(double) * (4 * KC * 512 + 8);
+    static int bpc = 0;
+    static jch_per_device_once occ_once;
+    if (!occ_once.done(ctx->device)) {
+        int nblk = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_bf16_v2<KC, R>, 256, lds);
+        bpc = (e == hipSuccess && nblk > 0) ? nblk : 2;
+        if (lds > 64 * 1024)
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_bf16_v2<KC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        occ_once.mark(ctx->device);
+    }
+    const int64_t ngroups = (n + R - 1) / R;
+    const char *eb = getenv("JCH_BF16_BPC");
+    const int use_bpc = (eb && atoi(eb) > 0) ? atoi(eb) : bpc;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * use_bpc));
+    const int m = ldr_b + 2, ldpart = (m + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
+    double *part = (double *)ctx->part.ptr;
+    (void)jch_ev(ctx);
+    hipLaunchKernelGGL((k_sweep_bf16_v2<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
     (void)jch_ev(ctx);
     JCH_TRY(jch_launch_reduce_part8(ctx, part, nb, ldpart, m, zt8, ldzb, nslice));
     JCH_HIP(ctx, hipGetLastError());
@@ -680,6 +873,16 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         static int rsel = -1;
         if (rsel < 0) { const char *e = getenv("JCH_BF16_R"); rsel = e ? atoi(e) : 4; }   // measured at n = 1e6, p = 500 with the prefetch: R = 2 / 4 / 8 -> 5.35 / 5.84 / 5.40 TB/s (without: 4.67 / 5.07)
         int nslice = 1;
+        {   // v2 kernels (permlane row sums, rotating buffers); JCH_BF16_V2=0 selects the round-1 kernels below (read per call)
+            const char *e2 = getenv("JCH_BF16_V2");
+            const int v2 = e2 ? atoi(e2) : 1;
+            if (v2 && ldr_b >= 8 && ldr_b <= 1024) {
+                if (ldr_b <= 512) { if (v2 == 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)));
+                                    else JCH_TRY((launch_sweep_bf16_v2_t<1, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice))); }
+                else JCH_TRY((launch_sweep_bf16_v2_t<2, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)));
+                goto swept;
+            }
+        }
 #define JCH_SWB(KC, R) JCH_TRY((launch_sweep_bf16_t<KC, R>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)))
         static int pfsel = -1;
         if (pfsel < 0) { const char *e = getenv("JCH_BF16_PF"); pfsel = e ? atoi(e) : 1; }
@@ -691,6 +894,7 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         else if (ldr_b <= 1024) JCH_SWB(2, 4);
         else JCH_SWB(4, 2);
 #undef JCH_SWB
+    swept:;
         if (ctx->nranks > 1) nslice = JCH_ZT_SLICES;                      // rank-independent message size (unused slices hold zeros)
         // ONE collective per LV: [zp_raw, tt, st].  Fast small-state kernel: it adds the slices, (with the inbox transport)
         // all-reduces them and applies the centring / scaling fix-up itself; generic kernel: separate steps.

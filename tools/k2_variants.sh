@@ -2,7 +2,7 @@
 rounds=$1; shift
 for r in $(seq $rounds); do
 for v in "$@"; do
-  env $v python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+  env $v python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-path 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('round $r', '$v', 'LV/s %.1f'%d['value'], 'prologue ms %.3f'%d['device_ms_per_step']['prologue'], 'sweeps %.3f'%d['device_ms_per_step']['sweeps'], 'fit ms %.3f'%d['device_ms_per_step']['fit'])"
 done
 done
