@@ -38,11 +38,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 T
 README_PLSKERN_LVS = 25 / 8.100469   # README.md:90-91: plskern n=1e6 p=500 q=10 nlv=25 in 8.10 s (i9-10885H)
 
 
+PMC_FILE = "profiles/r02_pmc_sweep.json"
+
+
 def pmc_traffic(algo, n_local, p):
-    """HBM bytes per sweep launch from the committed PMC pass (profiles/r01_pmc_sweep.json: FETCH_SIZE x2 gfx950
-    correction + WRITE_SIZE, separate passes), scaled by rows when this rank holds a different share."""
+    """HBM bytes per sweep launch from the COMMITTED PMC pass (profiles/r02_pmc_sweep.json: FETCH_SIZE x2 gfx950 correction
+    + WRITE_SIZE, separate rocprofv3 passes, tools/final_pmc_r02.sh), scaled by rows when this rank holds a different
+    share.  Not measured in the bench run itself (counters need the profiler); None for shapes without a committed pass."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_sweep.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             pm = json.load(f)
         w = pm["workload"]
         if algo == w["algo"] and p == w["p"]:
@@ -300,7 +304,7 @@ def main():
                           "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches} if args.algo == "plskern2" else
                          {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if (bf16 or args.algo not in ("plskern", "plsnipals")) else pmc_traffic(args.algo, n, p),
-                         "traffic_source": "profiles/r01_pmc_sweep.json: committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of this kernel at this shape, scaled by rows; NOT measured in this run",
+                         "traffic_source": PMC_FILE + ": committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of this kernel at this shape, scaled by rows; NOT measured in this run",
                          "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches,
                          **fit_roofline}),
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,

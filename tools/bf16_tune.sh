@@ -1,3 +1,4 @@
+#!/bin/bash
 for cfg in "4 0" "2 0" "4 4" "2 6"; do
   set -- $cfg
   JCH_BF16_R=$1 JCH_BF16_BPC=$2 python bench.py --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "

@@ -1,3 +1,4 @@
+#!/bin/bash
 # regenerates the round's committed evidence under gpurun_out/final (copied to profiles/ afterwards)
 set -x
 mkdir -p gpurun_out/final

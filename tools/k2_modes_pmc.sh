@@ -1,3 +1,4 @@
+#!/bin/bash
 # per-dispatch counters of the K2 kernel across ctx re-creations (tools/k2_modes.py) — which counter tracks the slow/fast mode?
 export TMPDIR=/tmp; R=$PWD; mkdir -p $R/gpurun_out/r02/modes; cd /tmp
 export JCH_K2_TH=64

@@ -1,3 +1,4 @@
+#!/bin/bash
 for m in 0 1 2 3; do
   JCH_K2_SKIP=$m python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('K2_SKIP=$m prologue ms %.3f'%d['device_ms_per_step']['prologue'])"

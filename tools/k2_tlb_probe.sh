@@ -1,3 +1,4 @@
+#!/bin/bash
 # Does the K2 time of a process correlate with its TLB misses?  4 separate processes, UTCL1 counters + kernel trace each.
 export JCH_K2_TH=64
 for i in 1 2 3 4; do

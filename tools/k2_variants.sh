@@ -1,3 +1,4 @@
+#!/bin/bash
 # K2 variants: prologue ms of the cfg2 bench under different JCH_K2_* settings; usage: k2_variants.sh <rounds> "ENV=.." ...
 rounds=$1; shift
 for r in $(seq $rounds); do

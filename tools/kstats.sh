@@ -1,3 +1,4 @@
+#!/bin/bash
 # rocprofv3 kernel-trace stats of one bench run: tools/kstats.sh <tag> <bench.py args...>  -> gpurun_out/<tag>/ + top kernels on stdout
 export TMPDIR=/tmp; R=$PWD; tag=$1; shift
 mkdir -p $R/gpurun_out/$tag; cd /tmp

@@ -1,3 +1,4 @@
+#!/bin/bash
 # One rocprofv3 PMC pass per counter group over a short bench run; output CSVs under gpurun_out/<tag>/<group>/.
 # usage: tools/pmc_pass.sh <tag> "<counters group 1>" "<counters group 2>" ... -- <bench.py args>
 export TMPDIR=/tmp; R=$PWD; tag=$1; shift

@@ -1,3 +1,4 @@
+#!/bin/bash
 # HBM traffic of the sweep kernel from PMC counters, one counter set per pass (MI355X_MICROARCH.md: TCC has 4 slots,
 # FETCH_SIZE costs 3, WRITE_SIZE 2 -> separate passes).  Output: gpurun_out/pmc_{fetch,write}/
 export TMPDIR=/tmp; R=$PWD; cd /tmp

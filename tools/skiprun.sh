@@ -1,3 +1,4 @@
+#!/bin/bash
 # diagnostic: time k_lv_update_fast with sections disabled (JCH_LV_SKIP bitmask; results are wrong, timing only)
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 for m in ${MASKS:-0 8 63}; do

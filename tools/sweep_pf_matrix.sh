@@ -1,3 +1,4 @@
+#!/bin/bash
 # prefetched vs plain sweep kernels over the row widths (KC = 1, 2, 4, 8, 16); prints LV/s and the sweep's GB/s
 for shape in "100 4 10" "200 4 10" "500 10 25" "1000 4 12" "2000 1 10"; do
   set -- $shape

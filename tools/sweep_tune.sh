@@ -1,3 +1,4 @@
+#!/bin/bash
 # diagnostic: HBM read ceiling + sweep variants (rows per iteration, non-temporal loads, blocks per CU)
 tools/hbm_read_bw
 for cfg in "4 0 0" "4 1 0" "2 0 0" "2 1 0" "8 0 0" "8 1 0" "4 0 2" "4 0 3" "8 0 2" "2 0 4"; do

@@ -1,3 +1,4 @@
+#!/bin/bash
 # sweep variants: device ms of the 25 sweeps of the cfg2 bench under different JCH_SWEEP_* settings; usage: sweep_variants.sh <rounds> [bench args --] "ENV=.." ...
 rounds=$1; shift
 extra=""
