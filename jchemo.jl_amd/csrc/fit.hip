@@ -140,6 +140,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     s.mom = cv.take(p + q); s.scl = cv.take(p + q);
     double *niter_dev = cv.take(nlv_cap);
     double *qual_dev = cv.take(8);   // [0]: pivot quality of the raw mode (fetched with the results)
+    double *mshift_buf = cv.take((size_t)ldr + 2);   // raw mode: means - pivot (both zeroed by the weights launch)
     s.mshift = nullptr; s.rs = nullptr;
     const size_t out_bytes = (size_t)((char *)(qual_dev + 8) - (char *)s.P);
     double qual_host = 0.0;
@@ -169,7 +170,6 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
 
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
-    JCH_HIP(ctx, hipMemsetAsync(qual_dev, 0, sizeof(double) * 8, ctx->stream));
     if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
         if (algo != ALGO_KERN) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
         const bool fastb = q <= 16 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
@@ -195,7 +195,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     }
     hipEvent_t ev_begin = jch_ev(ctx);
     // ---- K0 weights; global row count for the nlv clamp (src/plskern.jl:116-117)
-    JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr));
+    JCH_TRY(jch_launch_weights(ctx, wdev, n, dn, s.hdr, qual_dev, 8, mshift_buf, ldr + 2));
     int64_t n_total = n;
     // only a shard smaller than min(p, nlv) has to learn the global row count (one host sync); every rank reaches the
     // same clamp either way, because n_total >= the largest shard
@@ -231,16 +231,14 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
                           q <= 15 && d.reserved == 0 && p <= JCH_SWEEP_MAXP && allow_raw && !getenv("JCH_CENTRED_COPY") &&
                           !(d.scal && getenv("JCH_CENTRED_COPY_SCAL"));
     if (raw_mode) {
-        s.mshift = cv.take((size_t)ldr + 2);
-        JCH_HIP(ctx, hipMemsetAsync(s.mshift, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));
+        // (mshift and the pivot-quality word were zeroed by the weights launch above; the divisor slots `s.mom` handed to K2
+        // as `scl` are never read with SCAL = false; k_extract_means moves the Y means and resets s.scl to ones)
+        s.mshift = mshift_buf;
         double *spread2 = cv.take(p);
         JCH_TRY(jch_launch_pivot(ctx, Xc, ldxc, n, p, s.hdr, s.scl, spread2));                      // scl[0..p): the pivot K2 subtracts
         JCH_TRY(jch_launch_moments(ctx, Yc, ldyc, nullptr, 0, dn, n, q, 0, nullptr, s.scl + p));  // Y means -> scl[p..p+q)
-        hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.mom, p + q, 1.0);   // divisors (unused: SCAL = false)
         JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, /*mom =*/s.scl, /*scl =*/s.mom, false, Xr, ldr, Yr, qpad, s.K, false,
-                                      /*means_out =*/s.mom, /*mshift_out =*/s.mshift, spread2, qual_dev));
-        JCH_HIP(ctx, hipMemcpyAsync(s.mom + p, s.scl + p, sizeof(double) * (size_t)q, hipMemcpyDeviceToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_fill_const, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
+                                      /*means_out =*/s.mom, /*mshift_out =*/s.mshift, spread2, qual_dev, /*ones_out =*/s.scl));
         if (d.scal) {   // stds from ONE streaming pass over the row-major copy; the scaling itself is folded into r / s and zp / s
             s.rs = cv.take((size_t)ldr + 2);
             JCH_HIP(ctx, hipMemsetAsync(s.rs, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));

@@ -115,7 +115,8 @@ hipEvent_t jch_ev(jch_ctx *ctx);  // nullptr when profiling is off
 // ---- kernel launchers (each enqueues on ctx->stream; no host sync) --------------------------------
 // prologue.hip
 int32_t jch_launch_weights(jch_ctx *ctx, const double *w_dev /*may be null*/, int64_t n, double *dnorm,
-                           double *hdr /*[4] device: sum w, n_total*/);
+                           double *hdr /*[4] device: sum w, n_total*/, double *zero0 = nullptr, int nzero0 = 0,
+                           double *zero1 = nullptr, int nzero1 = 0 /*two small regions zeroed by the same launch*/);
 int32_t jch_launch_moments(jch_ctx *ctx, const double *Xc, int64_t ldx, const double *Yc, int64_t ldy,
                            const double *d, int64_t n, int p, int q, const double *means /*null: first moment*/,
                            double *out /*[p+q] device*/, bool do_sqrt = true);
@@ -125,7 +126,8 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                               double *means_out = nullptr /*raw mode: X is copied minus the pivot mom[0..p), its weighted means land here*/,
                               double *mshift_out = nullptr /*means - pivot*/,
                               const double *spread2 = nullptr /*[p] sample variances from jch_launch_pivot*/,
-                              double *qual = nullptr /*[1] max_j |means - pivot| / spread (atomicMax; zeroed by the caller)*/);
+                              double *qual = nullptr /*[1] max_j |means - pivot| / spread (atomicMax; zeroed by the caller)*/,
+                              double *ones_out = nullptr /*raw mode: == mom's storage; [0, p + q) becomes 1.0 and means_out[p..p+q) = mom[p..p+q)*/);
 int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n, int p, const double *hdr /*[1] = n_total*/,
                          double *pivot /*[p] device, same on all ranks*/, double *spread2 /*[p]*/);
 int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, const double *Yr, int qpad, int64_t n,

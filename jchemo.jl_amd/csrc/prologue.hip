@@ -25,9 +25,13 @@ __global__ __launch_bounds__(256) void k_wsum_part(const double *__restrict__ w,
 }
 
 __global__ __launch_bounds__(256) void k_wsum_final(const double *__restrict__ part, int nb, int64_t n, int have_w,
-                                                    double *__restrict__ hdr)
+                                                    double *__restrict__ hdr, double *__restrict__ zero0, int nzero0,
+                                                    double *__restrict__ zero1, int nzero1)
 {
     __shared__ double sc[4];
+    // (small per-fit state that has to start at zero rides along: one launch instead of a memset each)
+    for (int i = threadIdx.x; i < nzero0; i += 256) zero0[i] = 0.0;
+    for (int i = threadIdx.x; i < nzero1; i += 256) zero1[i] = 0.0;
     double s = 0.0;
     if (have_w)
         for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
@@ -46,13 +50,14 @@ __global__ __launch_bounds__(256) void k_wnorm(const double *__restrict__ w, int
         d[i] = (w ? w[i] : 1.0) / sw;
 }
 
-int32_t jch_launch_weights(jch_ctx *ctx, const double *w, int64_t n, double *dnorm, double *hdr)
+int32_t jch_launch_weights(jch_ctx *ctx, const double *w, int64_t n, double *dnorm, double *hdr, double *zero0, int nzero0,
+                           double *zero1, int nzero1)
 {
     const int nb = (int)std::min<int64_t>(1024, (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
     JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * 4096));
     double *part = (double *)ctx->colpart.ptr;
     if (w) hipLaunchKernelGGL(k_wsum_part, dim3(nb), dim3(256), 0, ctx->stream, w, n, part);
-    hipLaunchKernelGGL(k_wsum_final, dim3(1), dim3(256), 0, ctx->stream, part, nb, n, w ? 1 : 0, hdr);
+    hipLaunchKernelGGL(k_wsum_final, dim3(1), dim3(256), 0, ctx->stream, part, nb, n, w ? 1 : 0, hdr, zero0, nzero0, zero1, nzero1);
     JCH_TRY(jch_allreduce_f64(ctx, hdr, 2));  // global sum of weights, global row count
     hipLaunchKernelGGL(k_wnorm, dim3(nb), dim3(256), 0, ctx->stream, w, n, hdr, dnorm);
     JCH_HIP(ctx, hipGetLastError());
@@ -495,14 +500,20 @@ __global__ __launch_bounds__(256) void k_reduce_kpart(const double *__restrict__
 // its results and falls back to the centred copy when the pivot turned out to be far from the means (fit.hip).
 __global__ __launch_bounds__(256) void k_extract_means(double *__restrict__ K, int qpad, int p, int col, const double *__restrict__ pivot,
                                                        double *__restrict__ means, double *__restrict__ mshift,
-                                                       const double *__restrict__ spread2, double *__restrict__ qual)
+                                                       const double *__restrict__ spread2, double *__restrict__ qual, int q,
+                                                       double *__restrict__ ones_out)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    // raw mode, fit.hip: `pivot` is the scale vector's storage ([pivot (p) | Y means (q)]); once this kernel has read its
+    // entry it turns the slot into the divisor 1 the rest of the fit expects there, and the Y means move next to the X
+    // means (ones_out == pivot's storage, or null)
+    if (ones_out && j >= p && j < p + q) { means[j] = pivot[j]; ones_out[j] = 1.0; }
     if (j < p) {
         const double dm = K[(size_t)j * qpad + col];
         means[j] = pivot[j] + dm;
         mshift[j] = dm;
         K[(size_t)j * qpad + col] = 0.0;
+        if (ones_out) ones_out[j] = 1.0;
         if (qual) {
             const double a = fabs(dm);
             const double ratio = a > 0.0 ? a / sqrt(spread2[j]) : 0.0;   // (NaN data: comparison false -> 0, NaN propagates through the fit itself)
@@ -554,7 +565,7 @@ int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n,
 int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d, int64_t n,
                               int p, int q, const double *mom, const double *scl, bool writeback, double *Xr, int ldr,
                               double *Yr, int qpad, double *K, bool scal, double *means_out, double *mshift_out,
-                              const double *spread2, double *qual)
+                              const double *spread2, double *qual, double *ones_out)
 {
     const int ones_col = means_out ? q : -1;   // raw mode: needs a free pad column in y group 0 (q <= 15)
     // Row-panel kernel (k_center_xty_panel): q <= 16 and 16-B aligned columns; defaults (64-row x 64-column pieces, one block
@@ -597,7 +608,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
 #undef JCH_K2P
         hipLaunchKernelGGL(k_reduce_kpart_wide, dim3((p * 16 + 63) / 64), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, 16, K);
         JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
-        if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out, spread2, qual);
+        if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out, spread2, qual, q, ones_out);
         JCH_HIP(ctx, hipGetLastError());
         if (writeback)  // X went back inside the kernel; Y from the row-major copy
             JCH_TRY(jch_launch_export_colmajor(ctx, nullptr, ldr, Yr, qpad, n, p, q, Xc, ldx, Yc, ldy));
@@ -630,7 +641,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
     hipLaunchKernelGGL(k_reduce_kpart, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nslots, kp_rows, p, qpad,
                        K);
     JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
-    if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out, spread2, qual);
+    if (means_out) hipLaunchKernelGGL(k_extract_means, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out, spread2, qual, q, ones_out);
     JCH_HIP(ctx, hipGetLastError());
     if (writeback)  // Y always, X only when it could not be fused above
         JCH_TRY(jch_launch_export_colmajor(ctx, wb_fused ? nullptr : Xr, ldr, Yr, qpad, n, p, q, Xc, ldx, Yc, ldy));
