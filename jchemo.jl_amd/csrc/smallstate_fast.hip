@@ -20,6 +20,7 @@
 
 // diagnostic stamps (JCH_LV_DEBUG only): thread 0 records the shader clock at phase boundaries
 #define JCH_STAMP(k) do { if (g.s.dbg && tid == 0) g.s.dbg[512 + 16 * (g.do_a ? a + 1 : 0) + (k)] = (double)__builtin_readcyclecounter(); } while (0)
+#define JCH_STAMP_W1(k) do { if (g.s.dbg && tid == 64) g.s.dbg[512 + 16 * (g.do_a ? a + 1 : 0) + (k)] = (double)__builtin_readcyclecounter(); } while (0)
 
 
 // P2P: the cross-GPU all-reduce of the sweep output is done HERE through the inbox transport (p2p.hip) instead of by a
@@ -48,6 +49,17 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     const int anext = g.do_a ? a + 1 : a;                 // LVs finished once phase A is done
     const bool rec = g.algo == 0 && anext > 0;            // r-recursion state in use (src/plskern.jl:156-161)
     const bool recA = rec && g.do_a && a_old > 0;         // phase A has old Z rows to update
+    // DEFER (round 2): the dominant-eigenvector step below occupies ONE wave for ~10 k cycles while the other seven idle, so
+    // everything of phase A that the eigenvector does not depend on moves into that window and runs on waves 1..7 — the
+    // global write-back of K_new and of the P / W / R columns, the dots s_i = P_i . zp with their Z_i updates, and the new
+    // row Z_a = zp' K_new / tt.  (Needs both phases in one call and q > 1; otherwise the original order below.)
+    // Measured (JCH_LV_DEBUG stamps, cfg2, LV 12): 34.3 k -> 30.0 k cycles from the end of the staging to the end of the kernel;
+    // by LV 24 the deferred work (4 finished LVs per worker wave) outlasts the eigenvector and the gain is gone.
+    const bool defer = g.algo == 0 && g.do_a && g.do_b && q > 1;
+    // Workers: waves 1, 2, 3, 5, 6, 7.  Wave 4 shares its SIMD with wave 0 (the eigenvector wave) and finished the same
+    // share 4 k cycles after the others, so it gets none.
+    constexpr int DW = FT / 64 - 2;                       // waves doing deferred work
+    const int wi = wv == 0 || wv == 4 ? -1 : (wv < 4 ? wv - 1 : wv - 2);   // worker index, -1: none
     JCH_STAMP(0);
     // ---- issue EVERY global load of this kernel up front: one memory latency instead of one per phase
     double rreg[32];   // R[i][tid], i < min(a_old, 32)                         (phase B tail)
@@ -59,11 +71,11 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     if (recA) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int i = wv + (FT / 64) * v;
+            const int i = defer ? (wi < 0 ? -1 : wi + DW * v) : wv + (FT / 64) * v;   // (defer: waves 0 and 4 own no vector)
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int j = lane + 64 * c;
-                preg[v][c] = (i < a_old && j < p) ? g.s.P[(size_t)i * p + j] : 0.0;
+                preg[v][c] = (i >= 0 && i < a_old && j < p) ? g.s.P[(size_t)i * p + j] : 0.0;
             }
         }
     }
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
                 const int k = tid & 15, gr = tid >> 4;
                 scratch[gr * 16 + k] = k < QP ? kcol_dot(Kl, ldk, k, rl, gr, FT / 16, p) : 0.0;
             }
-            if (recA) {   // s_i = P_i . zp for the finished LVs (wave per vector)
+            if (recA && !defer) {   // s_i = P_i . zp for the finished LVs (wave per vector)
                 for (int v = 0; wv + (FT / 64) * v < a_old; ++v) {
                     const int i = wv + (FT / 64) * v;
                     double s = 0.0;
@@ -212,18 +224,20 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
 #pragma unroll
                 for (int k = 0; k < QP; ++k) {
                     Kl[j * ldk + k] = kv[k];
-                    K[(size_t)j * 16 + k] = kv[k];      // pad columns stay exactly zero (c_k = 0 there)
+                    if (!defer) K[(size_t)j * 16 + k] = kv[k];      // pad columns stay exactly zero (c_k = 0 there)
                 }
-                g.s.P[(size_t)a * p + j] = zp / tt;
-                g.s.W[(size_t)a * p + j] = wl[j];
-                g.s.R[(size_t)a * p + j] = rl[j];
+                if (!defer) {
+                    g.s.P[(size_t)a * p + j] = zp / tt;
+                    g.s.W[(size_t)a * p + j] = wl[j];
+                    g.s.R[(size_t)a * p + j] = rl[j];
+                }
             }
-            if (recA)     // Z_i <- Z_i - (P_i . zp) c'
+            if (recA && !defer)     // Z_i <- Z_i - (P_i . zp) c'
                 for (int i = wv; i < a_old; i += FT / 64)
                     if (lane < QP) Zl[i * QP + lane] -= ul[i] * cl[lane];
             __syncthreads();
             JCH_STAMP(4);
-            if (g.do_b) {   // new row Z_a = P_a' K_new = (zp' K_new) / tt
+            if (g.do_b && !defer) {   // new row Z_a = P_a' K_new = (zp' K_new) / tt
                 const int k = tid & 15, gr = tid >> 4;
                 scratch[FT + gr * 16 + k] = k < QP ? kcol_dot(Kl, ldk, k, ztl, gr, FT / 16, p) : 0.0;
             }
@@ -314,11 +328,52 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         if (tid == 0) vl[0] = 1.0;
         __syncthreads();
     }
-    if (rec && g.do_a && tid < QP) {   // finish Z_a (its partials were written before the Gram barriers)
+    if (rec && g.do_a && !defer && tid < QP) {   // finish Z_a (its partials were written before the Gram barriers)
         double t = 0.0;
 #pragma unroll
         for (int gg = 0; gg < FT / 16; ++gg) t += scratch[FT + gg * 16 + tid];
         Zl[a * QP + tid] = t / ztl[ldr];
+    }
+    if (defer && wi >= 0) {
+        // ---- work of phase A that the eigenvector does not depend on, on waves 1..DW while wave 0 solves
+        const double tt = ztl[ldr];
+        // write-back of K_new, flat and coalesced (one wave-instruction = 4 rows x 16 columns = 512 contiguous bytes; a
+        // thread-per-row loop scatters every store over 64 lines and kept the CU's address unit busy for ~8 k cycles)
+        for (int e = 64 * wi + lane; e < p * 16; e += 64 * DW) K[e] = (e & 15) < QP ? Kl[(e >> 4) * ldk + (e & 15)] : 0.0;
+        for (int j = 64 * wi + lane; j < p; j += 64 * DW) {        // the new P / W / R columns
+            g.s.P[(size_t)a * p + j] = ztl[j] / tt;
+            g.s.W[(size_t)a * p + j] = wl[j];
+            g.s.R[(size_t)a * p + j] = rl[j];
+        }
+        if (recA) {   // s_i = P_i . zp and Z_i <- Z_i - s_i c'  (wave per finished LV: no cross-wave step)
+            for (int v = 0; wi + DW * v < a_old; ++v) {
+                const int i = wi + DW * v;
+                double sd = 0.0;
+                if (v < 4) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int j = lane + 64 * c;
+                        double pij = 0.0;
+#pragma unroll
+                        for (int vv = 0; vv < 4; ++vv)
+                            if (vv == v) pij = preg[vv][c];
+                        sd += pij * ztl[min(j, p - 1)];   // pij is 0 beyond p
+                    }
+                }
+                for (int j = lane + (v < 4 ? 512 : 0); j < p; j += 64) sd += g.s.P[(size_t)i * p + j] * ztl[j];
+                sd = jch_wave_sum(sd);
+                if (lane < QP) Zl[i * QP + lane] -= sd * cl[lane];
+            }
+        }
+        if (rec) {   // new row Z_a = P_a' K_new = (zp' K_new) / tt : 16 columns x (4 row groups per wave) x DW waves; the DW
+                     // partial rows meet in `scratch` and are added up after the barrier below by the thread that owns row a
+            const int k = lane & 15;
+            double zr = k < QP ? kcol_dot(Kl, ldk, k, ztl, wi * 4 + (lane >> 4), 4 * DW, p) : 0.0;
+            zr += __shfl_xor(zr, 16, 64);
+            zr += __shfl_xor(zr, 32, 64);
+            if (lane < 16) scratch[FT + wi * 16 + lane] = zr;
+        }
+        JCH_STAMP_W1(7);
     }
     if (q > 1 && wv == 0) {
         bool solved;
@@ -336,11 +391,25 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     if (rec) {
         if (tid < anext) {   // u = Z v
             double u = 0.0;
+            if (defer && tid == a) {   // the new row arrives as DW partial rows (deferred work above): finish it here
+                const double tt = ztl[ldr];
 #pragma unroll
-            for (int k = 0; k < QP; ++k) u += Zl[tid * QP + k] * vl[k];
+                for (int k = 0; k < QP; ++k) {
+                    double z = 0.0;
+#pragma unroll
+                    for (int w = 0; w < DW; ++w) z += scratch[FT + w * 16 + k];
+                    z /= tt;
+                    Zl[a * QP + k] = z;
+                    g.s.Z[a * QP + k] = z;
+                    u += z * vl[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < QP; ++k) u += Zl[tid * QP + k] * vl[k];
+            }
             ul[tid] = u;
         }
-        for (int e = tid; e < anext * QP; e += FT) g.s.Z[e] = Zl[e];
+        for (int e = tid; e < (defer ? a : anext) * QP; e += FT) g.s.Z[e] = Zl[e];
     }
     // w_raw = K v ; ||w_raw||
     double wr[JCH_SWEEP_MAXP / FT];
