@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 100 /* 0.1.0 */
+#define JCH_VERSION 101 /* 0.1.1: + jch_ctx_get_counter; jch_lwplsr_predict accepts q <= 16 */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
