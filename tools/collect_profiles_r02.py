@@ -4,6 +4,9 @@ import csv, glob, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final2"); DST = os.path.join(ROOT, "profiles")
 PEAK = 8000.0
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]  # (gpurun merges successive runs into the same tree: take the latest)
 def cp(a, b):
     if os.path.exists(os.path.join(SRC, a)):
         shutil.copy(os.path.join(SRC, a), os.path.join(DST, b)); return True
@@ -24,13 +27,13 @@ with open(os.path.join(DST, "r02_rank_share_table.jsonl"), "w") as f:
         if os.path.exists(p_):
             d = json.load(open(p_)); f.write(json.dumps({"rows_per_gpu": d["config"]["rows_per_gpu"], "LV_per_s": d["value"], "device_ms_per_step": d["device_ms_per_step"], "sweep_GBps": d["roofline"]["achieved"]}) + "\n")
 for tag, out in (("stats", "r02_final_kernel_stats.csv"), ("stats_cfg4", "r02_final_kernel_stats_cfg4_plsnipals.csv"), ("stats_bf16", "r02_final_kernel_stats_bf16.csv")):
-    fs = glob.glob(os.path.join(SRC, tag, "*", "*kernel_stats.csv"))
+    fs = newest(os.path.join(SRC, tag, "*", "*kernel_stats.csv"))
     if fs: shutil.copy(fs[0], os.path.join(DST, out))
 # ---- PMC -> bytes per launch
 def pmc(tag):
     res = collections.defaultdict(dict)
     for g in sorted(glob.glob(os.path.join(SRC, tag, "g*"))):
-        cc = glob.glob(os.path.join(g, "*", "*_counter_collection.csv")); kt = glob.glob(os.path.join(g, "*", "*_kernel_trace.csv"))
+        cc = newest(os.path.join(g, "*", "*_counter_collection.csv")); kt = newest(os.path.join(g, "*", "*_kernel_trace.csv"))
         if not cc: continue
         acc = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
         for r in csv.DictReader(open(cc[0])): acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))

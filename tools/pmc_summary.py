@@ -6,7 +6,8 @@ out = collections.defaultdict(dict)
 for g in sorted(glob.glob(os.path.join(root, "g*"))):
     if not os.path.isdir(g):
         continue
-    cc = glob.glob(os.path.join(g, "*", "*_counter_collection.csv")); kt = glob.glob(os.path.join(g, "*", "*_kernel_trace.csv"))
+    cc = sorted(glob.glob(os.path.join(g, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]
+    kt = sorted(glob.glob(os.path.join(g, "*", "*_kernel_trace.csv")), key=os.path.getmtime)[-1:]
     if not cc:
         continue
     dur = collections.defaultdict(list)
