@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "jch_internal.h"
@@ -80,7 +81,9 @@ __global__ __launch_bounds__(256) void k_affine_gemm32(const double *__restrict_
 {
     __shared__ double bl[G32_CH * 33];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t i0 = (int64_t)blockIdx.x * 128 + 32 * wv;
+    // row tiles of 128 rows, interleaved over a persistent grid (JCH_GEMM_BPC blocks per CU; 0 = one block per tile)
+    for (int64_t tile = blockIdx.x; tile * 128 < m; tile += gridDim.x) {
+    const int64_t i0 = tile * 128 + 32 * wv;
     const int64_t irow = i0 + 2 * (lane & 15);        // this lane's row pair
     const bool two = irow + 1 < m, one = irow < m;
     const bool vec = two && (ldx % 2 == 0) && ((((uintptr_t)Xc) & 15) == 0) && (irow % 2 == 0);
@@ -143,13 +146,18 @@ __global__ __launch_bounds__(256) void k_affine_gemm32(const double *__restrict_
                 if (i < m) out[(size_t)i + (size_t)col * (size_t)ldo] = acc[par][t][reg] + bv;
             }
     }
+    }
 }
 
 int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p, int64_t ldx, const double *Bs, int k, int kpad,
                                const double *bias, double *out, int64_t ldo)
 {
     if (kpad <= 32 && !getenv("JCH_GEMM_GENERIC")) {
-        hipLaunchKernelGGL(k_affine_gemm32, dim3((unsigned)((m + 127) / 128)), dim3(256), 0, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias,
+        const char *eb = getenv("JCH_GEMM_BPC");
+        const int bpc = eb ? atoi(eb) : 0;
+        const int64_t ntile = (m + 127) / 128;
+        const unsigned nb = (unsigned)(bpc > 0 ? std::min<int64_t>(ntile, (int64_t)ctx->cus * bpc) : ntile);
+        hipLaunchKernelGGL(k_affine_gemm32, dim3(nb), dim3(256), 0, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias,
                            k, out, ldo);
         JCH_HIP(ctx, hipGetLastError());
         return JCH_OK;
