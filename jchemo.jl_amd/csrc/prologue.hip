@@ -309,6 +309,8 @@ __global__ __launch_bounds__(256, 2) void k_center_xty_panel(double *__restrict_
     double *xt = xp_lds;                 // [TH][PT]
     double *cm_s = xt + TH * PT;         // [512] column shifts of this column group
     double *cs_s = cm_s + 512;           // [512] column divisors (SCAL)
+    constexpr bool BLDS = TH > 64;       // tall tiles: the B operand lives in LDS (TH x 16 doubles) instead of TH / 4 registers
+    double *yt_s = cs_s + 512;           // [TH][16]  (BLDS only)
     constexpr int NL = TH / 8;           // 16-B loads per thread and 64-column half
     constexpr int HALF = TH / 2;         // row pairs per column
     constexpr int CPI = 128 / TH;        // columns per wave-instruction (1: TH = 128, 2: TH = 64)
@@ -362,9 +364,11 @@ __global__ __launch_bounds__(256, 2) void k_center_xty_panel(double *__restrict_
     __syncthreads();   // cm_s / cs_s
     for (; i0 < rend; i0 += istep) {
         // ---- B operand of this row range in the MFMA layout: lane l -> (k = row 4 kk + (l >> 4), n = y column l & 15)
-        double breg[TH / 4];
+        //      (registers: every wave builds all of it; LDS: each wave builds a quarter, published by the first fill barrier)
+        double breg[BLDS ? 1 : TH / 4];
 #pragma unroll
-        for (int kk = 0; kk < TH / 4; ++kk) {
+        for (int kq = 0; kq < (BLDS ? TH / 16 : TH / 4); ++kq) {
+            const int kk = BLDS ? wv * (TH / 16) + kq : kq;
             const int64_t row = i0 + 4 * kk + (lane >> 4);
             const bool ok = row < rend;
             double yv = 0.0, dv = 0.0;
@@ -374,11 +378,13 @@ __global__ __launch_bounds__(256, 2) void k_center_xty_panel(double *__restrict_
                     yv = Yc[(size_t)row + (size_t)ycol * (size_t)ldy] - ym;
                     if (SCAL) yv /= ysd;
                 }
-                if (wv == 0 && blockIdx.y == 0) Yr[(size_t)row * 16 + ycol] = yv;
+                if ((BLDS || wv == 0) && blockIdx.y == 0) Yr[(size_t)row * 16 + ycol] = yv;
             }
             // raw mode: the pad column `ones_col` carries the weights themselves -> that column of X'D[Yc | 1] is the vector
             // of weighted column sums of X (the means come out of the same pass, fit.hip)
-            breg[kk] = ycol == ones_col ? dv : dv * yv;
+            const double bv = ycol == ones_col ? dv : dv * yv;
+            if (BLDS) yt_s[(4 * kk + (lane >> 4)) * 16 + ycol] = bv;
+            else breg[kq] = bv;
         }
         // (runtime loop over the tiles: only the MFMA section below names its accumulator statically)
 #pragma unroll 1
@@ -418,8 +424,9 @@ __global__ __launch_bounds__(256, 2) void k_center_xty_panel(double *__restrict_
                 // ---- XtY on the matrix cores: wave wv owns x columns 16 wv .. 16 wv + 15 of the half tile
                 if (!(dbg_skip & 1) && ct < ntile) {
                     const double *ap = xt + (lane >> 4) * PT + 64 * sub + 16 * wv + (lane & 15);
+                    const double *bp = yt_s + (lane >> 4) * 16 + (lane & 15);
 #define JCH_XP_MM(T) case T: _Pragma("unroll") for (int kk = 0; kk < TH / 4; ++kk) \
-                             acc[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk * PT], breg[kk], acc[T], 0, 0, 0); break;
+                             acc[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk * PT], BLDS ? bp[64 * kk] : breg[BLDS ? 0 : kk], acc[T], 0, 0, 0); break;
                     switch (ct) { JCH_XP_MM(0) JCH_XP_MM(1) JCH_XP_MM(2) JCH_XP_MM(3) JCH_XP_MM(4) JCH_XP_MM(5) JCH_XP_MM(6) JCH_XP_MM(7) default: break; }
 #undef JCH_XP_MM
                 }
@@ -588,13 +595,13 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
         double *Kpart = (double *)ctx->kpart.ptr;
         dim3 grid(nbx, groups);
         const int th = th_sel == 128 ? 128 : 64;
-        const int tw = (th == 64 && env_int("JCH_K2_TW", 64) == 128) ? 128 : 64;
-        const size_t lds = sizeof(double) * ((size_t)th * (tw + 2) + 1024);
+        const int tw = env_int("JCH_K2_TW", 64) == 128 ? 128 : 64;
+        const size_t lds = sizeof(double) * ((size_t)th * (tw + 2) + 1024 + (th > 64 ? (size_t)th * 16 : 0));
         static jch_per_device_once attr_once;
         if (!attr_once.done(ctx->device)) {
-#define JCH_K2P_ATTR(TH, TW, WB, SC) JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_center_xty_panel<TH, TW, WB, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024))
+#define JCH_K2P_ATTR(TH, TW, WB, SC) JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_center_xty_panel<TH, TW, WB, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
 #define JCH_K2P_ATTR4(TH, TW) JCH_K2P_ATTR(TH, TW, false, false); JCH_K2P_ATTR(TH, TW, false, true); JCH_K2P_ATTR(TH, TW, true, false); JCH_K2P_ATTR(TH, TW, true, true)
-            JCH_K2P_ATTR4(128, 64); JCH_K2P_ATTR4(64, 64); JCH_K2P_ATTR4(64, 128);
+            JCH_K2P_ATTR4(128, 64); JCH_K2P_ATTR4(64, 64); JCH_K2P_ATTR4(64, 128); JCH_K2P_ATTR4(128, 128);
 #undef JCH_K2P_ATTR4
 #undef JCH_K2P_ATTR
             attr_once.mark(ctx->device);
@@ -603,7 +610,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                                                    mom, scl, Xr, ldr, Yr, Kpart, kp_rows, ones_col, dbg_skip)
 #define JCH_K2P_TH(TH, TW) do { if (writeback && scal) JCH_K2P(TH, TW, true, true); else if (writeback) JCH_K2P(TH, TW, true, false); \
                                 else if (scal) JCH_K2P(TH, TW, false, true); else JCH_K2P(TH, TW, false, false); } while (0)
-        if (th == 128) JCH_K2P_TH(128, 64); else if (tw == 128) JCH_K2P_TH(64, 128); else JCH_K2P_TH(64, 64);
+        if (th == 128 && tw == 128) JCH_K2P_TH(128, 128); else if (th == 128) JCH_K2P_TH(128, 64); else if (tw == 128) JCH_K2P_TH(64, 128); else JCH_K2P_TH(64, 64);
 #undef JCH_K2P_TH
 #undef JCH_K2P
         hipLaunchKernelGGL(k_reduce_kpart_wide, dim3((p * 16 + 63) / 64), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, 16, K);
