@@ -276,9 +276,9 @@ def main():
         value = k * args.steps / dt
         avg_sweep_s = (sweep_ms / max(sweep_launches, 1)) * 1e-3
         achieved = sweep_bytes / avg_sweep_s / 1e9 if avg_sweep_s > 0 else 0.0
-        kernel = {"plskern": "k_sweep (fused t = X r, tt, zp = X'Dt, T column store)", "plsnipals": "k_sweep + k_deflate (per LV)",
+        kernel = {"plskern": "k_sweep (fused t = X r, tt, zp = X'Dt, T column store)", "plsnipals": "k_sweep_lazy + k_kpass_lazy (per LV: two reads of X, rows rewritten every 6th LV; bytes_per_launch = bytes actually moved per LV)",
                   "plskern2": "k_syrk (X'DX on v_mfma_f64_16x16x4, once per fit)", "plssimp": "k_sweep (same fused sweep as plskern)",
-                  "plsrosa": "k_sweep (same fused sweep as plskern)", "plswold": "k_sweep + k_deflate (per LV)"}[args.algo]
+                  "plsrosa": "k_sweep (same fused sweep as plskern)", "plswold": "k_sweep + k_deflate (per LV; q <= 4: postponed write-back as plsnipals)"}[args.algo]
         # whole-fit and prologue fractions of the HBM roof (plskern-shaped f64 fits): the one-pass prologue
         # moves 2 n p 8 bytes (read column-major X, write the row-major copy), every LV one more read of the copy
         fit_roofline = {}

@@ -283,6 +283,185 @@ static int32_t launch_deflate_stream(jch_ctx *ctx, double *Xr, int64_t n, int p,
     return launch_deflate_stream_pf<KC, R, Q, false>(ctx, Xr, n, p, ldr, Yr, qpad, d, tcol, zpc, Knext);
 }
 
+// ---- postponed write-back (see k_sweep_lazy, sweep.hip): the same pass as k_deflate_stream, but the rows in memory are
+// `npend - 1` deflations behind.  All pending corrections (oldest first; the newest is this LV's) are applied in registers
+// with the eager kernel's own expression, K_next is accumulated from the result, Y is deflated eagerly (128 B per row),
+// and the rows are stored only when `flush` — every m-th LV.  HBM bytes per LV: n*ldr*8 read + n*ldr*8/m written.
+__device__ __forceinline__ double jch_kp_readlane(double v, int srclane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srclane), __builtin_amdgcn_readlane(__double2loint(v), srclane));
+}
+template <int KC, int R, int Q>
+__global__ __launch_bounds__(256) void k_kpass_lazy(double *__restrict__ Xr, int64_t n, int ldr, double *__restrict__ Yr, int qpad,
+                                                    const double *__restrict__ dw, const double *__restrict__ pend_p, int npend,
+                                                    const double *__restrict__ tpend, int64_t tstride,
+                                                    const double *__restrict__ cvec, int flush,
+                                                    double *__restrict__ part, int ldpart)
+{
+    extern __shared__ __attribute__((aligned(16))) double red[];  // loop: [npend][KC*128]; end: [4][Q][KC*128]
+    constexpr int LDP = KC * 128;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v2f64 kacc[Q][KC];
+    int coff[KC];
+    double cf[Q];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 2 * lane + 128 * k;
+        coff[k] = col < ldr ? col : ldr - 2;
+#pragma unroll
+        for (int y = 0; y < Q; ++y) kacc[y][k] = v2f64{0.0, 0.0};
+    }
+    const int64_t ngroups = (n + R - 1) / R;
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    const int pl = min(lane, npend * R - 1);                            // npend >= 1 here
+    const int64_t pk_off = (int64_t)(pl / R) * tstride;
+    const int pr = pl % R;
+    v2f64 xn[R][KC];
+    double dn_[R], tpn = 0.0;
+    auto fetch = [&](int64_t gg) {
+        const int64_t r0 = gg * R;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int64_t row = r0 + rr < n ? r0 + rr : n - 1;
+            const double *rp = Xr + (size_t)row * (size_t)ldr;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) xn[rr][k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(rp + coff[k]));
+            dn_[rr] = dw[row];
+        }
+        tpn = tpend[pk_off + (r0 + pr < n ? r0 + pr : n - 1)];
+    };
+    int64_t g = (int64_t)blockIdx.x * 4 + wv;
+    if (g < ngroups) fetch(g);
+    for (int e = threadIdx.x; e < npend * LDP; e += 256) red[e] = pend_p[e];
+#pragma unroll
+    for (int y = 0; y < Q; ++y) cf[y] = cvec[y];
+    __syncthreads();
+    for (; g < ngroups; g += gstride) {
+        const int64_t row0 = g * R;
+        v2f64 x[R][KC];
+        double dc[R];
+        const double tpc = tpn;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            dc[rr] = dn_[rr];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) x[rr][k] = xn[rr][k];
+        }
+        if (g + gstride < ngroups) fetch(g + gstride);
+        double tk[R];
+        for (int k = 0; k < npend; ++k) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) tk[rr] = jch_kp_readlane(tpc, k * R + rr);
+            const double *pl_k = red + k * LDP + 2 * lane;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                const v2f64 pf = *reinterpret_cast<const v2f64 *>(pl_k + 128 * kk);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    x[rr][kk].x -= tk[rr] * pf.x;
+                    x[rr][kk].y -= tk[rr] * pf.y;
+                }
+            }
+        }
+        // (tk now holds this LV's scores: the newest pending entry)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int64_t row = row0 + rr;
+            if (row < n) {   // wave-uniform
+                if (flush) {
+                    double *wp = Xr + (size_t)row * (size_t)ldr;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k)
+                        if (2 * lane + 128 * k < ldr) __builtin_nontemporal_store(x[rr][k], reinterpret_cast<v2f64 *>(wp + 2 * lane + 128 * k));
+                }
+#pragma unroll
+                for (int y = 0; y < Q; ++y) {
+                    const double yn = Yr[(size_t)row * qpad + y] - tk[rr] * cf[y];
+                    if (lane == y) Yr[(size_t)row * qpad + y] = yn;
+                    const double s = dc[rr] * yn;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        kacc[y][k].x += s * x[rr][k].x;
+                        kacc[y][k].y += s * x[rr][k].y;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                            // pending loadings dead: the area becomes the combine buffer
+    double *prow = part + (size_t)blockIdx.x * ldpart;
+#pragma unroll
+    for (int y = 0; y < Q; ++y) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            *reinterpret_cast<v2f64 *>(red + (size_t)(wv * Q + y) * (KC * 128) + 2 * lane + 128 * k) = kacc[y][k];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Q * ldr; e += 256) {
+        const int y = e / ldr, c = e - y * ldr;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(size_t)(w * Q + y) * (KC * 128) + c];
+        prow[e] = s;
+    }
+}
+
+template <int KC, int R, int Q>
+static int32_t launch_kpass_lazy_t(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, const double *d,
+                                   const double *pend_p, int npend, int npend_max, const double *tpend, int64_t tstride,
+                                   const double *cvec, bool flush, double *Knext)
+{
+    const size_t lds_red = sizeof(double) * 4 * Q * KC * 128;
+    const size_t lds = std::max(lds_red, sizeof(double) * (size_t)npend_max * KC * 128);
+    static int bpc = 0;
+    static jch_per_device_once once;
+    if (!once.done(ctx->device)) {
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_kpass_lazy<KC, R, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int nblk = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_kpass_lazy<KC, R, Q>, 256, lds_red);
+        bpc = (e == hipSuccess && nblk > 0) ? nblk : 1;
+        once.mark(ctx->device);
+    }
+    if (lds > 160 * 1024) return jch_fail(ctx, JCH_EINVAL, "internal: lazy NIPALS pass: %zu bytes of LDS", lds);
+    const char *e_bpc = getenv("JCH_DEFLATE_BPC");
+    int use_bpc = (e_bpc && atoi(e_bpc) > 0) ? std::min(atoi(e_bpc), bpc) : bpc;
+    use_bpc = std::max(1, std::min<int>(use_bpc, (int)((160 * 1024) / lds)));
+    const int64_t ngroups = (n + R - 1) / R;
+    const int nb = (int)std::max<int64_t>(std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * use_bpc), 1);
+    const int ldpart = (Q * ldr + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nb * ldpart));
+    double *part = (double *)ctx->kpart.ptr;
+    (void)jch_ev(ctx);
+    hipLaunchKernelGGL((k_kpass_lazy<KC, R, Q>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, Yr, qpad, d, pend_p, npend, tpend,
+                       tstride, cvec, flush ? 1 : 0, part, ldpart);
+    (void)jch_ev(ctx);
+    if (Knext) {
+        hipLaunchKernelGGL(k_reduce_kstream, dim3((Q * ldr + 63) / 64), dim3(1024), 0, ctx->stream, part, nb, ldpart, ldr, p, Q, qpad, Knext);
+        JCH_TRY(jch_allreduce_f64(ctx, Knext, (size_t)p * qpad));
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+int32_t jch_launch_kpass_lazy(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q, const double *d,
+                              const double *pend_p, int npend, int npend_max, const double *tpend, int64_t tstride,
+                              const double *cvec, bool flush, double *Knext)
+{
+    if (npend < 1 || npend > npend_max || npend_max > jch_nipals_lazy_capacity(ldr, q))
+        return jch_fail(ctx, JCH_EINVAL, "internal: lazy NIPALS pass: bad pending count");
+#define JCH_KL(KC, R) do { \
+        if (q == 1) return launch_kpass_lazy_t<KC, R, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, pend_p, npend, npend_max, tpend, tstride, cvec, flush, Knext); \
+        if (q == 2) return launch_kpass_lazy_t<KC, R, 2>(ctx, Xr, n, p, ldr, Yr, qpad, d, pend_p, npend, npend_max, tpend, tstride, cvec, flush, Knext); \
+        return launch_kpass_lazy_t<KC, R, 4>(ctx, Xr, n, p, ldr, Yr, qpad, d, pend_p, npend, npend_max, tpend, tstride, cvec, flush, Knext); } while (0)
+    if (ldr <= 128) JCH_KL(1, 4);
+    if (ldr <= 256) JCH_KL(2, 4);
+    if (ldr <= 512) JCH_KL(4, 2);
+    if (ldr <= 1024) JCH_KL(8, 1);
+    if (q == 1) return launch_kpass_lazy_t<16, 2, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, pend_p, npend, npend_max, tpend, tstride, cvec, flush, Knext);
+    return launch_kpass_lazy_t<16, 1, 2>(ctx, Xr, n, p, ldr, Yr, qpad, d, pend_p, npend, npend_max, tpend, tstride, cvec, flush, Knext);
+#undef JCH_KL
+}
+
 int32_t jch_launch_deflate(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q,
                            const double *d, const double *tcol, const double *zpc, double *Knext)
 {

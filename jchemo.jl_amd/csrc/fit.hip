@@ -128,7 +128,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     if (!host && io.T) Tdev = io.T;
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
-    const size_t small_bytes = 256 * 20 + sizeof(double) * (64 + (size_t)p + (size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
+    const size_t small_bytes = 256 * 21 + sizeof(double) * 16 * 2048 + sizeof(double) * (64 + (size_t)p + (size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
                                                          (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
@@ -168,6 +168,15 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         return JCH_OK;
     };
     s.dbg = getenv("JCH_LV_DEBUG") ? cv.take(512 + 16 * (nlv_cap + 2)) : nullptr;
+    // plsnipals / plswold with a narrow Y: the rewrite of X after every LV is postponed and done every `defer_m`-th LV
+    // (k_sweep_lazy / k_kpass_lazy; JCH_NIPALS_DEFER=1 restores the eager deflation)
+    int defer_m = 1;
+    double *pend_p = nullptr;
+    if (!kern_like && d.dtype == JCH_F64) {
+        const char *e_m = getenv("JCH_NIPALS_DEFER");
+        defer_m = std::max(1, std::min(e_m ? atoi(e_m) : JCH_NIPALS_DEFER_DEFAULT, jch_nipals_lazy_capacity(ldr, q)));
+        if (defer_m > 1) pend_p = cv.take((size_t)defer_m * jch_nipals_lazy_pitch(ldr));
+    }
 
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
     if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
@@ -263,6 +272,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     // ---- LV loop
     const size_t sweep_ev0 = ctx->ev_used;
     const bool variant2 = d.reserved == 1;
+    int x_reads = 0, x_writes = 0;   // plsnipals-shaped loops: whole passes over the working copy (profile: bytes actually moved)
     if (variant2) {   // OPT-IN kernel algorithm #2 (kern2.hip): Gram once, LV loop without X and without collectives
         if (algo != ALGO_KERN || !fast) return jch_fail(ctx, JCH_EINVAL, "%s: variant 2 needs plskern with q <= 16 and p <= %d", who, JCH_SWEEP_MAXP);
         JCH_TRY(jch_reserve(ctx, ctx->gram, sizeof(double) * (size_t)p * ldr));
@@ -281,6 +291,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     else if (algo == ALGO_WOLD && all_fast) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, 0, nlv, io.tol, io.maxit));
     else if (algo == ALGO_WOLD) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, 0 | 0x20000000, nlv, 4, 1, ldz, false, false, nullptr, 0, 0, io.tol, io.maxit));
     else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, kern_like ? 0 : 1, 1, ldz, fast));
+    int npend = 0, pend_a0 = 0;   // postponed deflations: LVs pend_a0 .. pend_a0 + npend - 1
+    if (pend_p) JCH_HIP(ctx, hipMemsetAsync(pend_p, 0, sizeof(double) * (size_t)defer_m * jch_nipals_lazy_pitch(ldr), ctx->stream));
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (kern_like) {
@@ -297,8 +309,11 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
                 else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast));
             }
         } else {
-            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
+            if (pend_p) JCH_TRY(jch_launch_sweep_lazy(ctx, Xr, n, ldr, dn, s.w, Yr, qpad, tcol, s.zt, ldz, max_slices, &nslice, pend_p, npend,
+                                                      defer_m - 1, Tdev + (size_t)pend_a0 * (size_t)n, n));
+            else JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;
+            ++x_reads;
             if (fuse_inbox) {   // [zp_raw, tt, c_raw] reduced inside the phase-A kernel
                 JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast, true));
             } else {
@@ -308,7 +323,20 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             const bool last = a + 1 == nlv;
             if (!last || inplace) {
                 // X -= t zp', Y -= t c' fused with the next K = X'DY (src/plsnipals.jl:86-87,71; src/plswold.jl:98-99)
-                JCH_TRY(jch_launch_deflate(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, tcol, s.zpc, last ? nullptr : s.K));
+                if (pend_p) {
+                    if (npend == 0) pend_a0 = a;
+                    JCH_HIP(ctx, hipMemcpyAsync(pend_p + (size_t)npend * jch_nipals_lazy_pitch(ldr), s.zpc, sizeof(double) * (size_t)ldr,
+                                                hipMemcpyDeviceToDevice, ctx->stream));
+                    ++npend;
+                    const bool flush = npend == defer_m || last;
+                    JCH_TRY(jch_launch_kpass_lazy(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, pend_p, npend, defer_m,
+                                                  Tdev + (size_t)pend_a0 * (size_t)n, n, s.zpc + ldr, flush, last ? nullptr : s.K));
+                    if (flush) { npend = 0; ++x_writes; }
+                } else {
+                    JCH_TRY(jch_launch_deflate(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, tcol, s.zpc, last ? nullptr : s.K));
+                    ++x_writes;
+                }
+                ++x_reads;
             }
             if (!last) {
                 if (algo == ALGO_WOLD && all_fast) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, a + 1, nlv, io.tol, io.maxit));
@@ -378,7 +406,9 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         pr.sweep_launches = variant2 ? 1 : (kern_like ? cnt : nlv);
         pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
         const double per_x = (double)n * ldr * 8.0;
-        pr.sweep_bytes = kern_like ? per_x + 16.0 * (double)n : 3.0 * per_x;
+        // plsnipals-shaped loops: average per LV of the passes actually made (eager: 2 reads + 1 write; postponed
+        // write-back: 2 reads + one write every m-th LV)
+        pr.sweep_bytes = kern_like ? per_x + 16.0 * (double)n : per_x * (double)(x_reads + x_writes) / (double)std::max(nlv, 1);
     }
     return JCH_OK;
 }

@@ -144,6 +144,19 @@ int32_t jch_launch_raw_scales(jch_ctx *ctx, const double *Xr, int64_t n, int p, 
 int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *zt, int ldz, int *nslice_out);
 int32_t jch_launch_sweep_wide(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                               const double *Yr, int qpad, bool nipals, double *tcol, double *zt);
+// plsnipals with postponed write-back (sweep.hip, deflate.hip): the working copy holds the rows of `npend` LVs ago; pending
+// loadings pend_p[k][jch_nipals_lazy_pitch(ldr)] (pad columns zero), pending scores tpend + k * tstride, oldest first
+#define JCH_NIPALS_DEFER_DEFAULT 6   // rows rewritten every 6th LV (cfg4, ms per LV: eager 8.5-8.9; m = 2: 6.6, 4: 5.76, 5-7: 5.3-5.55, 8-9: 5.45-5.5 — up to 4 pending corrections hide behind the loads, each further one costs ~0.17 ms per pass in LDS reads)
+static inline int jch_nipals_lazy_pitch(int ldr) { return 128 * (ldr <= 128 ? 1 : ldr <= 256 ? 2 : ldr <= 512 ? 4 : ldr <= 1024 ? 8 : 16); }
+int jch_nipals_lazy_capacity(int ldr, int q);   // 0: shape outside the lazy kernels' envelope
+int32_t jch_launch_sweep_lazy(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *wvec,
+                              const double *Yr, int qpad, double *tcol, double *zt, int ldz, int max_slices, int *nslice_out,
+                              const double *pend_p, int npend, int npend_max, const double *tpend, int64_t tstride);
+// next K = X'DY from the rows with all `npend` corrections applied (the newest is this LV's; its Y step uses cvec); the rows
+// are written back only when `flush`
+int32_t jch_launch_kpass_lazy(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q, const double *d,
+                              const double *pend_p, int npend, int npend_max, const double *tpend, int64_t tstride,
+                              const double *cvec, bool flush, double *Knext);
 int32_t jch_launch_deflate(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q,
                            const double *d, const double *tcol, const double *zpc /*[ldr + qpad]: zp then c*/,
                            double *Knext /*[p][qpad] or null*/);

@@ -566,6 +566,196 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     return JCH_OK;
 }
 
+// ---------------------------------------------------------------- NIPALS sweep over a LAZILY deflated working copy
+// plsnipals rewrites X after every LV (src/plsnipals.jl:86 `X .-= t * zp'`): 1 read + 1 write of X per LV on top of the two
+// reads of the sweep and of the next X'DY.  The rewritten value of an element depends only on its own row and column
+// (x_ij - t_i p_j), so the write can be POSTPONED: the working copy keeps the rows of `npend` LVs ago and both passes
+// re-apply the pending rank-one corrections in registers, in LV order and with the very expression the eager kernel uses
+// (x -= t * p: one fma each) — the same bits reach the dot products as if the rows had been stored and re-read.  The
+// rows are written back every m-th LV (k_kpass_lazy, deflate.hip).  Pending loadings p_k live in LDS (one 16-B read per
+// lane and chunk), the pending scores t_k[row] of a row group are ONE extra load per wave (lane l holds pending LV l / R,
+// row l % R) prefetched with the rows and handed out with v_readlane.
+template <int KC, int R>
+__global__ __launch_bounds__(256) void k_sweep_lazy(const double *__restrict__ Xr, int64_t n, int ldr,
+                                                    const double *__restrict__ dw, const double *__restrict__ wvec,
+                                                    const double *__restrict__ Yr, int qpad, double *__restrict__ tcol,
+                                                    double *__restrict__ part, int ldpart,
+                                                    const double *__restrict__ pend_p, int npend,
+                                                    const double *__restrict__ tpend, int64_t tstride)
+{
+    extern __shared__ __attribute__((aligned(16))) double red[];  // loop: [npend][KC*128] pending loadings; end: combine area
+    constexpr int LDP = KC * 128;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v2f64 rf[KC], zp[KC];
+    int coff[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int col = 2 * lane + 128 * k;
+        coff[k] = col < ldr ? col : ldr - 2;
+        zp[k] = v2f64{0.0, 0.0};
+    }
+    const int64_t ngroups = (n + R - 1) / R;
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    // lane -> (pending LV, row of the group) for the score prefetch
+    const int pl = npend > 0 ? min(lane, npend * R - 1) : 0;
+    const int64_t pk_off = (int64_t)(pl / R) * tstride;
+    const int pr = pl % R;
+    v2f64 xn[R][KC];
+    double dwn[R], tpn = 0.0;
+    auto fetch = [&](int64_t gg) {
+        const int64_t r0 = gg * R;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int64_t row = r0 + rr < n ? r0 + rr : n - 1;         // wave-uniform clamp
+            const double *rp = Xr + (size_t)row * (size_t)ldr;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) xn[rr][k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(rp + coff[k]));
+            dwn[rr] = dw[row];
+        }
+        if (npend > 0) tpn = tpend[pk_off + (r0 + pr < n ? r0 + pr : n - 1)];
+    };
+    int64_t g = (int64_t)blockIdx.x * 4 + wv;
+    if (g < ngroups) fetch(g);
+    for (int e = threadIdx.x; e < npend * LDP; e += 256) red[e] = pend_p[e];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) rf[k] = 2 * lane + 128 * k < ldr ? *reinterpret_cast<const v2f64 *>(wvec + 2 * lane + 128 * k) : v2f64{0.0, 0.0};
+    double tt = 0.0, cacc = 0.0;
+    __syncthreads();
+    for (; g < ngroups; g += gstride) {
+        const int64_t row0 = g * R;
+        v2f64 x[R][KC];
+        double dwc[R];
+        const double tpc = tpn;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            dwc[rr] = dwn[rr];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) x[rr][k] = xn[rr][k];
+        }
+        if (g + gstride < ngroups) fetch(g + gstride);
+        for (int k = 0; k < npend; ++k) {       // pending deflations, oldest first
+            double tk[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) tk[rr] = jch_readlane(tpc, k * R + rr);
+            const double *pl_k = red + k * LDP + 2 * lane;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                const v2f64 pf = *reinterpret_cast<const v2f64 *>(pl_k + 128 * kk);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    x[rr][kk].x -= tk[rr] * pf.x;
+                    x[rr][kk].y -= tk[rr] * pf.y;
+                }
+            }
+        }
+        double tsel = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) s += x[rr][k].x * rf[k].x + x[rr][k].y * rf[k].y;
+            const double t = jch_wave_sum(s);
+            const bool live = row0 + rr < n;
+            const double dt = live ? dwc[rr] * t : 0.0;
+            tt += dt * t;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                zp[k].x += dt * x[rr][k].x;
+                zp[k].y += dt * x[rr][k].y;
+            }
+            const double yv = (live && lane < qpad) ? Yr[(size_t)(row0 + rr) * qpad + lane] : 0.0;
+            cacc += dt * yv;
+            if (lane == rr) tsel = t;
+        }
+        if (lane < R && row0 + lane < n) tcol[row0 + lane] = tsel;
+    }
+    __syncthreads();                            // the pending loadings are dead: the area becomes the combine buffer
+    double *zred = red;                     // [4][KC*128]
+    double *tred = red + 4 * KC * 128;      // [16]
+    double *cred = tred + 16;               // [4][64]
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * k) = zp[k];
+    if (lane == 0) tred[wv] = tt;
+    cred[wv * 64 + lane] = cacc;
+    __syncthreads();
+    double *prow = part + (size_t)blockIdx.x * ldpart;
+    for (int c = threadIdx.x; c < ldr; c += 256) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += zred[w * (KC * 128) + c];
+        prow[c] = s;
+    }
+    if (threadIdx.x == 0) prow[ldr] = ((tred[0] + tred[1]) + tred[2]) + tred[3];
+    if (threadIdx.x < qpad) {
+        double s = 0.0;
+        for (int w = 0; w < 4; ++w) s += cred[w * 64 + threadIdx.x];
+        prow[ldr + 1 + threadIdx.x] = s;
+    }
+}
+
+template <int KC, int R>
+static int32_t launch_sweep_lazy_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *wvec,
+                                   const double *Yr, int qpad, double *tcol, double *zt, int ldz, int max_slices, int *nslice_out,
+                                   const double *pend_p, int npend, int npend_max, const double *tpend, int64_t tstride)
+{
+    const int64_t ngroups = (n + R - 1) / R;
+    const size_t lds_red = sizeof(double) * (4 * KC * 128 + 16 + 256);
+    const size_t lds = std::max(lds_red, sizeof(double) * (size_t)npend_max * KC * 128);
+    static int bpc = 0;
+    static jch_per_device_once once;
+    if (!once.done(ctx->device)) {
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_lazy<KC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int nblk = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_lazy<KC, R>, 256, lds_red);
+        bpc = (e == hipSuccess && nblk > 0) ? nblk : 1;
+        once.mark(ctx->device);
+    }
+    // (LDS and grid are sized for the fit's largest pending count, not the current one: one partial-row layout per fit)
+    int use_bpc = ctx->sweep_blocks_per_cu > 0 ? ctx->sweep_blocks_per_cu : bpc;
+    use_bpc = std::max(1, std::min<int>(use_bpc, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+    int64_t nb64 = std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * use_bpc);
+    const int nb = (int)std::max<int64_t>(nb64, 1);
+    const int m = ldr + 1 + qpad, ldpart = (m + 7) & ~7;
+    JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
+    double *part = (double *)ctx->part.ptr;
+    (void)jch_ev(ctx);
+    hipLaunchKernelGGL((k_sweep_lazy<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, wvec, Yr, qpad, tcol, part, ldpart,
+                       pend_p, npend, tpend, tstride);
+    (void)jch_ev(ctx);
+    int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
+    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
+    if (nslice > 1) nslice = JCH_ZT_SLICES;
+    if (max_slices == 1 && nslice > 1) {
+        hipLaunchKernelGGL(k_reduce_slices, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, zt, ldz, m, nslice);
+        nslice = 1;
+    }
+    *nslice_out = nslice;
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+// largest number of postponed deflations the lazy kernels can hold for this row pitch (0: not supported)
+int jch_nipals_lazy_capacity(int ldr, int q)
+{
+    if (ldr < 2 || ldr > 2048 || q < 1 || q > 4 || (ldr > 1024 && q > 2)) return 0;   // the envelope of the streaming deflation
+    return std::min((int)((144 * 1024) / (sizeof(double) * jch_nipals_lazy_pitch(ldr))), 16);   // 16 x R <= 64 lanes of scores
+}
+
+int32_t jch_launch_sweep_lazy(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *wvec,
+                              const double *Yr, int qpad, double *tcol, double *zt, int ldz, int max_slices, int *nslice_out,
+                              const double *pend_p, int npend, int npend_max, const double *tpend, int64_t tstride)
+{
+    if (npend < 0 || npend > npend_max || npend_max > jch_nipals_lazy_capacity(ldr, 1)) return jch_fail(ctx, JCH_EINVAL, "internal: lazy NIPALS sweep: bad pending count");
+#define JCH_SL(KC, R) return launch_sweep_lazy_t<KC, R>(ctx, Xr, n, ldr, d, wvec, Yr, qpad, tcol, zt, ldz, max_slices, nslice_out, pend_p, npend, npend_max, tpend, tstride)
+    if (ldr <= 128) JCH_SL(1, 4);
+    if (ldr <= 256) JCH_SL(2, 4);
+    if (ldr <= 512) JCH_SL(4, 4);
+    if (ldr <= 1024) JCH_SL(8, 2);
+    if (ldr <= 2048) JCH_SL(16, 2);
+#undef JCH_SL
+    return jch_fail(ctx, JCH_EINVAL, "internal: lazy NIPALS sweep needs p <= 2048");
+}
+
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra, double *tcol, double *zt, int ldz, int max_slices,
                          int *nslice_out, const double *mu)

@@ -314,6 +314,39 @@ def test_cfg4_shape_plsnipals_structured(J, ctx):
     assert O.rel_fro(Xo, Xg) < TOL and O.rel_fro(yo, yg) < TOL
 
 
+@pytest.mark.parametrize("alg", ["plsnipals", "plswold"])
+@pytest.mark.parametrize("shape", [(3001, 37, 1, 7), (2500, 130, 2, 9), (1800, 300, 3, 6), (1203, 700, 4, 5), (900, 1100, 2, 10),
+                                   (700, 1999, 1, 11)])
+def test_postponed_deflation_matches_the_eager_one(alg, shape, J, ctx, monkeypatch):
+    """plsnipals / plswold with q <= 4 rewrite the working copy only every m-th LV and re-apply the pending rank-one
+    corrections in registers (k_sweep_lazy / k_kpass_lazy).  Every m — including one that does not divide nlv, the
+    capacity limit and the in-place variants whose final X is the flushed copy — must reproduce the eager deflation
+    (JCH_NIPALS_DEFER=1) to rounding, and the oracle to the usual bound."""
+    n, p, q, nlv = shape
+    rng = np.random.default_rng(n + p)
+    Lt = rng.standard_normal((n, 2 * nlv))
+    X = np.asfortranarray(Lt @ rng.standard_normal((2 * nlv, p)) + 0.4 * rng.standard_normal((n, p)))
+    Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.2 * rng.standard_normal((n, q)))
+    w = rng.uniform(0.5, 1.5, n)
+    fit, fit_ = getattr(J, alg), getattr(J, alg + "_")
+    ref = getattr(O, alg)(X, Y, w, nlv=nlv)
+    monkeypatch.setenv("JCH_NIPALS_DEFER", "1")
+    eager = fit(X, Y, w, nlv=nlv, ctx=ctx)
+    Xe, Ye = X.copy(order="F"), Y.copy(order="F")
+    fit_(Xe, Ye, w, nlv=nlv, ctx=ctx)
+    _cmp(ref, eager)
+    for m in ("2", "3", "4", "9", "16"):
+        monkeypatch.setenv("JCH_NIPALS_DEFER", m)
+        lazy = fit(X, Y, w, nlv=nlv, ctx=ctx)
+        for f in FIELDS + ("TT",):
+            assert O.rel_fro(getattr(eager, f), getattr(lazy, f)) < 1e-11, (m, f)
+        Xl, Yl = X.copy(order="F"), Y.copy(order="F")
+        fit_(Xl, Yl, w, nlv=nlv, ctx=ctx)
+        assert O.rel_fro(Xe, Xl) < 1e-11 and O.rel_fro(Ye, Yl) < 1e-11, m
+    monkeypatch.delenv("JCH_NIPALS_DEFER")
+    _cmp(ref, fit(X, Y, w, nlv=nlv, ctx=ctx))           # the default
+
+
 def test_scores_and_gridscorelv(J, ctx):
     """§8f rank 1: scores from device-side sums and gridscorelv == the oracle (src/scores.jl, src/gridscore.jl:167-221)."""
     n, p, q, m = 3000, 40, 3, 700

@@ -21,7 +21,7 @@ variants = [v for v in os.environ.get("DEFL_VARIANTS", "").split(";") if v] or [
 res = {v: [] for v in variants}
 for it in range(3 * len(variants) + 1):
     v = variants[it % len(variants)]
-    for kv in [x for x in os.environ if x.startswith("JCH_DEFLATE_") or x.startswith("JCH_SWEEP_")]:
+    for kv in [x for x in os.environ if x.startswith(("JCH_DEFLATE_", "JCH_SWEEP_", "JCH_NIPALS_"))]:
         del os.environ[kv]
     for kv in v.split():
         k_, v_ = kv.split("="); os.environ[k_] = v_
