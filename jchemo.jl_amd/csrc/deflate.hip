@@ -443,12 +443,313 @@ static int32_t launch_kpass_lazy_t(jch_ctx *ctx, double *Xr, int64_t n, int p, i
     return JCH_OK;
 }
 
+// ---- the same postponed write-back for 4 < q <= 16 (and q = 3, 4 at the widest rows): the MFMA tile kernel above with up
+// to MP pending corrections — lane `jcol` keeps its MP loadings in registers, the scores of the 64-row chunk sit in LDS.
+// Y is read with this LV's step applied on the fly and rewritten by k_deflate_y afterwards, as in the eager path.
+#define JCH_TILE_MP 8
+__global__ __launch_bounds__(256) void k_kpass_tile_lazy(double *__restrict__ Xr, int64_t n, int ldr, const double *__restrict__ Yr, int qpad,
+                                                         int q, const double *__restrict__ d, const double *__restrict__ pend_p, int ldp,
+                                                         int npend, const double *__restrict__ tpend, int64_t tstride,
+                                                         const double *__restrict__ cvec, int flush, double *__restrict__ Kpart, int kp_rows)
+{
+    __shared__ double xt[64 * XT_LD];
+    __shared__ double yt[64 * YT_LD];
+    __shared__ double tl[JCH_TILE_MP][64], dl[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = blockIdx.y * 64;
+    const int64_t nchunks = (n + 63) / 64;
+    const int jcol = j0 + lane;
+    double zpj[JCH_TILE_MP];
+#pragma unroll
+    for (int k = 0; k < JCH_TILE_MP; ++k) zpj[k] = (k < npend && jcol < ldr) ? pend_p[(size_t)k * ldp + jcol] : 0.0;
+    const int knew = npend - 1;
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t i0 = c * 64;
+        {   // scores of the pending LVs and the weights of this chunk: thread (k = wv + 4 j, row = lane)
+            const int64_t i = i0 + lane;
+#pragma unroll
+            for (int k = wv; k < JCH_TILE_MP; k += 4) tl[k][lane] = (k < npend && i < n) ? tpend[(size_t)k * tstride + i] : 0.0;
+            if (wv == 3) dl[lane] = i < n ? d[i] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + 256 * k, row = e >> 4, col = e & 15;
+            const int64_t i = i0 + row;
+            double v = 0.0;
+            if (i < n && col < q) v = Yr[(size_t)i * qpad + col] - tl[knew][row] * cvec[col];
+            yt[row * YT_LD + col] = dl[row] * v;
+        }
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int row = wv + 4 * k;
+            const int64_t i = i0 + row;
+            double v = 0.0;
+            if (i < n && jcol < ldr) {
+                v = Xr[(size_t)i * ldr + jcol];
+#pragma unroll
+                for (int kk = 0; kk < JCH_TILE_MP; ++kk)
+                    if (kk < npend) v -= tl[kk][row] * zpj[kk];     // wave-uniform; oldest first
+                if (flush) Xr[(size_t)i * ldr + jcol] = v;
+            }
+            xt[row * XT_LD + lane] = v;
+        }
+        __syncthreads();
+        if (Kpart) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int row = 4 * kk + (lane >> 4);
+                const double a = xt[row * XT_LD + 16 * wv + (lane & 15)];
+                const double b = yt[row * YT_LD + (lane & 15)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (Kpart) {
+        double *kp = Kpart + ((size_t)blockIdx.x * kp_rows) * qpad;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int j = j0 + 16 * wv + (lane >> 4) + 4 * reg;
+            if (j < kp_rows) kp[(size_t)j * qpad + (lane & 15)] = acc[reg];
+        }
+    }
+}
+
+// K[e] = sum_b Kpart[b][e], e < m (fixed order: 16 interleaved block streams, then combined)
+__global__ __launch_bounds__(1024) void k_reduce_kpart3(const double *__restrict__ Kpart, int nb, int stride, int m, double *__restrict__ K)
+{
+    __shared__ double sc[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (e < m)
+        for (int b = g; b < nb; b += 16) s += Kpart[(size_t)b * stride + e];
+    sc[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && e < m) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sc[k][cl];
+        K[e] = t;
+    }
+}
+
+// ---- the MFMA pass without the LDS transpose (4 < q <= 16, p <= 1024).  v_mfma_f64_16x16x4 takes A[m = lane & 15][k = lane >> 4]:
+// with k = row and m = column, lane l can load its operand straight from the row-major copy — a 16-B load of row
+// i0 + (l >> 4), columns c, c + 1 with c = 32 s + 2 (l & 15) feeds TWO products (the even and the odd columns of the
+// 32-column span s are two 16-row "strips" of K); 16 lanes read 256 contiguous bytes, one instruction 4 rows.  The four
+// waves of a block share the rows of a chunk and split its spans (s = wave + 4 u), so the B operand d_i * y_i (with this
+// LV's Y step applied) and the pending scores are staged ONCE per chunk in LDS, double-buffered: one barrier per chunk,
+// nothing else.  Pending loadings of the lane's 2 NS columns sit in registers.  X is prefetched one chunk ahead.
+template <int NS, int STEPS, int MP, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_kpass_mfma_lazy(double *__restrict__ Xr, int64_t n, int ldr, double *__restrict__ Yr, int q,
+                                                         const double *__restrict__ dw, const double *__restrict__ pend_p, int ldp, int npend,
+                                                         const double *__restrict__ tpend, int64_t tstride, const double *__restrict__ cvec,
+                                                         int flush, double *__restrict__ Kpart, int kp_rows)
+{
+    constexpr int RB = 4 * STEPS;                       // rows per chunk
+    __shared__ double bt[2][RB][16];                    // d_i * (y_i - t_i c')
+    __shared__ double tl[2][MP][RB];                    // pending scores of the chunk's rows
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    int coff[NS];
+    bool in[NS];
+    double pk[MP][NS][2];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const int col = 32 * (wv + 4 * u) + 2 * c16;
+        in[u] = col < ldr;
+        coff[u] = in[u] ? col : ldr - 2;
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            pk[k][u][0] = (k < npend && in[u]) ? pend_p[(size_t)k * ldp + col] : 0.0;
+            pk[k][u][1] = (k < npend && in[u]) ? pend_p[(size_t)k * ldp + col + 1] : 0.0;
+        }
+    }
+    v4f64 acc[NS][2];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) { acc[u][0] = v4f64{0.0, 0.0, 0.0, 0.0}; acc[u][1] = v4f64{0.0, 0.0, 0.0, 0.0}; }
+    const int64_t nchunks = (n + RB - 1) / RB;
+    const int knew = npend - 1;
+    // staging roles: thread (row = tid >> 4, y = tid & 15) builds the B entry, thread (k = tid >> 4, row = tid & 15) a score
+    const int srow = tid >> 4, sy = tid & 15;
+    const double cy = sy < q ? cvec[sy] : 0.0;
+    const int tk = tid >> 4, trow = tid & 15;
+    // X is prefetched one whole chunk ahead.  (Rotating two buffers and re-requesting every consumed step for chunk c + 2 G
+    // — 1.5 chunks in flight — was measured SLOWER for the read-only pass, 968 against 800 us at cfg2 shape: the loads then
+    // queue behind each step's eight 64-cycle MFMAs instead of going out ahead of all of them.)
+    v2f64 xn[STEPS][NS];
+    double s_y = 0.0, s_t = 0.0, s_d = 0.0, s_tk = 0.0;
+    int64_t s_row = -1;
+    auto fetch = [&](int64_t c) {
+        const int64_t i0 = c * RB;
+        // the staging operands FIRST: vmcnt retires in order, so waiting for them at the end of the chunk must not mean
+        // waiting for the whole prefetched chunk behind which they would otherwise queue
+        if (srow < RB) {
+            const int64_t r = i0 + srow;
+            const bool live = r < n;
+            s_row = live ? r : -1;
+            s_y = live ? Yr[(size_t)r * 16 + sy] : 0.0;
+            s_t = live ? tpend[(size_t)knew * tstride + r] : 0.0;
+            s_d = live ? dw[r] : 0.0;
+        }
+        if (tk < npend && trow < RB) {
+            const int64_t r = i0 + trow;
+            s_tk = r < n ? tpend[(size_t)tk * tstride + r] : 0.0;
+        }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int64_t r = i0 + 4 * st + g;
+            const double *rp = Xr + (size_t)(r < n ? r : n - 1) * (size_t)ldr;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) xn[st][u] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(rp + coff[u]));
+        }
+    };
+    // (every Y element of a chunk is read by exactly one thread of exactly one block: that thread also stores the deflated value)
+    auto stage = [&](int buf) {
+        if (srow < RB) {
+            const double yd = s_y - s_t * cy;
+            bt[buf][srow][sy] = s_d * yd;
+            if (s_row >= 0 && sy < q) Yr[(size_t)s_row * 16 + sy] = yd;
+        }
+        if (tk < npend && trow < RB) tl[buf][tk][trow] = s_tk;
+    };
+    int64_t c = blockIdx.x;
+    int cur = 0;
+    if (c < nchunks) { fetch(c); stage(0); }
+    __syncthreads();
+    for (; c < nchunks; c += gridDim.x) {
+        const int64_t i0 = c * RB;
+        v2f64 x[STEPS][NS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) x[st][u] = xn[st][u];
+        const bool more = c + gridDim.x < nchunks;
+        if (more) fetch(c + gridDim.x);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int lr = 4 * st + g;
+            const int64_t r = i0 + lr;
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                if (k < npend) {                        // block-uniform; oldest first
+                    const double t = tl[cur][k][lr];
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) {
+                        x[st][u].x -= t * pk[k][u][0];
+                        x[st][u].y -= t * pk[k][u][1];
+                    }
+                }
+            }
+            const double b = bt[cur][lr][c16];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[st][u].x, b, acc[u][0], 0, 0, 0);
+                acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[st][u].y, b, acc[u][1], 0, 0, 0);
+            }
+            if (flush && r < n) {
+                double *wp = Xr + (size_t)r * (size_t)ldr;
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+                    if (in[u]) __builtin_nontemporal_store(x[st][u], reinterpret_cast<v2f64 *>(wp + coff[u]));
+            }
+        }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (Kpart) {   // D[m = 4 reg + g][n = c16]: K row = column 32 s + 2 m + h of X, K column = y
+        double *kp = Kpart + (size_t)blockIdx.x * kp_rows * 16;
+#pragma unroll
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int j = 32 * (wv + 4 * u) + 2 * (4 * reg + g) + h;
+                    if (j < kp_rows) kp[(size_t)j * 16 + c16] = acc[u][h][reg];
+                }
+    }
+}
+
+template <int NS, int STEPS, int MP, int MINB = 1>
+static int32_t launch_kpass_mfma_lazy_t(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int q, const double *d,
+                                        const double *pend_p, int npend, const double *tpend, int64_t tstride, const double *cvec,
+                                        bool flush, double *Knext)
+{
+    constexpr int RB = 4 * STEPS;
+    if (npend > MP) return jch_fail(ctx, JCH_EINVAL, "internal: lazy MFMA pass: %d pending corrections, at most %d", npend, MP);
+    const int64_t nchunks = (n + RB - 1) / RB;
+    const char *e_bpc = getenv("JCH_DEFLATE_BPC");
+    const int bpc = (e_bpc && atoi(e_bpc) > 0) ? atoi(e_bpc) : MINB;
+    const int nb = (int)std::max<int64_t>(std::min<int64_t>(nchunks, (int64_t)ctx->cus * bpc), 1);
+    const int kp_rows = ldr;
+    JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nb * kp_rows * 16));
+    double *Kpart = (double *)ctx->kpart.ptr;
+    (void)jch_ev(ctx);
+    hipLaunchKernelGGL((k_kpass_mfma_lazy<NS, STEPS, MP, MINB>), dim3(nb), dim3(256), 0, ctx->stream, Xr, n, ldr, Yr, q, d, pend_p,
+                       jch_nipals_lazy_pitch(ldr), npend, tpend, tstride, cvec, flush ? 1 : 0, Knext ? Kpart : nullptr, kp_rows);
+    (void)jch_ev(ctx);
+    if (Knext) {
+        hipLaunchKernelGGL(k_reduce_kpart3, dim3((p * 16 + 63) / 64), dim3(1024), 0, ctx->stream, Kpart, nb, kp_rows * 16, p * 16, Knext);
+        JCH_TRY(jch_allreduce_f64(ctx, Knext, (size_t)p * 16));
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
+static bool lazy_stream_shape(int ldr, int q) { return q >= 1 && q <= 4 && ldr <= 2048 && !(ldr > 1024 && q > 2); }
+
+static int32_t launch_kpass_tile_lazy(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q, const double *d,
+                                      const double *pend_p, int npend, const double *tpend, int64_t tstride, const double *cvec, bool flush,
+                                      double *Knext)
+{
+    const int ptiles = (ldr + 63) / 64, kp_rows = ptiles * 64;
+    const int64_t nchunks = (n + 63) / 64;
+    int nbx = (ctx->cus * 3 + ptiles - 1) / ptiles;
+    if (nbx > nchunks) nbx = (int)(nchunks > 0 ? nchunks : 1);
+    double *Kpart = nullptr;
+    if (Knext) {
+        JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * qpad));
+        Kpart = (double *)ctx->kpart.ptr;
+    }
+    (void)jch_ev(ctx);
+    hipLaunchKernelGGL(k_kpass_tile_lazy, dim3(nbx, ptiles, 1), dim3(256), 0, ctx->stream, Xr, n, ldr, Yr, qpad, q, d, pend_p,
+                       jch_nipals_lazy_pitch(ldr), npend, tpend, tstride, cvec, flush ? 1 : 0, Kpart, kp_rows);
+    (void)jch_ev(ctx);
+    const int nby = (int)std::min<int64_t>((n * qpad + 255) / 256, (int64_t)ctx->cus * 8);
+    hipLaunchKernelGGL(k_deflate_y, dim3(nby > 0 ? nby : 1), dim3(256), 0, ctx->stream, Yr, n, qpad, q, tpend + (size_t)(npend - 1) * tstride, cvec);
+    if (Knext) {
+        hipLaunchKernelGGL(k_reduce_kpart2, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad, Knext);
+        JCH_TRY(jch_allreduce_f64(ctx, Knext, (size_t)p * qpad));
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
 int32_t jch_launch_kpass_lazy(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int qpad, int q, const double *d,
                               const double *pend_p, int npend, int npend_max, const double *tpend, int64_t tstride,
                               const double *cvec, bool flush, double *Knext)
 {
     if (npend < 1 || npend > npend_max || npend_max > jch_nipals_lazy_capacity(ldr, q))
         return jch_fail(ctx, JCH_EINVAL, "internal: lazy NIPALS pass: bad pending count");
+    if (!lazy_stream_shape(ldr, q)) {
+        if (qpad == 16 && ldr <= 1024 && !getenv("JCH_KPASS_TILE")) {   // (JCH_KPASS_TILE=1: the LDS-transposing tile kernel instead)
+#define JCH_KM(NS, STEPS, MP, ...) return launch_kpass_mfma_lazy_t<NS, STEPS, MP, ##__VA_ARGS__>(ctx, Xr, n, p, ldr, Yr, q, d, pend_p, npend, tpend, tstride, cvec, flush, Knext)
+            if (ldr <= 128) JCH_KM(1, 4, 6);
+            if (ldr <= 256) JCH_KM(2, 4, 6);
+            // (measured at cfg2 shape, read-only pass: 16-row chunks 800-845 us; 32-row chunks with 2 loadings 802; 8-row chunks
+            // 914, with two blocks per CU and 3 loadings 745 — but rewriting every 3rd LV instead of every 6th costs as much;
+            // 4-row chunks with two blocks per CU 896)
+            if (ldr <= 512) JCH_KM(4, 4, 6);
+            JCH_KM(8, 2, 3);
+#undef JCH_KM
+        }
+        return launch_kpass_tile_lazy(ctx, Xr, n, p, ldr, Yr, qpad, q, d, pend_p, npend, tpend, tstride, cvec, flush, Knext);
+    }
 #define JCH_KL(KC, R) do { \
         if (q == 1) return launch_kpass_lazy_t<KC, R, 1>(ctx, Xr, n, p, ldr, Yr, qpad, d, pend_p, npend, npend_max, tpend, tstride, cvec, flush, Knext); \
         if (q == 2) return launch_kpass_lazy_t<KC, R, 2>(ctx, Xr, n, p, ldr, Yr, qpad, d, pend_p, npend, npend_max, tpend, tstride, cvec, flush, Knext); \

@@ -737,8 +737,12 @@ static int32_t launch_sweep_lazy_t(jch_ctx *ctx, const double *Xr, int64_t n, in
 // largest number of postponed deflations the lazy kernels can hold for this row pitch (0: not supported)
 int jch_nipals_lazy_capacity(int ldr, int q)
 {
-    if (ldr < 2 || ldr > 2048 || q < 1 || q > 4 || (ldr > 1024 && q > 2)) return 0;   // the envelope of the streaming deflation
-    return std::min((int)((144 * 1024) / (sizeof(double) * jch_nipals_lazy_pitch(ldr))), 16);   // 16 x R <= 64 lanes of scores
+    if (ldr < 2 || ldr > 2048 || q < 1 || q > 16) return 0;
+    const int lds_cap = std::min((int)((144 * 1024) / (sizeof(double) * jch_nipals_lazy_pitch(ldr))), 16);   // 16 x R <= 64 lanes of scores
+    const bool stream = q <= 4 && !(ldr > 1024 && q > 2);     // the envelope of the streaming pass; otherwise the MFMA tile pass
+    if (stream) return lds_cap;
+    if (getenv("JCH_KPASS_TILE") || ldr > 1024) return std::min(lds_cap, 8);   // LDS tile pass: JCH_TILE_MP loadings per lane
+    return ldr <= 512 ? 6 : 3;                                // direct-operand MFMA pass: loadings of 2 NS columns in registers
 }
 
 int32_t jch_launch_sweep_lazy(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *wvec,

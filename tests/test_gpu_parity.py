@@ -316,16 +316,17 @@ def test_cfg4_shape_plsnipals_structured(J, ctx):
 
 @pytest.mark.parametrize("alg", ["plsnipals", "plswold"])
 @pytest.mark.parametrize("shape", [(3001, 37, 1, 7), (2500, 130, 2, 9), (1800, 300, 3, 6), (1203, 700, 4, 5), (900, 1100, 2, 10),
-                                   (700, 1999, 1, 11)])
+                                   (700, 1999, 1, 11), (2500, 130, 7, 9), (1500, 500, 10, 8), (900, 1100, 16, 6), (700, 1999, 3, 7)])
 def test_postponed_deflation_matches_the_eager_one(alg, shape, J, ctx, monkeypatch):
-    """plsnipals / plswold with q <= 4 rewrite the working copy only every m-th LV and re-apply the pending rank-one
-    corrections in registers (k_sweep_lazy / k_kpass_lazy).  Every m — including one that does not divide nlv, the
+    """plsnipals / plswold with q <= 16 rewrite the working copy only every m-th LV and re-apply the pending rank-one
+    corrections in registers (k_sweep_lazy + k_kpass_lazy for q <= 4, + k_kpass_tile_lazy above).  Every m — including one that does not divide nlv, the
     capacity limit and the in-place variants whose final X is the flushed copy — must reproduce the eager deflation
     (JCH_NIPALS_DEFER=1) to rounding, and the oracle to the usual bound."""
     n, p, q, nlv = shape
     rng = np.random.default_rng(n + p)
-    Lt = rng.standard_normal((n, 2 * nlv))
-    X = np.asfortranarray(Lt @ rng.standard_normal((2 * nlv, p)) + 0.4 * rng.standard_normal((n, p)))
+    r = max(2 * nlv, q)
+    Lt = rng.standard_normal((n, r))
+    X = np.asfortranarray(Lt @ rng.standard_normal((r, p)) + 0.4 * rng.standard_normal((n, p)))
     Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.2 * rng.standard_normal((n, q)))
     w = rng.uniform(0.5, 1.5, n)
     fit, fit_ = getattr(J, alg), getattr(J, alg + "_")
