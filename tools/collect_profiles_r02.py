@@ -11,7 +11,9 @@ def cp(a, b):
     if os.path.exists(os.path.join(SRC, a)):
         shutil.copy(os.path.join(SRC, a), os.path.join(DST, b)); return True
     print("missing", a); return False
-for a, b in [("bench.json", "r02_final_bench.json"), ("bench_cfg4.json", "r02_final_bench_cfg4_plsnipals.json"), ("bench_cfg4_b.json", "r02_final_bench_cfg4_plsnipals_second_box.json"),
+for a, b in [("bench.json", "r02_final_bench.json"), ("bench_cfg4.json", "r02_final_bench_cfg4_plsnipals.json"), ("bench_cfg4_eager.json", "r02_bench_cfg4_plsnipals_eager_deflation.json"),
+             ("bench_plsnipals_q10.json", "r02_bench_plsnipals_q10_cfg2_shape.json"), ("bench_plsnipals_q10_eager.json", "r02_bench_plsnipals_q10_cfg2_shape_eager_deflation.json"),
+             ("bench_plswold_eager.json", "r02_sibling_bench_plswold_eager_deflation.json"), ("pmc_nipals_q10_summary.txt", "r02_pmc_plsnipals_q10.txt"),
              ("bench_bf16.json", "r02_final_bench_bf16.json"), ("bench_bf16_n8e6_one_gpu.json", "r02_final_bench_bf16_n8e6_one_gpu.json"),
              ("bench_rank_share_125k.json", "r02_rank_share_125k_rows.json"), ("bench_scal.json", "r02_final_bench_scal_true.json"),
              ("lwplsr_cfg5.json", "r02_lwplsr_cfg5.json"), ("lwplsr_cfg5_3replicas_one_gpu.json", "r02_lwplsr_cfg5_3replicas_one_gpu_rehearsal.json"),
@@ -26,7 +28,8 @@ with open(os.path.join(DST, "r02_rank_share_table.jsonl"), "w") as f:
         p_ = os.path.join(SRC, nm)
         if os.path.exists(p_):
             d = json.load(open(p_)); f.write(json.dumps({"rows_per_gpu": d["config"]["rows_per_gpu"], "LV_per_s": d["value"], "device_ms_per_step": d["device_ms_per_step"], "sweep_GBps": d["roofline"]["achieved"]}) + "\n")
-for tag, out in (("stats", "r02_final_kernel_stats.csv"), ("stats_cfg4", "r02_final_kernel_stats_cfg4_plsnipals.csv"), ("stats_bf16", "r02_final_kernel_stats_bf16.csv")):
+for tag, out in (("stats", "r02_final_kernel_stats.csv"), ("stats_cfg4", "r02_final_kernel_stats_cfg4_plsnipals.csv"), ("stats_bf16", "r02_final_kernel_stats_bf16.csv"),
+                 ("stats_nipals_q10", "r02_kernel_stats_plsnipals_q10_cfg2_shape.csv")):
     fs = newest(os.path.join(SRC, tag, "*", "*kernel_stats.csv"))
     if fs: shutil.copy(fs[0], os.path.join(DST, out))
 # ---- PMC -> bytes per launch
