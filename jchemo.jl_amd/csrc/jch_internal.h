@@ -59,7 +59,7 @@ struct jch_ctx {
     // workspace (grow-only)
     void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
     size_t hstage_bytes = 0;
-    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq;
+    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets;
     // profiling
     bool profiling = false;
     jch_profile prof{};
@@ -148,6 +148,7 @@ int32_t jch_launch_sweep_wide(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
 // loadings pend_p[k][jch_nipals_lazy_pitch(ldr)] (pad columns zero), pending scores tpend + k * tstride, oldest first
 #define JCH_NIPALS_DEFER_DEFAULT 6   // rows rewritten every 6th LV (cfg4, ms per LV: eager 8.5-8.9; m = 2: 6.6, 4: 5.76, 5-7: 5.3-5.55, 8-9: 5.45-5.5 — up to 4 pending corrections hide behind the loads, each further one costs ~0.17 ms per pass in LDS reads)
 static inline int jch_nipals_lazy_pitch(int ldr) { return 128 * (ldr <= 128 ? 1 : ldr <= 256 ? 2 : ldr <= 512 ? 4 : ldr <= 1024 ? 8 : 16); }
+int32_t jch_sweep_tickets(jch_ctx *ctx, int **out);   // sweep.hip: counters of the fused slice sums
 int jch_nipals_lazy_capacity(int ldr, int q);   // 0: shape outside the lazy kernels' envelope
 int32_t jch_launch_sweep_lazy(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *wvec,
                               const double *Yr, int qpad, double *tcol, double *zt, int ldz, int max_slices, int *nslice_out,

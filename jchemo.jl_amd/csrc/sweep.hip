@@ -204,11 +204,66 @@ __device__ __forceinline__ constexpr int jch_rowsum_lane(int rr)
     return 16 * (((rr & 3) == 1) ? 2 : ((rr & 3) == 2) ? 1 : (rr & 3)) + (R == 8 ? 8 * (rr >> 2) : 0);
 }
 
+// Stage 1 of the fixed-order reduction WITHOUT a launch of its own (round 2; `nslice` = 0: off, k_reduce_part does it): every
+// block publishes its partial row, takes a ticket in its slice, and the block that draws the last ticket of a slice sums
+// the slice's rows — in exactly k_reduce_part's order (16 interleaved block streams, combined in stream order), so zt holds
+// the same bits either way.  The ticket counters return to zero for the next launch.
+// Visibility across the 8 XCDs (one L2 each) WITHOUT agent-scope fences: a fence makes every wave write back / invalidate
+// its whole L2 (measured: +60 us per sweep launch).  Instead the partial rows are stored and re-read with agent-scope
+// relaxed atomics (sc1: they go through to / come from the memory side), each thread waits for its own stores to be
+// acknowledged (workgroup-scope release = s_waitcnt vmcnt(0)) before the block barrier that precedes the ticket.
+__device__ __forceinline__ void jch_publish(double *p, double v, bool coherent)
+{
+    if (coherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ void jch_slice_sum_by_last_block(const double *__restrict__ part, int ldpart, int m, int *__restrict__ tickets,
+                                                            double *__restrict__ zt, int ldz, int nslice)
+{
+    if (nslice <= 0) return;                            // grid-uniform
+    __shared__ int s_last;
+    const int nb = gridDim.x;
+    const int per = (nb + nslice - 1) / nslice;
+    const int slice = blockIdx.x / per;
+    const int b0 = slice * per, b1 = min(nb, b0 + per);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's published values have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(tickets + slice, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == b1 - b0 - 1;
+        if (s_last) __hip_atomic_store(tickets + slice, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;                                // block-uniform
+    for (int c = threadIdx.x; c < m; c += blockDim.x) {
+        double sg[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sg[g] = 0.0;
+        for (int bb = b0; bb < b1; bb += 16) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (bb + g < b1) sg[g] += __hip_atomic_load(part + (size_t)(bb + g) * ldpart + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += sg[g];
+        zt[(size_t)slice * ldz + c] = t;
+    }
+    if (slice == 0) {                                   // slices without blocks hold zeros (the consumer sums all JCH_ZT_SLICES)
+        const int used = (nb + per - 1) / per;
+        for (int e = threadIdx.x; e < (JCH_ZT_SLICES - used) * m; e += blockDim.x) {
+            const int sl = used + e / m, c = e - (e / m) * m;
+            zt[(size_t)sl * ldz + c] = 0.0;
+        }
+    }
+}
+
 template <int KC, int R, int NBUF>
 __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr, int64_t n, int ldr,
                                                   const double *__restrict__ dw, const double *__restrict__ rvec,
                                                   double *__restrict__ tcol, double *__restrict__ part, int ldpart,
-                                                  const double *__restrict__ mu)
+                                                  const double *__restrict__ mu, int *__restrict__ tickets,
+                                                  double *__restrict__ zt, int ldz, int nslice)
 {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [nw][KC*128] + [16] tt, st
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -306,14 +361,15 @@ __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr,
     for (int c = threadIdx.x; c < ldr; c += blockDim.x) {
         double a = 0.0;
         for (int w = 0; w < nw; ++w) a += zred[w * (KC * 128) + c];
-        prow[c] = a;
+        jch_publish(prow + c, a, nslice > 0);
     }
     if (threadIdx.x == 0) {
         double a = 0.0, a2 = 0.0;
         for (int w = 0; w < nw; ++w) { a += tred[w]; a2 += tred[8 + w]; }
-        prow[ldr] = a;
-        if (mu) prow[ldr + 1] = a2;
+        jch_publish(prow + ldr, a, nslice > 0);
+        if (mu) jch_publish(prow + ldr + 1, a2, nslice > 0);
     }
+    jch_slice_sum_by_last_block(part, ldpart, ldr + 1 + (mu ? 1 : 0), tickets, zt, ldz, nslice);
 }
 
 // Stage 1: slice s (blockIdx.y) sums its contiguous range of per-block partial rows -> zt[s][c].  Fixed order:
@@ -531,6 +587,17 @@ static int32_t launch_sweep_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     return JCH_OK;
 }
 
+// zero-initialised ticket counters of the fused slice sums (the kernels leave them at zero)
+int32_t jch_sweep_tickets(jch_ctx *ctx, int **out)
+{
+    if (!ctx->tickets.ptr) {
+        JCH_TRY(jch_reserve(ctx, ctx->tickets, 256));
+        JCH_HIP(ctx, hipMemsetAsync(ctx->tickets.ptr, 0, 256, ctx->stream));
+    }
+    *out = (int *)ctx->tickets.ptr;
+    return JCH_OK;
+}
+
 template <int KC, int R, int NBUF>
 static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                                  double *tcol, double *zt, int ldz, int max_slices, int *nslice_out, int m, const double *mu)
@@ -551,11 +618,22 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     const int ldpart = (m + 7) & ~7;
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->part.ptr;
-    (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
-    hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu);
-    (void)jch_ev(ctx);  // (end)
     int nslice = std::max(1, std::min(JCH_ZT_SLICES, nb / 8));
-    hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
+    // JCH_SWEEP_FUSED_REDUCE=1: the slice sums happen in the sweep's last-arriving blocks instead of k_reduce_part.  Measured
+    // and NOT the default: it removes 4 us of small-state time per LV (one launch boundary + the reduce kernel) but the tail it
+    // adds to every sweep — store acknowledged at the memory side, ticket, re-read through sc1 loads: three dependent
+    // memory-side round trips — costs 16 us (82.9 -> 99.0 us per launch at 125 k rows, 590 -> 601-614 at 1e6 rows); with
+    // agent-scope fences instead of sc1 accesses 60 us (every wave writes back / invalidates its XCD's L2).
+    const char *e_fr = getenv("JCH_SWEEP_FUSED_REDUCE");
+    const bool fused = e_fr && atoi(e_fr) == 1;
+    int *tickets = nullptr;
+    if (fused) JCH_TRY(jch_sweep_tickets(ctx, &tickets));
+    (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
+    hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
+                       tickets, zt, ldz, fused ? nslice : 0);
+    (void)jch_ev(ctx);  // (end)
+    if (!fused)
+        hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
     if (nslice > 1) nslice = JCH_ZT_SLICES;
     if (max_slices == 1 && nslice > 1) {
         hipLaunchKernelGGL(k_reduce_slices, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, zt, ldz, m, nslice);

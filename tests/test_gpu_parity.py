@@ -348,6 +348,25 @@ def test_postponed_deflation_matches_the_eager_one(alg, shape, J, ctx, monkeypat
     _cmp(ref, fit(X, Y, w, nlv=nlv, ctx=ctx))           # the default
 
 
+@pytest.mark.parametrize("shape", [(60000, 100, 3, 6), (300, 40, 2, 5), (25000, 500, 10, 8), (4100, 900, 1, 4)])
+def test_slice_sums_inside_the_sweep_are_bit_identical(shape, J, ctx, monkeypatch):
+    """JCH_SWEEP_FUSED_REDUCE=1 (measured slower, not the default): the first stage of the fixed-order reduction of the
+    sweep's partial rows runs in the sweep's last-arriving blocks.  It must produce the very bits of the stand-alone
+    `k_reduce_part`, fit after fit (the ticket counters have to return to zero)."""
+    n, p, q, nlv = shape
+    rng = np.random.default_rng(p)
+    Lt = rng.standard_normal((n, 2 * nlv))
+    X = np.asfortranarray(Lt @ rng.standard_normal((2 * nlv, p)) + 0.4 * rng.standard_normal((n, p)))
+    Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.2 * rng.standard_normal((n, q)))
+    ref = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    monkeypatch.setenv("JCH_SWEEP_FUSED_REDUCE", "1")
+    for _ in range(3):
+        fm = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+        for f in FIELDS + ("TT",):
+            assert np.array_equal(getattr(ref, f), getattr(fm, f)), f
+    _cmp(O.plskern(X, Y, nlv=nlv), fm)
+
+
 def test_scores_and_gridscorelv(J, ctx):
     """§8f rank 1: scores from device-side sums and gridscorelv == the oracle (src/scores.jl, src/gridscore.jl:167-221)."""
     n, p, q, m = 3000, 40, 3, 700
