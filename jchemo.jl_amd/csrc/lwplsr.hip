@@ -1,5 +1,5 @@
 // kNN-LWPLSR prediction path (BASELINE.json configs[4]):
-//   K9  k_knn_weights   brute-force k nearest neighbours in a (whitened) score space + `wdist` weights
+//   K9  k_knn_scan + k_knn_finish   brute-force k nearest neighbours in a (whitened) score space + `wdist` weights
 //                       replaces getknn (src/getknn.jl:29-57: NearestNeighbors.BruteTree + knn(sorted)) and the
 //                       per-query weight loop of predict(::Lwplsr) (src/lwplsr.jl:152-159, src/wdist.jl:64-75,
 //                       mad: src/utility.jl:679)
@@ -15,6 +15,7 @@
 
 #include "jch_internal.h"
 #include "lv_device.h"
+#include "rowsum_dev.h"
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
@@ -46,18 +47,22 @@ __global__ __launch_bounds__(256) void k_to_rowmajor(const double *__restrict__ 
 }
 
 // ---------------------------------------------------------------- K9: kNN + weights
-#define KNN_QB 4       // queries per workgroup (each loaded training value serves 4 queries)
+#define KNN_QB 4       // queries per workgroup (each loaded training value serves KNN_QB queries; 8 measured slower)
 #define KNN_CAP 1024   // candidate buffer per query (LDS); k <= KNN_CAP - 256
+#define KNN_RB 4        // 256-row chunks of the training scores in flight per trip
+#define KNN_CB 8        // score columns loaded together
 
-// bitonic sort of KNN_CAP (key, idx) pairs in LDS, ascending by (key, idx); 256 threads
-__device__ static void bitonic_sort_cap(double *key, int *idx)
+// bitonic sort of `cap` (a power of two <= KNN_CAP) (key, idx) pairs in LDS, ascending by (key, idx); 256 threads
+__device__ static void bitonic_sort_n(double *key, int *idx, int cap)
 {
     const int tid = threadIdx.x;
-    for (int size = 2; size <= KNN_CAP; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    for (int size = 2; size <= cap; size <<= 1) {
+        for (int stride = size >> 1, ls = 31 - __builtin_clz(size >> 1); stride > 0; stride >>= 1, --ls) {
             __syncthreads();
-            for (int t = tid; t < KNN_CAP / 2; t += 256) {
-                const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+            for (int t = tid; t < cap / 2; t += 256) {
+                // (shifts, not t / stride and t % stride: a runtime integer division is ~40 instructions on this ISA and was
+                // 3/4 of the sort's time)
+                const int lo = ((t >> ls) << (ls + 1)) | (t & (stride - 1)), hi = lo + stride;
                 const bool up = ((lo & size) == 0);
                 const double a = key[lo], b = key[hi];
                 const int ia = idx[lo], ib = idx[hi];
@@ -68,6 +73,8 @@ __device__ static void bitonic_sort_cap(double *key, int *idx)
     }
     __syncthreads();
 }
+__device__ static void bitonic_sort_cap(double *key, int *idx) { bitonic_sort_n(key, idx, KNN_CAP); }
+__device__ __forceinline__ int knn_pow2_at_least(int v) { int c = 64; while (c < v) c <<= 1; return c; }
 
 struct knn_args {
     const double *Zt; int64_t ldzt; int64_t n;   // train scores, column-major n x dd
@@ -77,9 +84,12 @@ struct knn_args {
     int *ind;      // [m][k]
     double *dist;  // [m][k]
     double *w;     // [m][k]
+    int nseg;      // the training rows are scanned in nseg segments by different workgroups (blockIdx.y)
+    double *ckey;  // [m][nseg][k] squared distances of every segment's k best (ascending; +inf beyond the segment's rows)
+    int *cidx;     // [m][nseg][k]
 };
 
-__global__ __launch_bounds__(256) void k_knn_weights(knn_args g)
+__global__ __launch_bounds__(256) void k_knn_scan(knn_args g)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bkey = lds;                                            // [QB][CAP]
@@ -97,80 +107,139 @@ __global__ __launch_bounds__(256) void k_knn_weights(knn_args g)
     if (tid < KNN_QB) { tau[tid] = __builtin_inf(); cnt[tid] = 0; }
     __syncthreads();
     const int k = g.k;
-    for (int64_t base = 0; base < g.n; base += 256) {
-        const int64_t i = base + tid;
-        double d2[KNN_QB];
+    // KNN_RB chunks of 256 training rows per trip: all their loads go out together (the kernel is bound by the latency of the
+    // score matrix in L2 / MALL with 4 waves per CU), then the chunks are offered to the candidate buffers one after the
+    // other, exactly as if they had been read one at a time (round 2: 4.1 -> 1.3 ms per 1000 queries at cfg5)
+    // this block's segment of the training rows (multiples of 256 rows; the last one takes the rest)
+    const int64_t seg_rows = ((g.n + g.nseg - 1) / g.nseg + 255) / 256 * 256;
+    const int64_t row_lo = (int64_t)blockIdx.y * seg_rows, row_hi = min(g.n, row_lo + seg_rows);
+    for (int64_t base = row_lo; base < row_hi; base += 256 * KNN_RB) {
+        double d2[KNN_RB][KNN_QB];
 #pragma unroll
-        for (int qq = 0; qq < KNN_QB; ++qq) d2[qq] = 0.0;
-        if (i < g.n) {
-            for (int c = 0; c < g.dd; ++c) {
-                const double x = g.Zt[(size_t)i + (size_t)c * (size_t)g.ldzt];
+        for (int r = 0; r < KNN_RB; ++r)
 #pragma unroll
-                for (int qq = 0; qq < KNN_QB; ++qq) { const double e = x - zq[qq * g.dd + c]; d2[qq] += e * e; }
+            for (int qq = 0; qq < KNN_QB; ++qq) d2[r][qq] = 0.0;
+        // KNN_CB score columns x KNN_RB row chunks = 32 loads per thread go out before the first is used (written as a plain
+        // loop the compiler waited for each column's 4 loads before it issued the next: 20 round trips per trip instead of 3)
+        for (int c0 = 0; c0 < g.dd; c0 += KNN_CB) {
+            double x[KNN_CB][KNN_RB];
+#pragma unroll
+            for (int cc = 0; cc < KNN_CB; ++cc) {
+                const size_t coff = (size_t)min(c0 + cc, g.dd - 1) * (size_t)g.ldzt;
+#pragma unroll
+                for (int r = 0; r < KNN_RB; ++r) {
+                    const int64_t i = base + 256 * r + tid;
+                    x[cc][r] = g.Zt[(size_t)(i < row_hi ? i : g.n - 1) + coff];
+                }
             }
 #pragma unroll
-            for (int qq = 0; qq < KNN_QB; ++qq)
-                if (qq < nq && (d2[qq] < tau[qq] || (d2[qq] == tau[qq] && cnt[qq] < k))) {
-                    const int pos = atomicAdd(&cnt[qq], 1);
-                    bkey[qq * KNN_CAP + pos] = d2[qq];
-                    bidx[qq * KNN_CAP + pos] = (int)i;
+            for (int cc = 0; cc < KNN_CB; ++cc)
+                if (c0 + cc < g.dd) {                        // block-uniform
+#pragma unroll
+                    for (int r = 0; r < KNN_RB; ++r)
+#pragma unroll
+                        for (int qq = 0; qq < KNN_QB; ++qq) { const double e = x[cc][r] - zq[qq * g.dd + c0 + cc]; d2[r][qq] += e * e; }
                 }
         }
-        __syncthreads();
-        for (int qq = 0; qq < nq; ++qq) {
-            if (cnt[qq] > KNN_CAP - 256) {   // compact: keep the k best, raise the bar (block-uniform decision)
-                const int c0 = cnt[qq];
-                for (int e = c0 + tid; e < KNN_CAP; e += 256) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
-                bitonic_sort_cap(bkey + qq * KNN_CAP, bidx + qq * KNN_CAP);
-                if (tid == 0) { cnt[qq] = k; tau[qq] = bkey[qq * KNN_CAP + k - 1]; }
-                __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KNN_RB; ++r) {
+            const int64_t i = base + 256 * r + tid;
+            if (base + 256 * r >= row_hi) break;            // block-uniform
+            double tq[KNN_QB];                               // one LDS round trip for the four bars instead of one per test
+#pragma unroll
+            for (int qq = 0; qq < KNN_QB; ++qq) tq[qq] = tau[qq];
+            if (i < row_hi) {
+#pragma unroll
+                for (int qq = 0; qq < KNN_QB; ++qq)
+                    if (qq < nq && (d2[r][qq] < tq[qq] || (d2[r][qq] == tq[qq] && cnt[qq] < k))) {
+                        const int pos = atomicAdd(&cnt[qq], 1);
+                        bkey[qq * KNN_CAP + pos] = d2[r][qq];
+                        bidx[qq * KNN_CAP + pos] = (int)i;
+                    }
+            }
+            __syncthreads();
+            int cq[KNN_QB];
+#pragma unroll
+            for (int qq = 0; qq < KNN_QB; ++qq) cq[qq] = cnt[qq];
+#pragma unroll
+            for (int qq = 0; qq < KNN_QB; ++qq) {
+                if (qq < nq && cq[qq] > KNN_CAP - 256) {   // compact: keep the k best, raise the bar (block-uniform decision)
+                    const int c0 = cq[qq];
+                    for (int e = c0 + tid; e < KNN_CAP; e += 256) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
+                    bitonic_sort_cap(bkey + qq * KNN_CAP, bidx + qq * KNN_CAP);
+                    if (tid == 0) { cnt[qq] = k; tau[qq] = bkey[qq * KNN_CAP + k - 1]; }
+                    __syncthreads();
+                }
             }
         }
     }
-    // final ordering + weights, one query at a time
+    // the segment's k best of every query, in (distance, index) order
     for (int qq = 0; qq < nq; ++qq) {
         const int c0 = cnt[qq];
-        for (int e = c0 + tid; e < KNN_CAP; e += 256) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
+        const int cap = knn_pow2_at_least(c0);
         double *key = bkey + qq * KNN_CAP;
         int *idx = bidx + qq * KNN_CAP;
-        bitonic_sort_cap(key, idx);
-        const int kk = min(k, c0);
-        int *oi = g.ind + (size_t)(q0 + qq) * k;
-        double *od = g.dist + (size_t)(q0 + qq) * k, *ow = g.w + (size_t)(q0 + qq) * k;
-        for (int e = tid; e < kk; e += 256) { oi[e] = idx[e]; key[e] = sqrt(key[e]); od[e] = key[e]; }
-        __syncthreads();
-        // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
-        const double med = (kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]);
-        __syncthreads();
-        // the distances are saved in the output array; |d - med| is sorted in place in the candidate buffer
-        for (int e = tid; e < KNN_CAP; e += 256) {
-            const double v = e < kk ? fabs(od[e] - med) : __builtin_inf();
-            key[e] = v;
-            idx[e] = e;
-        }
-        bitonic_sort_cap(key, idx);
-        const double zmad = 1.4826 * ((kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]));
-        const double cutoff = med + g.cri * zmad;
-        __syncthreads();
-        // weights; max with NaN propagation (Julia's `maximum` returns NaN if any NaN is present)
-        double wmax = -__builtin_inf();
-        bool anynan = false;
-        for (int e = 0; e < kk; ++e) {   // every thread scans the same k values: k <= 768, cheap and branch-uniform
-            const double dv = od[e];
-            const double wv = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
-            if (wv != wv) anynan = true;
-            if (wv > wmax) wmax = wv;
-        }
-        if (anynan) wmax = __builtin_nan("");
-        for (int e = tid; e < kk; e += 256) {
-            const double dv = od[e];
-            double wv = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
-            wv = wv / wmax;
-            if (wv != wv) wv = 1.0;
-            if (wv < g.tol) wv = g.tol;
-            ow[e] = wv;
-        }
-        __syncthreads();
+        for (int e = c0 + tid; e < cap; e += 256) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
+        bitonic_sort_n(key, idx, cap);
+        double *ok = g.ckey + ((size_t)(q0 + qq) * g.nseg + blockIdx.y) * k;
+        int *oi = g.cidx + ((size_t)(q0 + qq) * g.nseg + blockIdx.y) * k;
+        for (int e = tid; e < k; e += 256) { ok[e] = e < c0 ? key[e] : __builtin_inf(); oi[e] = e < c0 ? idx[e] : 0x7fffffff; }
+    }
+}
+
+// K9b: one workgroup per query merges the segments' candidates, orders the k nearest and turns the distances into weights
+__global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
+{
+    __shared__ double key[KNN_CAP];
+    __shared__ int idx[KNN_CAP];
+    __shared__ double sred[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int qi = blockIdx.x, k = g.k;
+    const int ncand = g.nseg * k;
+    const int cap = knn_pow2_at_least(ncand);
+    const double *ck = g.ckey + (size_t)qi * ncand;
+    const int *ci = g.cidx + (size_t)qi * ncand;
+    for (int e = tid; e < cap; e += 256) { key[e] = e < ncand ? ck[e] : __builtin_inf(); idx[e] = e < ncand ? ci[e] : 0x7fffffff; }
+    bitonic_sort_n(key, idx, cap);
+    const int kk = (int)min<int64_t>(k, g.n);
+    int *oi = g.ind + (size_t)qi * k;
+    double *od = g.dist + (size_t)qi * k, *ow = g.w + (size_t)qi * k;
+    for (int e = tid; e < kk; e += 256) { oi[e] = idx[e]; key[e] = sqrt(key[e]); od[e] = key[e]; }
+    __syncthreads();
+    // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
+    const double med = (kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]);
+    __syncthreads();
+    // the distances are saved in the output array; |d - med| is sorted in place in the candidate buffer
+    const int cap2 = knn_pow2_at_least(kk);
+    for (int e = tid; e < cap2; e += 256) {
+        const double v = e < kk ? fabs(od[e] - med) : __builtin_inf();
+        key[e] = v;
+        idx[e] = e;
+    }
+    bitonic_sort_n(key, idx, cap2);
+    const double zmad = 1.4826 * ((kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]));
+    const double cutoff = med + g.cri * zmad;
+    __syncthreads();
+    // weights; max with NaN propagation (Julia's `maximum` returns NaN if any NaN is present)
+    double wmax = -__builtin_inf();
+    int anynan = 0;
+    for (int e = tid; e < kk; e += 256) {
+        const double dv = od[e];
+        const double wv_ = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
+        key[e] = wv_;
+        if (wv_ != wv_) anynan = 1;
+        else if (wv_ > wmax) wmax = wv_;
+    }
+    for (int o = 32; o > 0; o >>= 1) { wmax = fmax(wmax, __shfl_xor(wmax, o, 64)); anynan |= __shfl_xor(anynan, o, 64); }
+    if (lane == 0) { sred[wv] = wmax; sred[4 + wv] = (double)anynan; }
+    __syncthreads();
+    wmax = fmax(fmax(sred[0], sred[1]), fmax(sred[2], sred[3]));
+    if (sred[4] + sred[5] + sred[6] + sred[7] > 0.0) wmax = __builtin_nan("");
+    for (int e = tid; e < kk; e += 256) {
+        double wv_ = key[e] / wmax;
+        if (wv_ != wv_) wv_ = 1.0;
+        if (wv_ < g.tol) wv_ = g.tol;
+        ow[e] = wv_;
     }
 }
 
@@ -267,18 +336,68 @@ __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
             for (int a = tid; a < le; a += 256) g.pred[(size_t)qi * le + a] = gmin;
             continue;
         }
-        // ---- local weighted means / stds of X (thread per column; rows gathered from the row-major copy)
-        for (int j = tid; j < ldr; j += 256) {
-            double m1 = 0.0;
-            if (j < p)
-                for (int e = 0; e < k; ++e) m1 += dl[e] * g.Xrm[(size_t)idx[e] * ldr + j];
-            double sd = 1.0;
-            if (g.scal && j < p) {
-                double v = 0.0;
-                for (int e = 0; e < k; ++e) { const double z = g.Xrm[(size_t)idx[e] * ldr + j] - m1; v += dl[e] * z * z; }
-                sd = sqrt(v);
+        // ---- local weighted means / stds of X: wave per neighbour row, SR rows per trip with all loads first (random rows of
+        // the row-major copy: HBM latency), column sums in registers like zp in the sweep, 4-wave combine through LDS
+        constexpr int SR = KC <= 4 ? 4 : (KC == 8 ? 2 : 1);
+        auto load_rows = [&](v2f64 (&x)[SR][KC], int e0) {
+#pragma unroll
+            for (int rr = 0; rr < SR; ++rr) {
+                const int e = min(e0 + 4 * rr, k - 1);          // rows past k: re-read the last one (weight zero below)
+                const v2f64 *rp = reinterpret_cast<const v2f64 *>(g.Xrm + (size_t)idx[e] * ldr) + lane;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) x[rr][c] = (2 * lane + 128 * c < ldr) ? rp[64 * c] : v2f64{0.0, 0.0};
             }
-            mu[j] = m1; sg[j] = sd;
+        };
+        auto combine_cols = [&](const v2f64 (&acc)[KC], double *out, bool root) {   // out[j] = sum over the 4 waves (sqrt if root)
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < KC; ++c) *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * c) = acc[c];
+            __syncthreads();
+            for (int j = tid; j < ldr; j += 256) {
+                const double v = ((zred[j] + zred[KC * 128 + j]) + zred[2 * KC * 128 + j]) + zred[3 * KC * 128 + j];
+                out[j] = root ? (j < p ? sqrt(v) : 1.0) : v;
+            }
+            __syncthreads();
+        };
+        {
+            v2f64 acc[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) acc[c] = v2f64{0.0, 0.0};
+            for (int e0 = wv; e0 < k; e0 += 4 * SR) {
+                v2f64 x[SR][KC];
+                load_rows(x, e0);
+#pragma unroll
+                for (int rr = 0; rr < SR; ++rr) {
+                    const double d = e0 + 4 * rr < k ? dl[e0 + 4 * rr] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) { acc[c].x += d * x[rr][c].x; acc[c].y += d * x[rr][c].y; }
+                }
+            }
+            combine_cols(acc, mu, false);
+            if (g.scal) {
+                v2f64 mf[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    mf[c] = (2 * lane + 128 * c < ldr) ? *reinterpret_cast<const v2f64 *>(mu + 2 * lane + 128 * c) : v2f64{0.0, 0.0};
+                    acc[c] = v2f64{0.0, 0.0};
+                }
+                for (int e0 = wv; e0 < k; e0 += 4 * SR) {
+                    v2f64 x[SR][KC];
+                    load_rows(x, e0);
+#pragma unroll
+                    for (int rr = 0; rr < SR; ++rr) {
+                        const double d = e0 + 4 * rr < k ? dl[e0 + 4 * rr] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < KC; ++c) {
+                            const double zx = x[rr][c].x - mf[c].x, zy = x[rr][c].y - mf[c].y;
+                            acc[c].x += d * zx * zx; acc[c].y += d * zy * zy;
+                        }
+                    }
+                }
+                combine_cols(acc, sg, true);
+            } else {
+                for (int j = tid; j < ldr; j += 256) sg[j] = 1.0;
+            }
         }
         {
             double vv[Q];
@@ -298,28 +417,67 @@ __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
                 const double z = yc[(size_t)e * Q + y] - ymean[y];
                 yc[(size_t)e * Q + y] = y < q ? (g.scal ? z / ysd[y] : z) : 0.0;
             }
-        // ---- gather + centre/scale into the slab; centred query; K = X' D Y
-        for (int e = wv; e < k; e += 4) {
-            const double *src = g.Xrm + (size_t)idx[e] * ldr;
-            double *dst = Xg + (size_t)e * ldr;
-            for (int j = lane; j < ldr; j += 64) dst[j] = j < p ? (g.scal ? (src[j] - mu[j]) / sg[j] : src[j] - mu[j]) : 0.0;
-        }
+        // ---- gather + centre/scale into the slab; centred query; K = X' D Y (for Q * KC <= 16 accumulated in the same pass)
+        __syncthreads();
         for (int j = tid; j < ldr; j += 256)
             xq[j] = j < p ? (g.scal ? (g.Xq[(size_t)qi + (size_t)j * (size_t)g.ldxq] - mu[j]) / sg[j]
                                     : g.Xq[(size_t)qi + (size_t)j * (size_t)g.ldxq] - mu[j]) : 0.0;
-        __syncthreads();
-        for (int j = tid; j < ldr; j += 256) {
-            double s2[Q];
+        {
+            constexpr bool FUSEK = Q * KC <= 16;
+            v2f64 mf[KC], sf[KC], kacc[FUSEK ? Q : 1][KC];
 #pragma unroll
-            for (int y = 0; y < Q; ++y) s2[y] = 0.0;
-            if (j < p)
-                for (int e = 0; e < k; ++e) {
-                    const double xv = dl[e] * Xg[(size_t)e * ldr + j];
+            for (int c = 0; c < KC; ++c) {
+                const bool in = 2 * lane + 128 * c < ldr;
+                mf[c] = in ? *reinterpret_cast<const v2f64 *>(mu + 2 * lane + 128 * c) : v2f64{0.0, 0.0};
+                sf[c] = in ? *reinterpret_cast<const v2f64 *>(sg + 2 * lane + 128 * c) : v2f64{1.0, 1.0};
 #pragma unroll
-                    for (int y = 0; y < Q; ++y) s2[y] += xv * yc[(size_t)e * Q + y];
+                for (int y = 0; y < (FUSEK ? Q : 1); ++y) kacc[y][c] = v2f64{0.0, 0.0};
+            }
+            for (int e0 = wv; e0 < k; e0 += 4 * SR) {
+                v2f64 x[SR][KC];
+                load_rows(x, e0);
+#pragma unroll
+                for (int rr = 0; rr < SR; ++rr) {
+                    const int e = e0 + 4 * rr;
+                    if (e < k) {                                 // wave-uniform
+                        double *dst = Xg + (size_t)e * ldr;
+#pragma unroll
+                        for (int c = 0; c < KC; ++c) {
+                            const int col = 2 * lane + 128 * c;
+                            v2f64 z;
+                            z.x = col < p ? (g.scal ? (x[rr][c].x - mf[c].x) / sf[c].x : x[rr][c].x - mf[c].x) : 0.0;
+                            z.y = col + 1 < p ? (g.scal ? (x[rr][c].y - mf[c].y) / sf[c].y : x[rr][c].y - mf[c].y) : 0.0;
+                            if (col < ldr) *reinterpret_cast<v2f64 *>(dst + col) = z;
+                            if constexpr (FUSEK) {
+#pragma unroll
+                                for (int y = 0; y < Q; ++y) {
+                                    const double sy_ = dl[e] * yc[(size_t)e * Q + y];
+                                    kacc[y][c].x += sy_ * z.x; kacc[y][c].y += sy_ * z.y;
+                                }
+                            }
+                        }
+                    }
                 }
+            }
+            if constexpr (FUSEK) {
 #pragma unroll
-            for (int y = 0; y < Q; ++y) Kv[(size_t)y * ldr + j] = s2[y];
+                for (int y = 0; y < Q; ++y) combine_cols(kacc[y], Kv + (size_t)y * ldr, false);
+            } else {
+                __syncthreads();
+                for (int j = tid; j < ldr; j += 256) {
+                    double s2[Q];
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) s2[y] = 0.0;
+                    if (j < p)
+                        for (int e = 0; e < k; ++e) {
+                            const double xv = dl[e] * Xg[(size_t)e * ldr + j];
+#pragma unroll
+                            for (int y = 0; y < Q; ++y) s2[y] += xv * yc[(size_t)e * Q + y];
+                        }
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) Kv[(size_t)y * ldr + j] = s2[y];
+                }
+            }
         }
         if (tid < Q) prun[tid] = ymean[tid];   // nlv = 0: the intercept alone (src/plskern.jl:207-217 with B = 0)
         __syncthreads();
@@ -420,20 +578,44 @@ __global__ __launch_bounds__(256) void k_locw_plskern(locw_args g)
                 zp[c] = v2f64{0.0, 0.0};
             }
             double tt = 0.0;
-            for (int e = wv; e < k; e += 4) {
-                const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xg + (size_t)e * ldr) + lane;
-                v2f64 x[KC];
-                double s4 = 0.0;
+            // LR rows of the wave per trip, all loads first (the slab sits in L2: with 4-8 waves per CU the loop is bound by
+            // that latency, one trip = one round trip), row sums by the transposing permlane reduction of the K4 sweep
+            constexpr int LR = KC <= 4 ? 4 : (KC == 8 ? 2 : 1);   // rows per wave and trip (register budget: LR x KC pairs)
+            for (int e0 = wv; e0 < k; e0 += 4 * LR) {
+                v2f64 x[LR][KC];
+                double s4[LR];
 #pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    x[c] = (2 * lane + 128 * c < ldr) ? rp[64 * c] : v2f64{0.0, 0.0};
-                    s4 += x[c].x * rf[c].x + x[c].y * rf[c].y;
+                for (int rr = 0; rr < LR; ++rr) {
+                    const int e = min(e0 + 4 * rr, k - 1);      // rows past k: re-read the last one, weight zero
+                    const v2f64 *rp = reinterpret_cast<const v2f64 *>(Xg + (size_t)e * ldr) + lane;
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) x[rr][c] = (2 * lane + 128 * c < ldr) ? rp[64 * c] : v2f64{0.0, 0.0};
                 }
-                const double t = jch_wave_sum(s4);
-                const double dt = dl[e] * t;
-                tt += dt * t;
 #pragma unroll
-                for (int c = 0; c < KC; ++c) { zp[c].x += dt * x[c].x; zp[c].y += dt * x[c].y; }
+                for (int rr = 0; rr < LR; ++rr) {
+                    double a4 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) a4 += x[rr][c].x * rf[c].x + x[rr][c].y * rf[c].y;
+                    s4[rr] = a4;
+                }
+                double tv[LR];
+                if constexpr (LR == 4) {
+                    const double hsum = jch_rowsums<4>(s4, lane);
+#pragma unroll
+                    for (int rr = 0; rr < LR; ++rr) tv[rr] = jch_readlane(hsum, jch_rowsum_lane<4>(rr));
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < LR; ++rr) tv[rr] = jch_wave_sum(s4[rr]);
+                }
+#pragma unroll
+                for (int rr = 0; rr < LR; ++rr) {
+                    const int e = e0 + 4 * rr;
+                    const double t = tv[rr];
+                    const double dt = e < k ? dl[e] * t : 0.0;
+                    tt += dt * t;
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) { zp[c].x += dt * x[rr][c].x; zp[c].y += dt * x[rr][c].y; }
+                }
             }
 #pragma unroll
             for (int c = 0; c < KC; ++c) *reinterpret_cast<v2f64 *>(zred + wv * (KC * 128) + 2 * lane + 128 * c) = zp[c];
@@ -486,7 +668,8 @@ static int32_t launch_locw_q(jch_ctx *ctx, locw_args &g)
         attr.mark(ctx->device);
     }
     if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k / p / q too large for the batched local-PLS kernel");
-    int nb = std::min(g.m, ctx->cus * 2);
+    const char *e_bpc = getenv("JCH_LOCW_BPC");   // (measurement knob) blocks per CU of the local-fit kernel
+    int nb = std::min(g.m, ctx->cus * ((e_bpc && atoi(e_bpc) > 0) ? atoi(e_bpc) : 2));
     g.slab = ((size_t)g.k * g.ldr + 2 * (size_t)g.nlv_hi * g.ldr + 31) & ~(size_t)31;
     JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
     g.scratch = (double *)ctx->xstage.ptr;
@@ -558,9 +741,18 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         a.h = h; a.cri = 4.0; a.tol = tol; a.ind = dind; a.dist = ddist; a.w = dw;
         const size_t lds = (sizeof(double) + sizeof(int)) * KNN_QB * KNN_CAP + sizeof(double) * (KNN_QB * (size_t)dd + KNN_QB) + sizeof(int) * KNN_QB + 64;
         if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: score dimension %lld too large", (long long)dd);
+        // row segments: as many as keep every segment at >= 4 trips and the merged candidate lists inside one sort (nseg * k <= KNN_CAP)
+        // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
+        // its own compaction sorts)
+        int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_CAP / k), n / (4 * 256 * KNN_RB)));
+        if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_CAP / k));
+        a.nseg = nseg;
+        JCH_TRY(jch_reserve(ctx, ctx->gemm_b, (sizeof(double) + sizeof(int)) * (size_t)m * nseg * k + 256));
+        a.ckey = (double *)ctx->gemm_b.ptr; a.cidx = (int *)(a.ckey + (size_t)m * nseg * k);
         static jch_per_device_once attr;
-        if (!attr.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_weights, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.mark(ctx->device); }
-        hipLaunchKernelGGL(k_knn_weights, dim3((unsigned)((m + KNN_QB - 1) / KNN_QB)), dim3(256), lds, ctx->stream, a);
+        if (!attr.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.mark(ctx->device); }
+        hipLaunchKernelGGL(k_knn_scan, dim3((unsigned)((m + KNN_QB - 1) / KNN_QB), nseg), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
     }
     {
         locw_args g;

@@ -21,7 +21,7 @@ if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
-n, p, m, k, nlvdis, nlv = 100_000, 500, 1000, 200, 20, 15
+n, p, m, k, nlvdis, nlv = int(os.environ.get("LW_N", "100000")), 500, 1000, 200, 20, int(os.environ.get("LW_NLV", "15"))   # (LW_NLV: probe of the per-LV cost)
 ctx = J.Context(local, stream="torch")
 lib = J.load()
 dev = torch.device("cuda", local)
