@@ -116,13 +116,24 @@ __global__ __launch_bounds__(256) void k_moments_bf16_v8(const bf16_t *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void k_colreduce_b(const double *__restrict__ colpart, int S, int m, double *__restrict__ out)
+// out[j] = sum_k colpart[k][j] in a fixed order: 16 interleaved streams of partial rows per column, combined in stream order
+// (one thread walking all S rows of a column was latency-bound: 81 us at cfg3 for 2 x 256 threads)
+__global__ __launch_bounds__(1024) void k_colreduce_b(const double *__restrict__ colpart, int S, int m, double *__restrict__ out)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= m) return;
+    __shared__ double sc[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cl;
     double s = 0.0;
-    for (int k = 0; k < S; ++k) s += colpart[(size_t)k * m + j];
-    out[j] = s;
+    if (j < m)
+        for (int k = g; k < S; k += 16) s += colpart[(size_t)k * m + j];
+    sc[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && j < m) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sc[k][cl];
+        out[j] = t;
+    }
 }
 __global__ __launch_bounds__(256) void k_fill_b(double *__restrict__ v, int m, double c)
 {
@@ -155,7 +166,7 @@ static int32_t launch_moments_bf16(jch_ctx *ctx, const bf16_t *Xc, int64_t ldx, 
         if (means) { if (MCGv == 4) JCH_K1B(true, 4); else if (MCGv == 8) JCH_K1B(true, 8); else JCH_K1B(true, 16); }
         else { if (MCGv == 4) JCH_K1B(false, 4); else if (MCGv == 8) JCH_K1B(false, 8); else JCH_K1B(false, 16); }
 #undef JCH_K1B
-        hipLaunchKernelGGL(k_colreduce_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, colpart, S, m, out);
+        hipLaunchKernelGGL(k_colreduce_b, dim3((m + 63) / 64), dim3(1024), 0, ctx->stream, colpart, S, m, out);
         JCH_TRY(jch_allreduce_f64(ctx, out, (size_t)m));
         if (means) hipLaunchKernelGGL(k_sqrt_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, out, m);
         JCH_HIP(ctx, hipGetLastError());
@@ -169,7 +180,7 @@ static int32_t launch_moments_bf16(jch_ctx *ctx, const bf16_t *Xc, int64_t ldx, 
     double *colpart = (double *)ctx->colpart.ptr;
     if (means) hipLaunchKernelGGL(k_moments_bf16<true>, dim3(m, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk, means, colpart);
     else hipLaunchKernelGGL(k_moments_bf16<false>, dim3(m, S), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, d, n, p, q, chunk, means, colpart);
-    hipLaunchKernelGGL(k_colreduce_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, colpart, S, m, out);
+    hipLaunchKernelGGL(k_colreduce_b, dim3((m + 63) / 64), dim3(1024), 0, ctx->stream, colpart, S, m, out);
     JCH_TRY(jch_allreduce_f64(ctx, out, (size_t)m));
     if (means) hipLaunchKernelGGL(k_sqrt_b, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, out, m);
     JCH_HIP(ctx, hipGetLastError());
