@@ -149,6 +149,7 @@ def main():
     lib = J.load()
     ctx = J.Context(local_rank, stream="torch")
     p2p_candidate = False
+    rccl_ok = 1
     fdev = dev
     transport = "none (single GPU)"
     if world > 1:
@@ -158,9 +159,26 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            box = [J.unique_id() if rank == 0 else None]
+            # the library's own RCCL communicator (dlopen'ed librccl: the copy torch loaded).  Should it fail to come up on some
+            # rank, the run continues on the P2P inbox alone if THAT passes its self-test everywhere (every message of a
+            # plskern-shaped fit fits the inbox), exactly like the one-GPU rehearsal; otherwise it stops with the error.
+            rccl_ok = 1
+            try:
+                box = [J.unique_id() if rank == 0 else None]
+            except Exception as e:  # noqa: BLE001
+                box = [None]
+                print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
-            ctx.comm_init(box[0], rank, world)
+            try:
+                if box[0] is None:
+                    raise RuntimeError("no RCCL unique id")
+                ctx.comm_init(box[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                rccl_ok = 0
+                print(f"[bench] rank {rank}: RCCL communicator failed: {e}", file=sys.stderr)
+            flag = torch.tensor([rccl_ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            rccl_ok = int(flag.item())
         fdev = torch.device("cpu") if rehearsal else dev      # where the small agreement tensors live
         # P2P inbox transport for the latency-bound per-LV all-reduce (csrc/p2p.hip): IPC handles exchanged here, the
         # library runs a collective self-test; it is only ENABLED further down, after a whole fit through it has
@@ -181,9 +199,10 @@ def main():
             flag = torch.tensor([1 if ok else 0], device=fdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             p2p_candidate = bool(flag.item() == 1)
-        if rehearsal:
+        if rehearsal or not rccl_ok:
             if not p2p_candidate:
-                sys.exit("bench.py rehearsal: the P2P transport did not come up")
+                sys.exit("bench.py: neither the RCCL communicator nor the P2P transport came up" if not rehearsal else
+                         "bench.py rehearsal: the P2P transport did not come up")
             ctx.p2p_enable(True)
 
     n_total, p, q, nlv = args.n, args.p, args.q, args.nlv
@@ -230,6 +249,8 @@ def main():
 
     if rehearsal:
         transport = "p2p inbox only (one-GPU rehearsal)"
+    elif world > 1 and not rccl_ok:
+        transport = "p2p inbox over xGMI only (the library's RCCL communicator did not come up)"
     elif world > 1:
         transport = "rccl"
         step()                          # reference fit: every collective through RCCL
