@@ -367,6 +367,29 @@ def test_slice_sums_inside_the_sweep_are_bit_identical(shape, J, ctx, monkeypatc
     _cmp(O.plskern(X, Y, nlv=nlv), fm)
 
 
+@pytest.mark.parametrize("shape", [(70000, 123, 3, 5), (66002, 500, 10, 25), (65537, 500, 2, 20), (131072, 37, 1, 16)])
+def test_long_input_accessors(shape, J, ctx, monkeypatch):
+    """`transform` / `predict` on inputs long enough for the persistent accessor kernel (whole coefficient matrix in LDS,
+    barrier-free row tiles; m >= 65536, even leading dimension) against the tiled kernel (JCH_GEMM_PERSIST=0) and numpy."""
+    m, p, q, nlv = shape
+    rng = np.random.default_rng(m)
+    Lt = rng.standard_normal((3000, 2 * nlv))
+    X = np.asfortranarray(Lt @ rng.standard_normal((2 * nlv, p)) + 0.3 * rng.standard_normal((3000, p)) + 2.0)
+    Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.2 * rng.standard_normal((3000, q)))
+    fm = J.plskern(X, Y, nlv=nlv, scal=True, ctx=ctx)
+    Xn = np.asfortranarray(rng.standard_normal((m, p)) + 2.0)
+    ref_T = ((Xn - fm.xmeans) / fm.xscales) @ fm.R
+    got_T = J.transform(fm, Xn, ctx=ctx)
+    assert O.rel_fro(ref_T, got_T) < 1e-12
+    B = (fm.R @ fm.C.T) / fm.xscales[:, None] * fm.yscales[None, :]
+    ref_p = fm.ymeans + (Xn - fm.xmeans) @ B
+    got_p = J.predict(fm, Xn, ctx=ctx)
+    got_p = got_p[0] if isinstance(got_p, (list, tuple)) else getattr(got_p, "pred", got_p)
+    assert O.rel_fro(ref_p, np.asarray(got_p)) < 1e-11
+    monkeypatch.setenv("JCH_GEMM_PERSIST", "0")
+    assert O.rel_fro(J.transform(fm, Xn, ctx=ctx), got_T) < 1e-13
+
+
 def test_scores_and_gridscorelv(J, ctx):
     """§8f rank 1: scores from device-side sums and gridscorelv == the oracle (src/scores.jl, src/gridscore.jl:167-221)."""
     n, p, q, m = 3000, 40, 3, 700
