@@ -366,25 +366,39 @@ __global__ __launch_bounds__(256, 2) void k_center_xty_panel(double *__restrict_
         // ---- B operand of this row range in the MFMA layout: lane l -> (k = row 4 kk + (l >> 4), n = y column l & 15)
         //      (registers: every wave builds all of it; LDS: each wave builds a quarter, published by the first fill barrier)
         double breg[BLDS ? 1 : TH / 4];
+        {
+            // all loads of the tile's Y rows and weights go out back to back, UNCONDITIONALLY (clamped row / column, masked
+            // afterwards): written as `if (row < rend) { load ... }` per k-step the compiler put a vmcnt(0) into every one of
+            // the TH / 4 iterations — 16 dependent memory round trips at the head of every row tile
+            constexpr int NB = BLDS ? TH / 16 : TH / 4;
+            double yraw[NB], draw[NB];
+            const int yc_ = min(ycol, q - 1);
 #pragma unroll
-        for (int kq = 0; kq < (BLDS ? TH / 16 : TH / 4); ++kq) {
-            const int kk = BLDS ? wv * (TH / 16) + kq : kq;
-            const int64_t row = i0 + 4 * kk + (lane >> 4);
-            const bool ok = row < rend;
-            double yv = 0.0, dv = 0.0;
-            if (ok) {
-                dv = d[row];
+            for (int kq = 0; kq < NB; ++kq) {
+                const int kk = BLDS ? wv * (TH / 16) + kq : kq;
+                const int64_t row = min(i0 + 4 * kk + (lane >> 4), rend - 1);
+                draw[kq] = d[row];
+                yraw[kq] = Yc[(size_t)row + (size_t)yc_ * (size_t)ldy];
+            }
+#pragma unroll
+            for (int kq = 0; kq < NB; ++kq) {
+                const int kk = BLDS ? wv * (TH / 16) + kq : kq;
+                const int64_t row = i0 + 4 * kk + (lane >> 4);
+                const bool ok = row < rend;
+                double yv = 0.0;
                 if (ycol < q) {
-                    yv = Yc[(size_t)row + (size_t)ycol * (size_t)ldy] - ym;
+                    yv = yraw[kq] - ym;
                     if (SCAL) yv /= ysd;
                 }
-                if ((BLDS || wv == 0) && blockIdx.y == 0) Yr[(size_t)row * 16 + ycol] = yv;
+                const double dv = ok ? draw[kq] : 0.0;
+                if (!ok) yv = 0.0;
+                if (ok && (BLDS || wv == 0) && blockIdx.y == 0) Yr[(size_t)row * 16 + ycol] = yv;
+                // raw mode: the pad column `ones_col` carries the weights themselves -> that column of X'D[Yc | 1] is the vector
+                // of weighted column sums of X (the means come out of the same pass, fit.hip)
+                const double bv = ycol == ones_col ? dv : dv * yv;
+                if (BLDS) yt_s[(4 * kk + (lane >> 4)) * 16 + ycol] = bv;
+                else breg[kq] = bv;
             }
-            // raw mode: the pad column `ones_col` carries the weights themselves -> that column of X'D[Yc | 1] is the vector
-            // of weighted column sums of X (the means come out of the same pass, fit.hip)
-            const double bv = ycol == ones_col ? dv : dv * yv;
-            if (BLDS) yt_s[(4 * kk + (lane >> 4)) * 16 + ycol] = bv;
-            else breg[kq] = bv;
         }
         // (runtime loop over the tiles: only the MFMA section below names its accumulator statically)
 #pragma unroll 1

@@ -382,46 +382,60 @@ __global__ __launch_bounds__(NT) void k_nipals_M(nipR_args g)
     const double s = jch_wave_sum(s0 + s1);
     if (lane == 0) { g.M[e] = s; g.Mi[e] = (i == j) ? 1.0 : 0.0; }
 }
+// LDS = true (2 m^2 doubles fit: m <= 90): the whole elimination runs on LDS copies — barriers only; the global-memory version
+// needs a device-scope fence after every phase (4 per pivot: 5.8 ms at nlv = 50, each fence writes back / invalidates the L2).
+template <bool LDS>
 __global__ __launch_bounds__(NT) void k_nipals_inv(nipR_args g)
 {
+    extern __shared__ __attribute__((aligned(16))) double inv_lds[];
     __shared__ int piv_s;
     const int m = g.nlv, tid = threadIdx.x;
+    double *M = LDS ? inv_lds : g.M, *Mi = LDS ? inv_lds + m * m : g.Mi;
+    if (LDS) {
+        for (int e = tid; e < m * m; e += NT) { M[e] = g.M[e]; Mi[e] = g.Mi[e]; }
+        __syncthreads();
+    }
+    const int jl = tid % 64, il = tid / 64;             // (compile-time divisors) column lane / row group of the update
     for (int c = 0; c < m; ++c) {
         if (tid == 0) {
-            int piv = c; double best = fabs(g.M[c * m + c]);
+            int piv = c; double best = fabs(M[c * m + c]);
             for (int i = c + 1; i < m; ++i)
-                if (fabs(g.M[i * m + c]) > best) { best = fabs(g.M[i * m + c]); piv = i; }
+                if (fabs(M[i * m + c]) > best) { best = fabs(M[i * m + c]); piv = i; }
             piv_s = piv;
         }
         __syncthreads();
         const int piv = piv_s;
         if (piv != c)
             for (int j = tid; j < m; j += NT) {
-                double t = g.M[c * m + j]; g.M[c * m + j] = g.M[piv * m + j]; g.M[piv * m + j] = t;
-                t = g.Mi[c * m + j]; g.Mi[c * m + j] = g.Mi[piv * m + j]; g.Mi[piv * m + j] = t;
+                double t = M[c * m + j]; M[c * m + j] = M[piv * m + j]; M[piv * m + j] = t;
+                t = Mi[c * m + j]; Mi[c * m + j] = Mi[piv * m + j]; Mi[piv * m + j] = t;
             }
-        __threadfence();
+        if (!LDS) __threadfence();
         __syncthreads();
-        const double dd = g.M[c * m + c];
+        const double dd = M[c * m + c];
         __syncthreads();
-        for (int j = tid; j < m; j += NT) { g.M[c * m + j] /= dd; g.Mi[c * m + j] /= dd; }
-        __threadfence();
+        for (int j = tid; j < m; j += NT) { M[c * m + j] /= dd; Mi[c * m + j] /= dd; }
+        if (!LDS) __threadfence();
         __syncthreads();
-        for (int e = tid; e < m * m; e += NT) {
-            const int i = e / m, j = e % m;
+        for (int i = il; i < m; i += NT / 64) {
             if (i == c) continue;
-            const double f = g.M[i * m + c];
+            const double f = M[i * m + c];
+            if (f == 0.0) continue;
             // column c of M (the multipliers f) is left untouched in this step and zeroed in the next
-            if (f != 0.0 && j != c) g.M[i * m + j] -= f * g.M[c * m + j];
-            if (f != 0.0) g.Mi[i * m + j] -= f * g.Mi[c * m + j];
+            for (int j = jl; j < m; j += 64) {
+                if (j != c) M[i * m + j] -= f * M[c * m + j];
+                Mi[i * m + j] -= f * Mi[c * m + j];
+            }
         }
-        __threadfence();
+        if (!LDS) __threadfence();
         __syncthreads();
         for (int i = tid; i < m; i += NT)
-            if (i != c) g.M[i * m + c] = 0.0;
-        __threadfence();
+            if (i != c) M[i * m + c] = 0.0;
+        if (!LDS) __threadfence();
         __syncthreads();
     }
+    if (LDS)
+        for (int e = tid; e < m * m; e += NT) g.Mi[e] = Mi[e];
 }
 __global__ __launch_bounds__(NT) void k_nipals_Rmul(nipR_args g)
 {
@@ -442,7 +456,17 @@ int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv)
     g.M = (double *)ctx->gemm_b.ptr;
     g.Mi = g.M + (size_t)nlv * nlv;
     hipLaunchKernelGGL(k_nipals_M, dim3((nlv * nlv + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, ctx->stream, g);
-    hipLaunchKernelGGL(k_nipals_inv, dim3(1), dim3(NT), 0, ctx->stream, g);
+    const size_t inv_lds = sizeof(double) * 2 * (size_t)nlv * nlv;
+    if (inv_lds <= 140 * 1024) {
+        static jch_per_device_once attr;
+        if (!attr.done(ctx->device)) {
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_nipals_inv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));   // (+ the static pivot word)
+            attr.mark(ctx->device);
+        }
+        hipLaunchKernelGGL(k_nipals_inv<true>, dim3(1), dim3(NT), inv_lds, ctx->stream, g);
+    } else {
+        hipLaunchKernelGGL(k_nipals_inv<false>, dim3(1), dim3(NT), 0, ctx->stream, g);
+    }
     hipLaunchKernelGGL(k_nipals_Rmul, dim3((nlv * p + NT - 1) / NT), dim3(NT), 0, ctx->stream, g);
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
