@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NT) void k_nipals_M(nipR_args g)
     if (lane == 0) { g.M[e] = s; g.Mi[e] = (i == j) ? 1.0 : 0.0; }
 }
 // LDS = true (2 m^2 doubles fit: m <= 90): the whole elimination runs on LDS copies — barriers only; the global-memory version
-// needs a device-scope fence after every phase (4 per pivot: 5.8 ms at nlv = 50, each fence writes back / invalidates the L2).
+// orders its phases with block-scope fences (round 1 used device-scope ones: each wrote back / invalidated the L2).
 template <bool LDS>
 __global__ __launch_bounds__(NT) void k_nipals_inv(nipR_args g)
 {
@@ -410,12 +410,12 @@ __global__ __launch_bounds__(NT) void k_nipals_inv(nipR_args g)
                 double t = M[c * m + j]; M[c * m + j] = M[piv * m + j]; M[piv * m + j] = t;
                 t = Mi[c * m + j]; Mi[c * m + j] = Mi[piv * m + j]; Mi[piv * m + j] = t;
             }
-        if (!LDS) __threadfence();
+        if (!LDS) __threadfence_block();
         __syncthreads();
         const double dd = M[c * m + c];
         __syncthreads();
         for (int j = tid; j < m; j += NT) { M[c * m + j] /= dd; Mi[c * m + j] /= dd; }
-        if (!LDS) __threadfence();
+        if (!LDS) __threadfence_block();
         __syncthreads();
         for (int i = il; i < m; i += NT / 64) {
             if (i == c) continue;
@@ -427,11 +427,11 @@ __global__ __launch_bounds__(NT) void k_nipals_inv(nipR_args g)
                 Mi[i * m + j] -= f * Mi[c * m + j];
             }
         }
-        if (!LDS) __threadfence();
+        if (!LDS) __threadfence_block();
         __syncthreads();
         for (int i = tid; i < m; i += NT)
             if (i != c) M[i * m + c] = 0.0;
-        if (!LDS) __threadfence();
+        if (!LDS) __threadfence_block();
         __syncthreads();
     }
     if (LDS)

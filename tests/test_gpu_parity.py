@@ -390,6 +390,19 @@ def test_long_input_accessors(shape, J, ctx, monkeypatch):
     assert O.rel_fro(J.transform(fm, Xn, ctx=ctx), got_T) < 1e-13
 
 
+def test_plsnipals_many_lvs_inverse_outside_lds(J, ctx):
+    """`R = W inv(P'W)` (src/plsnipals.jl:95) with nlv = 100 > 90: the Gauss-Jordan runs on global scratch instead of LDS copies."""
+    n, p, q, nlv = 600, 130, 2, 100
+    rng = np.random.default_rng(3)
+    X = np.asfortranarray(rng.standard_normal((n, p)) * np.linspace(3.0, 0.5, p))
+    Y = np.asfortranarray(X[:, :q] + 0.5 * rng.standard_normal((n, q)))
+    fm = J.plsnipals(X, Y, nlv=nlv, ctx=ctx)
+    ref = O.plsnipals(X, Y, nlv=nlv)
+    assert np.allclose(fm.R.T @ fm.P, np.eye(nlv), atol=1e-8)
+    s = O.sign_align(ref.W, fm.W)
+    assert O.rel_fro(ref.R, fm.R * s) < 1e-6 and O.rel_fro(ref.T, fm.T * s) < 1e-6
+
+
 def test_scores_and_gridscorelv(J, ctx):
     """§8f rank 1: scores from device-side sums and gridscorelv == the oracle (src/scores.jl, src/gridscore.jl:167-221)."""
     n, p, q, m = 3000, 40, 3, 700
