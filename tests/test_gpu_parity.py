@@ -225,14 +225,24 @@ def test_bf16_storage_mode(shape, J):
 
 @pytest.mark.parametrize("case", [dict(n=2000, p=60, m=41, k=50, nlvdis=8, nlv=6, metric="mahal", scal=False, h=1.0),
                                   dict(n=1500, p=33, m=10, k=40, nlvdis=5, nlv=9, metric="eucl", scal=True, h=2.0),
-                                  dict(n=20000, p=500, m=48, k=200, nlvdis=20, nlv=15, metric="mahal", scal=False, h=1.0)])
+                                  dict(n=20000, p=500, m=48, k=200, nlvdis=20, nlv=15, metric="mahal", scal=False, h=1.0),
+                                  # the kNN scan in 1 / 2 / 3 row segments, rows not a multiple of 256, k at the capacity (768: one
+                                  # segment), a single query, one score dimension, more than 8 (two column batches, the last partial)
+                                  dict(n=4097, p=20, m=1, k=30, nlvdis=1, nlv=2, metric="eucl", scal=False, h=1.0),
+                                  dict(n=9001, p=25, m=7, k=768, nlvdis=3, nlv=4, metric="mahal", scal=False, h=1.5),
+                                  dict(n=13000, p=40, m=130, k=300, nlvdis=11, nlv=5, metric="mahal", scal=True, h=1.0, sources=25),
+                                  dict(n=50011, p=30, m=33, k=120, nlvdis=17, nlv=6, metric="eucl", scal=False, h=3.0, sources=28)])
 def test_lwplsr_predict(case, J, ctx):
     """BASELINE.json configs[4] shape (last case: cfg5 with fewer rows/queries): kNN in the (whitened) global-score
     space, wdist weights, one weighted local plskern per query, predictions for nlv = 0..nlv (src/lwplsr.jl:134-166)."""
     c = case
     X = CO.fill_uniform(20250112, c["n"], c["p"])
-    y = (X[:, :5] @ np.array([1.0, -2.0, 0.5, 3.0, 1.5]) + np.sin(3 * X[:, 5]) + 0.05 * CO.fill_uniform(20250113, c["n"], 1)[:, 0])
     Xq = CO.fill_uniform(20250115, c["m"], c["p"])
+    if c.get("sources"):   # latent structure: on iid columns a PLS1 fit has ~8 meaningful LVs, the later scores are rounding noise
+        L = CO.fill_uniform(7, c["sources"], c["p"]) - 0.5
+        X = CO.fill_uniform(5, c["n"], c["sources"]) @ L + 0.05 * X
+        Xq = CO.fill_uniform(6, c["m"], c["sources"]) @ L + 0.05 * Xq
+    y = (X[:, :5] @ np.array([1.0, -2.0, 0.5, 3.0, 1.5]) + np.sin(3 * X[:, 5]) + 0.05 * CO.fill_uniform(20250113, c["n"], 1)[:, 0])
     kw = dict(nlvdis=c["nlvdis"], metric=c["metric"], h=c["h"], k=c["k"], nlv=c["nlv"], scal=c["scal"])
     ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, c["nlv"] + 1))
     fm = J.lwplsr(X, y, ctx=ctx, **kw)
@@ -245,8 +255,9 @@ def test_lwplsr_predict(case, J, ctx):
     pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)            # m x le
     assert pred.shape == ref["pred"][:, 0, :].shape
     assert O.rel_fro(ref["pred"][:, 0, :], pred) < 1e-7
-    one = J.predict(fm, Xq, nlv=3, ctx=ctx)
-    assert isinstance(one.pred, np.ndarray) and O.rel_fro(ref["pred"][:, 0, 3], one.pred[:, 0]) < 1e-7
+    a1 = min(3, c["nlv"])
+    one = J.predict(fm, Xq, nlv=a1, ctx=ctx)
+    assert isinstance(one.pred, np.ndarray) and O.rel_fro(ref["pred"][:, 0, a1], one.pred[:, 0]) < 1e-7
 
 
 def test_lwplsr_constant_neighbourhood(J, ctx):
