@@ -13,7 +13,7 @@ def cp(a, b):
     print("missing", a); return False
 for a, b in [("bench.json", "r02_final_bench.json"), ("bench_cfg4.json", "r02_final_bench_cfg4_plsnipals.json"), ("bench_cfg4_eager.json", "r02_bench_cfg4_plsnipals_eager_deflation.json"),
              ("bench_plsnipals_q10.json", "r02_bench_plsnipals_q10_cfg2_shape.json"), ("bench_plsnipals_q10_eager.json", "r02_bench_plsnipals_q10_cfg2_shape_eager_deflation.json"),
-             ("bench_plswold_eager.json", "r02_sibling_bench_plswold_eager_deflation.json"), ("pmc_nipals_q10_summary.txt", "r02_pmc_plsnipals_q10.txt"),
+             ("bench_plswold_eager.json", "r02_sibling_bench_plswold_eager_deflation.json"), ("pmc_nipals_q10_summary.txt", "r02_pmc_plsnipals_q10.txt"), ("pmc_lwplsr_summary.txt", "r02_pmc_lwplsr_cfg5.txt"),
              ("bench_bf16.json", "r02_final_bench_bf16.json"), ("bench_bf16_n8e6_one_gpu.json", "r02_final_bench_bf16_n8e6_one_gpu.json"),
              ("bench_rank_share_125k.json", "r02_rank_share_125k_rows.json"), ("bench_scal.json", "r02_final_bench_scal_true.json"),
              ("lwplsr_cfg5.json", "r02_lwplsr_cfg5.json"), ("lwplsr_cfg5_3replicas_one_gpu.json", "r02_lwplsr_cfg5_3replicas_one_gpu_rehearsal.json"),
