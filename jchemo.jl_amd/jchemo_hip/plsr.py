@@ -799,14 +799,19 @@ def _grid_table(pars, rng, res):
     return out
 
 
-def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, ctx: Optional[Context] = None, **kwargs):
-    """`gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars)` — src/gridscore.jl:167-221: per parameter combination
+def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, verbose: bool = False, ctx: Optional[Context] = None, **kwargs):
+    """`gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars, verbose)` — src/gridscore.jl:167-221: per parameter combination
     one fit at max(nlv), predictions for the whole range in ONE pass over X, scores from device-side sums.
+    `verbose` prints what the reference prints (:178,189,191,217).
     Returns dict(nlv=[...], <one list per pars key>, res=(ncomb * le_nlv, q)), rows combination-major."""
     rng = _nlv_range(nlv, ensure_mat(Xtrain).shape[1])
     name = getattr(score, "_jch_name", None)
     blocks = []
+    if verbose:
+        print("-- Nb. combinations = 0." if pars is None else f"-- Nb. combinations = {len(_pars_rows(pars))}")
     for kw in _pars_rows(pars):
+        if verbose and pars is not None:
+            print("".join(f"{k_} => {v_}" for k_, v_ in kw.items()))
         fm = fun(Xtrain, Ytrain, nlv=max(rng), ctx=ctx, **kwargs, **kw)
         if name is None or not isinstance(fm, Plsr):   # arbitrary score(pred, Y) or a non-Plsr model: what predict returns
             pred = predict(fm, X, nlv=rng, ctx=ctx)
@@ -816,13 +821,15 @@ def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, ctx: Option
             blocks.append(np.vstack([np.asarray(score(pr, Y)).reshape(1, -1) for pr in pred]))
         else:
             blocks.append(_score_from_sums(name, _score_sums(_pred_matrix(fm, X, rng, ctx), Y, None, ctx)))
+    if verbose:
+        print("-- End.")
     return _grid_table(pars, rng, np.vstack(blocks))
 
 
 _CV_FUNS = None
 
 
-def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] = None, **kwargs):
+def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, verbose: bool = False, ctx: Optional[Context] = None, **kwargs):
     """`gridcvlv(X, Y; segm, score, fun, nlv, pars)` — src/gridcv.jl:187-228.  The reference copies rmrow(X, s) for
     every segment; here X stays where it is and each fold is ONE weighted fit with weight 0 on the held-out rows
     (identical means / XtY / loadings), whose scores T on the held-out rows already are their transformed rows:
@@ -842,9 +849,13 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] =
     rng = _nlv_range(nlv, p)
     combos = _pars_rows(pars)
     rep_out = []
-    for listsegm in segm:
+    for irep, listsegm in enumerate(segm):
+        if verbose:                                     # src/gridcv.jl:197,202,226
+            print(f"/ repl={irep + 1} ", end="")
         zres = []
-        for s in listsegm:
+        for jseg, s in enumerate(listsegm):
+            if verbose:
+                print(f"segm={jseg + 1} ", end="")
             s = np.asarray(s)
             held = np.zeros(n); held[s] = 1.0
             w = 1.0 - held
@@ -864,6 +875,8 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, ctx: Optional[Context] =
                 blocks.append(_score_from_sums(name, _score_sums(Pm, Y, held, ctx)))
             zres.append(np.vstack(blocks))
         rep_out.append(np.stack(zres))
+    if verbose:
+        print("/ End.")
     res_rep = np.stack(rep_out)
     out = _grid_table(pars, rng, res_rep.mean(axis=(0, 1)))
     out["res_rep"] = res_rep

@@ -808,6 +808,23 @@ def test_pars_grids(J, ctx):
     assert np.allclose(res["res"], ref, rtol=1e-6)
 
 
+def test_grid_verbose_prints_what_the_reference_prints(J, ctx, capsys):
+    """`verbose = true` of gridscorelv / gridcvlv (src/gridscore.jl:178,189,191,217; src/gridcv.jl:197,202,226)."""
+    rng_ = np.random.default_rng(6)
+    X = rng_.standard_normal((300, 12)); Y = X[:, :2] + 0.1 * rng_.standard_normal((300, 2))
+    pars = J.mpar(scal=[False, True])
+    quiet = J.gridscorelv(X[50:], Y[50:], X[:50], Y[:50], score=J.rmsep, fun=J.plskern, nlv=range(0, 3), pars=pars, ctx=ctx)
+    assert capsys.readouterr().out == ""
+    loud = J.gridscorelv(X[50:], Y[50:], X[:50], Y[:50], score=J.rmsep, fun=J.plskern, nlv=range(0, 3), pars=pars, verbose=True, ctx=ctx)
+    out = capsys.readouterr().out
+    assert out.splitlines() == ["-- Nb. combinations = 2", "scal => False", "scal => True", "-- End."]
+    assert np.array_equal(quiet["res"], loud["res"])
+    J.gridscorelv(X[50:], Y[50:], X[:50], Y[:50], score=J.rmsep, fun=J.plskern, nlv=2, verbose=True, ctx=ctx)
+    assert capsys.readouterr().out.splitlines() == ["-- Nb. combinations = 0.", "-- End."]
+    J.gridcvlv(X, Y, segm=J.segmkf(300, 3, rep=2, seed=1), score=J.msep, fun=J.plskern, nlv=range(0, 3), verbose=True, ctx=ctx)
+    assert capsys.readouterr().out == "/ repl=1 segm=1 segm=2 segm=3 / repl=2 segm=1 segm=2 segm=3 / End.\n"
+
+
 def test_row_sharded_bf16_and_reductions(J):
     """BASELINE configs[2] is the bf16 storage mode on 8 GPUs: its sharded path (fp64 statistics and all-reduces from
     bf16 rows) on 3 loopback ranks vs the single-rank bf16 fit; plus the sharded `summary` (jch_weighted_ss) and
