@@ -655,6 +655,8 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, r
     ctx.check(_lib.load().jch_lwplsr_predict(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, ya, q if batched else 1, ldy,
                                              za, ldz, qa, ldq, Zt.shape[1], xqa, m, ldxq, k, float(obj.h), float(obj.tol), int(obj.scal),
                                              lo, hi, pred.ctypes.data, ind.ctypes.data, dist.ctypes.data, w.ctypes.data))
+    if getattr(obj, "verbose", False):                            # src/locwlv.jl:19,40 (`print(i, " ")` per query, then a newline)
+        print("".join(f"{i} " for i in range(1, m + 1)))
     if not batched:
         # one weighted plskern + predict per query through the same device library (unbatched; src/locwlv.jl:18-39)
         rng = list(range(lo, hi + 1))
