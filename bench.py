@@ -18,6 +18,14 @@ The JSON line also carries
   cpu_baseline : both CPU stand-ins of the reference's `plskern!` — the numpy/OpenBLAS restatement (the same dgemv /
                  dgemm / dgesdd Julia calls) and the C + OpenMP port of its schedule — timed on this host's cores at the
                  FULL n, two runs each; value = the faster one (rank 0, N == 1 only).
+  other_configs: (N == 1) the other BASELINE.json configs that fit one GPU, run AFTER the headline's timed region: cfg4
+                 plsnipals n=1e6 p=2000 q=1 nlv=50, the one-GPU share of cfg3 (bf16 storage, n=1e6), cfg5 lwplsr
+                 (1000 queries x k=200) — each with value, ms_per_step and its own roofline block.
+  collective   : (N > 1) what the all-reduces cost — transport, ranks actually reached, per-LV all-reduce microseconds
+                 through RCCL and through the P2P inbox (probe on the fit's own message size + HIP-event / device-clock
+                 time inside profiled fits), prologue collectives; plus per-rank device times (min / max over ranks) and
+                 rank_share = the same shard fitted WITHOUT any collective on the same GPU (efficiency_vs_rank_share).
+                 DESIGN.md §8 says how to read each field.
 """
 import argparse
 import ctypes as C
@@ -104,11 +112,117 @@ def cpu_baseline(n_total, p, q, nlv, sample_rows):
             probe = f"julia present, probe failed: {e}"
     lvs = {k_: nlv / (v * scale) for k_, v in best.items()}
     return {"value": lvs[winner], "unit": "LV/s", "cores": cores, "kind": "port", "stand_in": winner,
+            "thread_cap_note": (f"the reported stand-in ran on {cores} threads of a host with {os.cpu_count()} hardware threads "
+                                f"(OpenBLAS in this image is built for at most {blas_threads} threads; the C port used {omp_threads}); "
+                                "vs_cpu_baseline is a ratio against THAT, context only — the roofline fraction is the quality measure"),
             "host_cpus": os.cpu_count(), "threads": {"openblas": blas_threads, "blas": blas_name, "c_port_openmp": omp_threads},
             "lv_per_s": lvs, "seconds": {k_: [round(t, 3) for t in v] for k_, v in runs.items()},
             "sample": (f"plskern! (in place, README.md:93) on {'all' if ns == n_total else 'the first'} {ns} of {n_total} rows "
                        f"(p={p}, q={q}, nlv={nlv}), two runs per stand-in, best run reported"
                        + ("" if ns == n_total else f", time scaled x{scale:.2f}") + f"; {probe}")}
+
+
+def _roof(bytes_per_launch, kernel_ms_total, launches, kernel, note=None):
+    avg_s = kernel_ms_total / max(launches, 1) * 1e-3
+    ach = bytes_per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+    r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_s * 1e3, "launches": launches}
+    if note:
+        r["note"] = note
+    return r
+
+
+def secondary_fit(J, _lib, lib, ctx, dev, *, label, algo, n, p, q, nlv, bf16, steps, warmup):
+    """One of BASELINE.json's OTHER configs on this GPU (device-resident synthetic inputs, same generator and the same C-ABI
+    entry points as the headline; run after — never inside — the headline's timed region).  value = LV/s over `steps` fits."""
+    X = J.colmajor_empty(n, p, dev); Y = J.colmajor_empty(n, q, dev)
+    ctx.check(lib.jch_fill_uniform(ctx._h, X.data_ptr(), n, p, n, 0, n, 20250112))
+    ctx.check(lib.jch_fill_uniform(ctx._h, Y.data_ptr(), n, q, n, 0, n, 20250113))
+    if bf16:
+        Xb = J.colmajor_empty(n, p, dev, dtype=torch.bfloat16); Xb.copy_(X); X = Xb
+        Yb = J.colmajor_empty(n, q, dev, dtype=torch.bfloat16); Yb.copy_(Y); Y = Yb
+        del Xb, Yb
+        torch.cuda.empty_cache()
+    kmax = min(nlv, p, n)
+    T = J.colmajor_empty(n, kmax, dev); wn = torch.empty(n, dtype=torch.float64, device=dev)
+    P = np.zeros((p, kmax), order="F"); R = np.zeros((p, kmax), order="F"); W = np.zeros((p, kmax), order="F")
+    Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
+    xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
+    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0, reserved=0)
+    got = C.c_int32(0)
+    entry = lib.jch_plsnipals_fit if algo == "plsnipals" else lib.jch_plskern_fit
+
+    def step():
+        ctx.check(entry(ctx._h, C.byref(desc), X.data_ptr(), n, Y.data_ptr(), n, None, T.data_ptr(), P.ctypes.data, R.ctypes.data,
+                        W.ctypes.data, Cm.ctypes.data, TT.ctypes.data, xm.ctypes.data, xs.ctypes.data, ym.ctypes.data, ys.ctypes.data,
+                        wn.data_ptr(), C.byref(got)))
+    for _ in range(warmup):
+        step()
+    sw = 0.0; nl = 0; fit = 0.0; pro = 0.0; sb = 0.0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        pr = ctx.profile()
+        sw += pr.sweep_ms; nl += pr.sweep_launches; fit += pr.fit_ms; pro += pr.prologue_ms; sb = pr.sweep_bytes
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    k = got.value
+    assert np.all(np.isfinite(TT[:k])) and np.all(TT[:k] > 0), "secondary fit produced non-finite / non-positive t't"
+    kernel = ("k_sweep_lazy + k_kpass_lazy (per LV: two reads of X, rows rewritten every 6th LV; bytes_per_launch = bytes actually moved per LV)"
+              if algo == "plsnipals" else "k_sweep_bf16_v2 (fused sweep over the bf16 row-major copy)" if bf16 else "k_sweep")
+    out = {"config": label, "metric": "latent-variables/sec", "value": k * steps / dt, "unit": "LV/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "dtype": "bf16 storage / f32 rows / f64 state" if bf16 else "f64",
+           "roofline": _roof(sb, sw, nl, kernel),
+           "device_ms_per_step": {"fit": fit / steps, "prologue": pro / steps, "dominant_kernels": sw / steps,
+                                  "small_state_and_gaps": (fit - pro - sw) / steps}}
+    del X, Y, T, wn
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_lwplsr(J, lib, ctx, dev, calls):
+    """cfg5 (BASELINE.json configs[4]): predict(::Lwplsr) for 1000 queries, k = 200, n = 1e5, p = 500, nlvdis = 20, mahal,
+    nlv = 0..15 on device-resident spectra-like inputs (30 latent sources + noise: on iid-uniform columns a PLS1 fit has
+    ~10 meaningful LVs and every fp64 implementation returns rounding noise afterwards; tools/bench_lwplsr.py).
+    value = queries/s of the whole predict call (global transform + kNN + weights + local fits + results to the host)."""
+    n, p, m, k, nlvdis, nlv, r = 100_000, 500, 1000, 200, 20, 15, 30
+
+    def gen(rows, seed):
+        S = J.colmajor_empty(rows, r, dev); E = J.colmajor_empty(rows, p, dev); L = J.colmajor_empty(r, p, dev)
+        ctx.check(lib.jch_fill_uniform(ctx._h, S.data_ptr(), rows, r, rows, 0, rows, seed))
+        ctx.check(lib.jch_fill_uniform(ctx._h, E.data_ptr(), rows, p, rows, 0, rows, seed + 100))
+        ctx.check(lib.jch_fill_uniform(ctx._h, L.data_ptr(), r, p, r, 0, r, 777))
+        out = J.colmajor_empty(rows, p, dev); out.copy_(S @ L + 0.1 * E)
+        return out
+    X = gen(n, 20250112); Xq = gen(m, 20250115)
+    beta = torch.zeros(p, dtype=torch.float64, device=dev); beta[:5] = torch.tensor([1.0, -2.0, 0.5, 3.0, 1.5], dtype=torch.float64)
+    noise = J.colmajor_empty(n, 1, dev); ctx.check(lib.jch_fill_uniform(ctx._h, noise.data_ptr(), n, 1, n, 0, n, 20250113))
+    y = J.colmajor_empty(n, 1, dev); y.copy_((X @ beta + torch.sin(3 * X[:, 5])).reshape(-1, 1) + 0.05 * noise)
+    fm = J.lwplsr(X, y, nlvdis=nlvdis, metric="mahal", h=1.0, k=k, nlv=nlv, ctx=ctx)
+    J.predict(fm, Xq, nlv=range(0, nlv + 1), ctx=ctx)
+    dev_ms = {"copy": 0.0, "knn_and_weights": 0.0, "local_fits": 0.0}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(calls):
+        res = J.predict(fm, Xq, nlv=range(0, nlv + 1), ctx=ctx)
+        pr = ctx.profile()
+        dev_ms["copy"] += pr.smallstate_ms; dev_ms["knn_and_weights"] += pr.prologue_ms - pr.smallstate_ms; dev_ms["local_fits"] += pr.sweep_ms
+        gather_bytes = pr.sweep_bytes
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / calls
+    pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)
+    assert pred.shape == (m, nlv + 1) and np.all(np.isfinite(pred)), "lwplsr predictions are not finite"
+    out = {"config": f"lwplsr predict n={n} p={p}, {m} queries x k={k} neighbours, nlvdis={nlvdis} mahal, nlv=0..{nlv} (BASELINE.json configs[4])",
+           "metric": "queries/sec", "value": m / dt, "unit": "queries/s", "steps": calls, "warmup": 1, "ms_per_step": dt * 1e3, "dtype": "f64",
+           "local_lv_per_s": m * nlv / dt,
+           "roofline": _roof(gather_bytes, dev_ms["local_fits"], calls, "k_locw_* (batched local weighted plskern, one workgroup per query)",
+                             note="algorithmic bytes = the gathered neighbour rows m k p 8 (SURVEY §8d: the path is latency / occupancy bound, "
+                                  "the HBM fraction is reported for completeness; profiles/ holds the counted traffic)"),
+           "device_ms_per_step": {k_: v / calls for k_, v in dev_ms.items()}}
+    del X, Xq, y, noise, fm
+    torch.cuda.empty_cache()
+    return out
+
+
+def _minmax(vals):
+    return {"min": float(min(vals)), "max": float(max(vals))}
 
 
 def main():
@@ -127,6 +241,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU baseline run (0 = all n: no extrapolation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the secondary host-arrays-in / host-Plsr-out timing")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip cfg4 / cfg3-share / cfg5 after the headline (N == 1)")
+    ap.add_argument("--no-rank-share", action="store_true", help="N > 1: skip the collective-free fit of this rank's shard")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,7 +347,7 @@ def main():
     entry = {"plsnipals": lib.jch_plsnipals_fit, "plssimp": lib.jch_plssimp_fit, "plsrosa": lib.jch_plsrosa_fit}.get(args.algo, lib.jch_plskern_fit)
     niter = np.zeros(kmax)
 
-    def step():
+    def step(ctx=ctx):
         if args.algo == "plswold":   # sibling algorithm: reference defaults tol = sqrt(eps), maxit = 200
             ctx.check(lib.jch_plswold_fit(ctx._h, C.byref(desc), X.data_ptr(), n, Y.data_ptr(), n, None, float(np.sqrt(np.finfo(float).eps)), 200,
                                           T.data_ptr(), P.ctypes.data, R.ctypes.data, W.ctypes.data, Cm.ctypes.data, TT.ctypes.data,
@@ -247,13 +363,23 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    in_fit = {}
+
+    def _coll_of(pr):   # per-LV all-reduce microseconds of one profiled fit (include/jchemo_hip.h: jch_profile collective fields)
+        return {"transport": _lib.TRANSPORT_NAMES.get(pr.collective_transport, str(pr.collective_transport)),
+                "us_per_lv": pr.collective_ms * 1e3 / max(pr.collective_calls, 1), "calls": pr.collective_calls,
+                "polling_us_per_lv": pr.collective_wait_ms * 1e3 / max(pr.collective_calls, 1), "prologue_us": pr.prologue_collective_ms * 1e3}
     if rehearsal:
         transport = "p2p inbox only (one-GPU rehearsal)"
     elif world > 1 and not rccl_ok:
         transport = "p2p inbox over xGMI only (the library's RCCL communicator did not come up)"
     elif world > 1:
         transport = "rccl"
-        step()                          # reference fit: every collective through RCCL
+        step()                          # reference fit: every collective through RCCL (also RCCL's lazy channel set-up)
+        ctx.set_profiling(True)
+        step()
+        in_fit["rccl"] = _coll_of(ctx.profile())
+        ctx.set_profiling(False)
         if p2p_candidate:
             P_ref, TT_ref = P.copy(), TT.copy()
             good = 0
@@ -277,6 +403,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sweep_ms = 0.0; sweep_launches = 0; fit_ms = 0.0; prologue_ms = 0.0; small_ms = 0.0
+    coll_ms = 0.0; coll_wait_ms = 0.0; coll_pro_ms = 0.0; coll_calls = 0; coll_tr = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -284,6 +411,8 @@ def main():
         pr = ctx.profile()     # host-side read of already-recorded events (the fit call is blocking)
         sweep_ms += pr.sweep_ms; sweep_launches += pr.sweep_launches; fit_ms += pr.fit_ms
         prologue_ms += pr.prologue_ms; small_ms += pr.smallstate_ms
+        coll_ms += pr.collective_ms; coll_wait_ms += pr.collective_wait_ms; coll_pro_ms += pr.prologue_collective_ms
+        coll_calls += pr.collective_calls; coll_tr = pr.collective_transport
         sweep_bytes = pr.sweep_bytes
     barrier()
     dt = time.perf_counter() - t0
@@ -292,6 +421,69 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    collective = None; ranks_stats = None; rank_share = None
+    if world > 1:
+        import torch.distributed as dist
+        mine = {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps, "sweeps": sweep_ms / args.steps,
+                "small_state_and_gaps": small_ms / args.steps, "collective": coll_ms / args.steps,
+                "collective_polling": coll_wait_ms / args.steps, "prologue_collective": coll_pro_ms / args.steps, "rows": n}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        ranks_stats = {k_: _minmax([a_[k_] for a_ in allr]) for k_ in mine}
+        # ---- what one all-reduce costs on this fit's own message sizes, per transport (collective probe: every rank calls it)
+        ldr_b = (p + 1) & ~1
+        sizes = {"per_lv_zp_tt": ldr_b + 2, "prologue_moments": p + q, "prologue_xty": p * 16}
+        probes = {}; seen = {"torch_distributed_world": world}
+        ri, ni = C.c_int32(-1), C.c_int32(-1)
+        ctx.check(lib.jch_ctx_comm_info(ctx._h, C.byref(ri), C.byref(ni)))
+        seen["jch_ctx_comm_info"] = {"rank": int(ri.value), "nranks": int(ni.value)}
+        for name, code, ok_ in (("rccl", _lib.TRANSPORT_RCCL, (not rehearsal) and bool(rccl_ok)), ("inbox", _lib.TRANSPORT_INBOX, p2p_candidate)):
+            if not ok_:
+                probes[name] = None
+                continue
+            try:
+                pr_ = {}
+                for what, cnt in sizes.items():
+                    vec, us = ctx.allreduce_probe(np.ones(cnt), code, iters=40)
+                    pr_[what] = {"doubles": cnt, "us": us}
+                    seen[name] = int(round(float(vec[0])))
+                    if not np.all(vec == vec[0]):
+                        seen[name + "_inconsistent"] = True
+                probes[name] = pr_
+            except Exception as e:  # noqa: BLE001
+                probes[name] = {"failed": str(e)}
+        collective = {"transport_timed": transport, "transport_in_fit": _lib.TRANSPORT_NAMES.get(coll_tr, str(coll_tr)), "ranks_seen": seen,
+                      "per_lv_allreduce_us": {"in_timed_fits": coll_ms * 1e3 / max(coll_calls, 1), "polling_part": coll_wait_ms * 1e3 / max(coll_calls, 1),
+                                              "calls_per_fit": coll_calls / max(args.steps, 1),
+                                              "probe_rccl": (probes.get("rccl") or {}).get("per_lv_zp_tt", {}).get("us") if isinstance(probes.get("rccl"), dict) else None,
+                                              "probe_inbox_kernel": (probes.get("inbox") or {}).get("per_lv_zp_tt", {}).get("us") if isinstance(probes.get("inbox"), dict) else None,
+                                              "one_profiled_fit": in_fit},
+                      "prologue_collectives_us_per_fit": coll_pro_ms * 1e3 / max(args.steps, 1), "probes": probes,
+                      "how_measured": "in_timed_fits / one_profiled_fit: rank 0's jch_profile (RCCL, stand-alone inbox kernel: HIP events around each call on "
+                                      "the ctx stream, so waiting for the slowest rank is included; fused inbox: wall_clock64 inside the small-state kernel); "
+                                      "probe_*: 39 back-to-back all-reduces of the same message, HIP events, no compute in between"}
+        # ---- this rank's shard fitted with NO communicator on the same GPU: what the fit would cost if collectives were free
+        if not args.no_rank_share:
+            solo = J.Context(local_rank, stream="torch")
+            solo.set_profiling(True)
+            step(solo)
+            torch.cuda.synchronize(); ts = time.perf_counter()
+            reps = max(2, min(args.steps, 5)); sfit = 0.0; ssmall = 0.0
+            for _ in range(reps):
+                step(solo)
+                prs = solo.profile(); sfit += prs.fit_ms; ssmall += prs.smallstate_ms
+            torch.cuda.synchronize(); share = (time.perf_counter() - ts) / reps
+            solo.close()
+            shares = [None] * world
+            dist.all_gather_object(shares, {"ms": share * 1e3, "device_fit_ms": sfit / reps, "small_state_and_gaps_ms": ssmall / reps})
+            smax = max(s_["ms"] for s_ in shares)
+            rank_share = {"rows_per_rank": _minmax([a_["rows"] for a_ in allr]), "ms_per_fit": _minmax([s_["ms"] for s_ in shares]),
+                          "device_fit_ms": _minmax([s_["device_fit_ms"] for s_ in shares]),
+                          "small_state_and_gaps_ms": _minmax([s_["small_state_and_gaps_ms"] for s_ in shares]),
+                          "efficiency_vs_rank_share": smax / (dt / args.steps * 1e3),
+                          "note": "every rank fits its own shard alone (no communicator) on its GPU, all ranks at the same time; "
+                                  "efficiency_vs_rank_share = slowest share / measured ms_per_step: 1.0 would mean the all-reduces and the skew between ranks cost nothing"
+                                  + ("; REHEARSAL: the ranks share one GPU, so the shares contend and the ratio is not meaningful" if rehearsal else "")}
     if rank == 0:
         k = got.value
         value = k * args.steps / dt
@@ -329,8 +521,15 @@ def main():
                          "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches,
                          **fit_roofline}),
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
-                                   "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps},
+                                   "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps,
+                                   "collective": coll_ms / args.steps, "small_state_kernels_and_gaps": (small_ms - coll_ms) / args.steps},
         }
+        if world > 1:
+            out["collective"] = collective
+            out["device_ms_per_step_ranks"] = ranks_stats
+            if rank_share:
+                out["rank_share"] = rank_share
+                out["efficiency_vs_rank_share"] = rank_share["efficiency_vs_rank_share"]
         if world == 1 and not args.no_host_path and args.algo == "plskern" and not bf16:
             # SURVEY §8(d) "secondary, also reported": host arrays in -> host Plsr out (H2D of X, Y + D2H of T and the small
             # matrices inside the timed call).  PCIe-bound; never `value`.
@@ -348,6 +547,21 @@ def main():
                 del Xh, Yh
             except Exception as e:  # noqa: BLE001
                 out["host_arrays"] = {"value": None, "note": f"failed: {e}"}
+        if world == 1 and not args.no_other_configs and args.algo == "plskern" and not bf16 and (n_total, p, q, nlv) == (1_000_000, 500, 10, 25):
+            # the other BASELINE.json configs that fit one GPU — outside the headline's timed region, same library, same generator
+            del X, Y, T, wn
+            torch.cuda.empty_cache()
+            others = []
+            for fn_, kw_ in ((secondary_fit, dict(label="plsnipals n=1000000 p=2000 q=1 nlv=50 Float64 (BASELINE.json configs[3])", algo="plsnipals",
+                                                  n=1_000_000, p=2000, q=1, nlv=50, bf16=False, steps=2, warmup=1)),
+                             (secondary_fit, dict(label="plskern n=1000000 p=500 q=10 nlv=25 bf16-stored: the one-GPU share of BASELINE.json configs[2] (n=8e6 over 8 GPUs)",
+                                                  algo="plskern", n=1_000_000, p=500, q=10, nlv=25, bf16=True, steps=5, warmup=2)),
+                             (secondary_lwplsr, dict(calls=5))):
+                try:
+                    others.append(fn_(J, _lib, lib, ctx, dev, **kw_) if fn_ is secondary_fit else fn_(J, lib, ctx, dev, **kw_))
+                except Exception as e:  # noqa: BLE001   (never take the headline down)
+                    others.append({"config": kw_.get("label", "lwplsr cfg5"), "value": None, "note": f"failed: {e}"})
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n_total, p, q, nlv, args.cpu_sample_rows or n_total)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 101 /* 0.1.1: + jch_ctx_get_counter; jch_lwplsr_predict accepts q <= 16 */
+#define JCH_VERSION 102 /* 0.1.2: + collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
@@ -257,11 +257,37 @@ typedef struct jch_profile {
     int32_t sweep_launches;
     int32_t nlv;
     double sweep_bytes;   /* algorithmic bytes of ONE dominant-kernel launch          */
+    /* ---- cross-GPU all-reduces of the last fit (all zero on one GPU).  RCCL / loopback / stand-alone inbox kernel: HIP
+     * events around each call on the ctx stream (so the time includes waiting for the slowest rank); inbox fused into
+     * the small-state kernel: wall_clock64 stamps inside that kernel, first peer store -> rank-ordered sum done.  The
+     * fused time is part of smallstate_ms, the others sit between the kernels smallstate_ms spans: either way
+     * smallstate_ms - collective_ms is the small-state kernels + launch gaps alone. */
+    double collective_ms;          /* sum over the LV loop's all-reduces ([zp, tt] per LV; plsnipals: + K)      */
+    double prologue_collective_ms; /* sum over the prologue's all-reduces (weights, moments / pivot, XtY)        */
+    double collective_wait_ms;     /* inbox only: the part of collective_ms spent polling the peers' flags      */
+    int32_t collective_calls;      /* all-reduces inside the LV loop                                            */
+    int32_t collective_transport;  /* JCH_TRANSPORT_* of the LV loop's all-reduce                               */
 } jch_profile;
+#define JCH_TRANSPORT_NONE 0
+#define JCH_TRANSPORT_RCCL 1
+#define JCH_TRANSPORT_INBOX 2       /* stand-alone single-workgroup inbox kernel (p2p.hip)                       */
+#define JCH_TRANSPORT_INBOX_FUSED 3 /* inbox exchange inside the small-state kernel (no launch of its own)       */
+#define JCH_TRANSPORT_LOOPBACK 4    /* test harness                                                              */
 /* Enable (1) / disable (0) per-kernel HIP-event timing of subsequent fits (adds event records on the
  * ctx stream, no host syncs inside the fit). */
 JCH_API int32_t jch_ctx_set_profiling(jch_ctx *ctx, int32_t enable);
 JCH_API int32_t jch_ctx_get_profile(const jch_ctx *ctx, jch_profile *out);
+
+/* jch_ctx_allreduce_probe — diagnostic: all-reduce (sum) the `count` doubles of `vec` (HOST, in/out) `iters` times
+ * back to back through ONE named transport and report the average time per all-reduce in microseconds (HIP events on
+ * the ctx stream; iteration 0 is a warm-up and excluded when iters > 1).  Every iteration starts from the caller's
+ * values, so on return vec = the sum over ranks: a vector of ones comes back as the number of ranks the transport
+ * actually reached.  Collective: every rank calls it with the same count / iters / transport.
+ *   transport: JCH_TRANSPORT_RCCL (needs jch_ctx_comm_init), JCH_TRANSPORT_INBOX (needs a self-tested inbox; it need
+ *   not be enabled), JCH_TRANSPORT_LOOPBACK, or JCH_TRANSPORT_NONE = whatever a fit would use for this message size.
+ * This is how bench.py compares RCCL and the inbox on the per-LV message of the fit it times. */
+JCH_API int32_t jch_ctx_allreduce_probe(jch_ctx *ctx, int32_t transport, double *vec, int64_t count, int32_t iters,
+                                        double *avg_us);
 
 /* Diagnostic counters of a ctx (cumulative since jch_ctx_create).  which = JCH_COUNTER_PIVOT_REFITS: fits whose one-pass
  * ("raw") prologue was repeated on the centred working copy because the sampled pivot turned out to be further than 64

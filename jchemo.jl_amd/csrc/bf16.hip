@@ -877,6 +877,7 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     }
     (void)jch_ev(ctx);  // end of prologue
     ctx->ev_mark = ctx->ev_used;  // (begin, end) event pairs of the sweeps start here
+    ctx->coll_phase = 1;          // all-reduces from here on belong to the LV loop (profile: collective_ms)
     // ---- LV loop
     JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, -1, nlv, 0, 1, ldz, fast));
     for (int a = 0; a < nlv; ++a) {
@@ -912,6 +913,7 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         if (fast) {
             const bool fuse = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED") && (size_t)(ldr_b + 2) <= ctx->p2p.cap;
             if (!fuse) JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));
+            else ctx->coll_transport = JCH_TRANSPORT_INBOX_FUSED;
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, nslice, ldz, true, fuse, zt8, ldzb, ldr_b));
         } else {
             JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));

@@ -1,5 +1,7 @@
 // Context, error plumbing, workspace, RCCL binding, profiling events.  Public ABI: include/jchemo_hip.h.
 #include <dlfcn.h>
+
+#include <algorithm>
 #include <pthread.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -86,6 +88,7 @@ extern "C" int32_t jch_ctx_destroy(jch_ctx *ctx)
         free_buf(*b);
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->cev_pool) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return JCH_OK;
@@ -263,17 +266,131 @@ static int32_t loopback_allreduce(jch_ctx *ctx, double *dev_buf, size_t count)
 // (X'DX of the opt-in algorithm #2) stay on RCCL when a communicator exists
 static const size_t P2P_SMALL = 32768;
 
+static int32_t rccl_allreduce(jch_ctx *ctx, double *dev_buf, size_t count)
+{
+    int r = g_rccl.AllReduce(dev_buf, dev_buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    if (r != 0) return jch_fail(ctx, JCH_ERCCL, "ncclAllReduce(%zu f64): %s", count, g_rccl.GetErrorString(r));
+    return JCH_OK;
+}
+
 int32_t jch_allreduce_f64(jch_ctx *ctx, double *dev_buf, size_t count)
 {
     if (count == 0) return JCH_OK;
-    if (ctx->loop) return loopback_allreduce(ctx, dev_buf, count);
-    if (ctx->p2p.ready && (count <= P2P_SMALL || !ctx->comm)) return jch_p2p_allreduce(ctx, dev_buf, count, 1, 0, dev_buf);
+    if (ctx->loop) {
+        jch_coll_begin(ctx);
+        const int32_t st = loopback_allreduce(ctx, dev_buf, count);
+        jch_coll_end(ctx);
+        if (ctx->coll_phase) ctx->coll_transport = JCH_TRANSPORT_LOOPBACK;
+        return st;
+    }
+    if (ctx->p2p.ready && (count <= P2P_SMALL || !ctx->comm)) {   // (timed inside the inbox kernel: p2p.stats)
+        if (ctx->coll_phase) ctx->coll_transport = JCH_TRANSPORT_INBOX;
+        return jch_p2p_allreduce(ctx, dev_buf, count, 1, 0, dev_buf);
+    }
     if (!ctx->comm) {
         if (ctx->nranks > 1) return jch_fail(ctx, JCH_ERCCL, "rank %d of %d has no enabled transport (jch_ctx_p2p_enable not called?)", ctx->rank, ctx->nranks);
         return JCH_OK;  // single rank: the local sum is the global sum
     }
-    int r = g_rccl.AllReduce(dev_buf, dev_buf, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
-    if (r != 0) return jch_fail(ctx, JCH_ERCCL, "ncclAllReduce(%zu f64): %s", count, g_rccl.GetErrorString(r));
+    jch_coll_begin(ctx);
+    const int32_t st = rccl_allreduce(ctx, dev_buf, count);
+    jch_coll_end(ctx);
+    if (ctx->coll_phase) ctx->coll_transport = JCH_TRANSPORT_RCCL;
+    return st;
+}
+
+// ---- collective timing (profiling only) ---------------------------------------------------------------------------
+static hipEvent_t coll_event(jch_ctx *ctx)
+{
+    if (ctx->cev_used == ctx->cev_pool.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->cev_pool.push_back(ev);
+    }
+    hipEvent_t ev = ctx->cev_pool[ctx->cev_used++];
+    (void)hipEventRecord(ev, ctx->stream);
+    return ev;
+}
+void jch_coll_begin(jch_ctx *ctx)
+{
+    if (!ctx->profiling) return;
+    if (ctx->cev_used & 1) return;    // (unbalanced: a failed call left a begin behind — keep the pairing)
+    if (coll_event(ctx)) ctx->cev_phase.push_back(ctx->coll_phase);
+}
+void jch_coll_end(jch_ctx *ctx)
+{
+    if (!ctx->profiling || !(ctx->cev_used & 1)) return;
+    (void)coll_event(ctx);
+}
+void jch_coll_reset(jch_ctx *ctx)
+{
+    ctx->cev_used = 0;
+    ctx->cev_phase.clear();
+    ctx->coll_phase = 0;
+    ctx->coll_transport = JCH_TRANSPORT_NONE;
+    if (ctx->profiling && ctx->p2p.stats) (void)hipMemsetAsync(ctx->p2p.stats, 0, 64, ctx->stream);
+}
+void jch_coll_collect(jch_ctx *ctx, jch_profile &pr)
+{
+    pr.collective_ms = pr.prologue_collective_ms = pr.collective_wait_ms = 0.0;
+    pr.collective_calls = 0;
+    pr.collective_transport = ctx->coll_transport;
+    if (!ctx->profiling) return;
+    for (size_t i = 0; 2 * i + 1 < ctx->cev_used && i < ctx->cev_phase.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->cev_pool[2 * i], ctx->cev_pool[2 * i + 1]) != hipSuccess) continue;
+        if (ctx->cev_phase[i]) { pr.collective_ms += ms; pr.collective_calls++; }
+        else pr.prologue_collective_ms += ms;
+    }
+    if (ctx->p2p.stats) {   // inbox kernels (stand-alone or fused): device tick counters, 100 MHz
+        unsigned long long h[8] = {};
+        if (hipMemcpy(h, ctx->p2p.stats, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            const double nr = (double)std::max(1, ctx->p2p.nranks);
+            pr.prologue_collective_ms += (double)h[0] * 1e-5;
+            pr.collective_ms += (double)h[4] * 1e-5;
+            pr.collective_wait_ms += (double)h[5] * 1e-5 / nr;   // every poller added its own wait: average over the nranks flags
+            pr.collective_calls += (int32_t)h[6];
+        }
+    }
+}
+
+extern "C" int32_t jch_ctx_allreduce_probe(jch_ctx *ctx, int32_t transport, double *vec, int64_t count, int32_t iters, double *avg_us)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!vec || count < 1 || count > (1 << 24) || iters < 1 || iters > 100000)
+        return jch_fail(ctx, JCH_EINVAL, "jch_ctx_allreduce_probe: bad arguments");
+    if (transport == JCH_TRANSPORT_RCCL && !ctx->comm) return jch_fail(ctx, JCH_EINVAL, "jch_ctx_allreduce_probe: no RCCL communicator on this ctx");
+    if (transport == JCH_TRANSPORT_INBOX && !ctx->p2p.tested) return jch_fail(ctx, JCH_EINVAL, "jch_ctx_allreduce_probe: the inbox has not passed its self-test");
+    if (transport == JCH_TRANSPORT_LOOPBACK && !ctx->loop) return jch_fail(ctx, JCH_EINVAL, "jch_ctx_allreduce_probe: no loopback group on this ctx");
+    if (transport != JCH_TRANSPORT_NONE && transport != JCH_TRANSPORT_RCCL && transport != JCH_TRANSPORT_INBOX && transport != JCH_TRANSPORT_LOOPBACK)
+        return jch_fail(ctx, JCH_EINVAL, "jch_ctx_allreduce_probe: unknown transport %d", transport);
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    JCH_TRY(jch_reserve(ctx, ctx->colpart, sizeof(double) * 2 * (size_t)count));
+    double *src = (double *)ctx->colpart.ptr, *work = src + count;
+    JCH_HIP(ctx, hipMemcpyAsync(src, vec, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    JCH_HIP(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return jch_fail(ctx, JCH_EHIP, "hipEventCreate failed"); }
+    const bool was_prof = ctx->profiling;
+    ctx->profiling = false;                        // (no event pairs / tick counters from inside the probe)
+    int32_t st = JCH_OK;
+    for (int it = 0; it < iters && st == JCH_OK; ++it) {
+        if (it == (iters > 1 ? 1 : 0)) (void)hipEventRecord(e0, ctx->stream);
+        if (hipMemcpyAsync(work, src, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { st = jch_fail(ctx, JCH_EHIP, "probe copy failed"); break; }
+        if (transport == JCH_TRANSPORT_RCCL) st = rccl_allreduce(ctx, work, (size_t)count);
+        else if (transport == JCH_TRANSPORT_INBOX) st = jch_p2p_allreduce(ctx, work, (size_t)count, 1, 0, work);
+        else st = jch_allreduce_f64(ctx, work, (size_t)count);
+    }
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->profiling = was_prof;
+    hipError_t he = hipMemcpyAsync(vec, work, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (he == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (st != JCH_OK) return st;
+    if (he != hipSuccess) return jch_fail(ctx, JCH_EHIP, "jch_ctx_allreduce_probe: %s", hipGetErrorString(he));
+    JCH_TRY(jch_p2p_check(ctx));
+    if (avg_us) *avg_us = (double)ms * 1e3 / (double)(iters > 1 ? iters - 1 : 1);
     return JCH_OK;
 }
 
@@ -318,6 +435,7 @@ int32_t jch_allreduce_slices(jch_ctx *ctx, double *zt, int m, int nslice, int ld
     if (ctx->nranks <= 1 && !ctx->p2p.ready) return JCH_OK;   // (a one-rank inbox is allowed: it is how the transport's own cost is measured)
     if (ctx->p2p.ready && !ctx->loop) {   // the inbox kernel adds the slices itself: a 4 KB message instead of 33 KB
         *nslice_out = 1;
+        if (ctx->coll_phase) ctx->coll_transport = JCH_TRANSPORT_INBOX;
         return jch_p2p_allreduce(ctx, zt, (size_t)m, nslice, ldz, zt);
     }
     return jch_allreduce_f64(ctx, zt, nslice > 1 ? (size_t)nslice * ldz : (size_t)m);

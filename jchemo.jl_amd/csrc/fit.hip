@@ -97,6 +97,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     const bool inplace = d.inplace != 0;
     ctx->ev_used = 0;
     ctx->prof = jch_profile{};
+    jch_coll_reset(ctx);
 
     // ---- inputs on the device (column-major as handed over)
     double *Xc = (double *)io.X, *Yc = (double *)io.Y;
@@ -199,6 +200,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             pr.sweep_ms = sw; pr.sweep_launches = cnt; pr.nlv = nlvb;
             pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
             pr.sweep_bytes = (double)n * ((p + 7) & ~7) * 2.0 + 16.0 * (double)n;
+            jch_coll_collect(ctx, pr);
         }
         return JCH_OK;
     }
@@ -268,6 +270,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, s.mom, s.scl, inplace && kern_like, Xr, ldr, Yr, qpad, s.K, d.scal != 0 || ext_scales));
     }
     hipEvent_t ev_prologue = jch_ev(ctx);
+    ctx->coll_phase = 1;   // all-reduces from here on belong to the LV loop (profile: collective_ms)
 
     // ---- LV loop
     const size_t sweep_ev0 = ctx->ev_used;
@@ -301,6 +304,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             // ONE collective per LV: [zp (p), tt].  With the inbox transport and the fast small-state kernel it happens
             // INSIDE that kernel (no launch of its own); otherwise here (RCCL / inbox kernel / loopback).
             if (fuse_inbox && algo != ALGO_SIMP) {
+                ctx->coll_transport = JCH_TRANSPORT_INBOX_FUSED;
                 JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a, nlv, 0, nslice, ldz, fast, true));
             } else {
                 JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + (raw_mode ? 1 : 0), nslice, ldz, &nslice));
@@ -315,6 +319,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;
             ++x_reads;
             if (fuse_inbox) {   // [zp_raw, tt, c_raw] reduced inside the phase-A kernel
+                ctx->coll_transport = JCH_TRANSPORT_INBOX_FUSED;
                 JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, a | 0x40000000, nlv, 1, nslice, ldz, fast, true));
             } else {
                 JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + qpad, nslice, ldz, &nslice));
@@ -409,6 +414,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         // plsnipals-shaped loops: average per LV of the passes actually made (eager: 2 reads + 1 write; postponed
         // write-back: 2 reads + one write every m-th LV)
         pr.sweep_bytes = kern_like ? per_x + 16.0 * (double)n : per_x * (double)(x_reads + x_writes) / (double)std::max(nlv, 1);
+        jch_coll_collect(ctx, pr);
     }
     return JCH_OK;
 }

@@ -42,6 +42,7 @@ struct jch_p2p {   // P2P inbox transport (p2p.hip)
     unsigned long long epoch = 0;
     long long timeout_ticks = 0;
     size_t cap = 0;                            // doubles per (parity, rank) slot
+    unsigned long long *stats = nullptr;       // device [2 phases][4]: ticks in the exchange, ticks polling flags, calls, -
 };
 
 struct jch_ctx {
@@ -66,6 +67,13 @@ struct jch_ctx {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     size_t ev_mark = 0;
+    // collective timing (profiling only): event pairs around the all-reduces that are calls of their own, tagged with the
+    // phase of the fit (0 prologue, 1 LV loop); the fused inbox exchange is timed inside its kernel (p2p.stats)
+    std::vector<hipEvent_t> cev_pool;
+    std::vector<int> cev_phase;      // one entry per PAIR
+    size_t cev_used = 0;             // events handed out (2 per pair)
+    int coll_phase = 0;
+    int coll_transport = 0;          // JCH_TRANSPORT_* of the last LV-loop all-reduce
     // tuning knobs (env JCH_SWEEP_BLOCKS_PER_CU etc.)
     int sweep_blocks_per_cu = 0;
     // diagnostics
@@ -111,6 +119,10 @@ struct jch_span {
     hipEvent_t a = nullptr, b = nullptr;
 };
 hipEvent_t jch_ev(jch_ctx *ctx);  // nullptr when profiling is off
+void jch_coll_begin(jch_ctx *ctx);   // profiling: event in front of / behind an all-reduce call (ctx.hip)
+void jch_coll_end(jch_ctx *ctx);
+void jch_coll_reset(jch_ctx *ctx);   // start of a fit: forget the pairs, zero the inbox tick counters
+void jch_coll_collect(jch_ctx *ctx, jch_profile &pr);   // after the fit's final sync: fill the collective fields
 
 // ---- kernel launchers (each enqueues on ctx->stream; no host sync) --------------------------------
 // prologue.hip

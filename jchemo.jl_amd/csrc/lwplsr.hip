@@ -161,6 +161,9 @@ __global__ __launch_bounds__(256) void k_knn_scan(knn_args g)
             int cq[KNN_QB];
 #pragma unroll
             for (int qq = 0; qq < KNN_QB; ++qq) cq[qq] = cnt[qq];
+            // every wave must have taken its snapshot before any wave's next chunk bumps the counters: the compaction
+            // below contains barriers, so the decision has to be the same in all four waves
+            __syncthreads();
 #pragma unroll
             for (int qq = 0; qq < KNN_QB; ++qq) {
                 if (qq < nq && cq[qq] > KNN_CAP - 256) {   // compact: keep the k best, raise the bar (block-uniform decision)
@@ -204,7 +207,16 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
     const int kk = (int)min<int64_t>(k, g.n);
     int *oi = g.ind + (size_t)qi * k;
     double *od = g.dist + (size_t)qi * k, *ow = g.w + (size_t)qi * k;
-    for (int e = tid; e < kk; e += 256) { oi[e] = idx[e]; key[e] = sqrt(key[e]); od[e] = key[e]; }
+    // fewer than k candidates with a finite distance (NaN / Inf in the query's or the training scores: no comparison
+    // against the bar ever holds): the empty places keep the sentinel index.  They are given the in-range row `e` and a
+    // NaN distance — wdist then yields weights 1 for the query exactly as the reference's arithmetic does (every
+    // comparison with NaN is false, 0 / 0 -> NaN -> 1, src/wdist.jl:64-75) and nothing downstream reads out of bounds.
+    for (int e = tid; e < kk; e += 256) {
+        const bool hole = idx[e] < 0 || (int64_t)idx[e] >= g.n;
+        oi[e] = hole ? e : idx[e];
+        key[e] = hole ? __builtin_nan("") : sqrt(key[e]);
+        od[e] = key[e];
+    }
     __syncthreads();
     // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
     const double med = (kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]);
@@ -729,12 +741,16 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     double *Xrm = (double *)ctx->xr.ptr;
     double *ddist = (double *)ctx->gemm_out.ptr, *dw = ddist + (size_t)m * k, *dpred = dw + (size_t)m * k;
     int *dind = (int *)(dpred + (size_t)m * le * q);
+    ctx->ev_used = 0;
+    ctx->prof = jch_profile{};
+    hipEvent_t ev0 = jch_ev(ctx), ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // profiling: copy | kNN + weights | local fits
     {
         const int ptiles = (ldr + 63) / 64;
         const int64_t nchunks = (n + 63) / 64;
         int nbx = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, (ctx->cus * 4 + ptiles - 1) / ptiles));
         hipLaunchKernelGGL(k_to_rowmajor, dim3(nbx, ptiles), dim3(256), 0, ctx->stream, dX, ldxd, n, (int)p, Xrm, ldr);
     }
+    ev1 = jch_ev(ctx);
     {
         knn_args a;
         a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
@@ -754,6 +770,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         hipLaunchKernelGGL(k_knn_scan, dim3((unsigned)((m + KNN_QB - 1) / KNN_QB), nseg), dim3(256), lds, ctx->stream, a);
         hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
     }
+    ev2 = jch_ev(ctx);
     {
         locw_args g;
         g.Xrm = Xrm; g.ldr = ldr; g.p = (int)p; g.Y = dY; g.ldy = ldyd; g.q = (int)q; g.Xq = dXq; g.ldxq = ldxqd; g.m = (int)m;
@@ -766,11 +783,22 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         else JCH_TRY(launch_locw<16>(ctx, g));
     }
     JCH_HIP(ctx, hipGetLastError());
+    ev3 = jch_ev(ctx);
     JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
     if (ind_out) JCH_HIP(ctx, hipMemcpyAsync(ind_out, dind, sizeof(int) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     if (dist_out) JCH_HIP(ctx, hipMemcpyAsync(dist_out, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     if (w_out) JCH_HIP(ctx, hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling && ev0 && ev1 && ev2 && ev3) {
+        // jch_profile of a prediction call: fit_ms = device time of the three stages, prologue_ms = row-major copy + kNN +
+        // weights, sweep_ms = the batched local fits (ONE launch), sweep_bytes = the gathered neighbour rows m k ldr 8
+        // (algorithmic bytes per query = k p 8), smallstate_ms = the row-major copy alone
+        float a = 0.f, b = 0.f, c = 0.f;
+        (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2); (void)hipEventElapsedTime(&c, ev2, ev3);
+        jch_profile &pr = ctx->prof;
+        pr.fit_ms = a + b + c; pr.prologue_ms = a + b; pr.sweep_ms = c; pr.smallstate_ms = a;
+        pr.sweep_launches = 1; pr.nlv = nlv_hi; pr.sweep_bytes = (double)m * k * ldr * 8.0;
+    }
     return JCH_OK;
 }
 

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(P2P_NT) void k_p2p_allreduce(p2p_args g)
     if (tid == 0) bail = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
     __syncthreads();
     if (bail) return;
+    const long long ts0 = p2p_stat_begin(g.t, tid);
     // ---- 1. local slice sum, scattered into slot [par][rank] of every inbox
     for (int i = tid; i < g.count; i += P2P_NT) {
         double v = 0.0;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(P2P_NT) void k_p2p_allreduce(p2p_args g)
         for (int r = 0; r < g.t.nranks; ++r) s += p2p_load_slot(p2p_slot(mine, par, r, g.t.nranks, g.t.cap) + i);
         g.dst[i] = s;
     }
+    p2p_stat_end(g.t, tid, ts0);
 }
 
 static size_t p2p_bytes(int nranks, size_t cap) { return P2P_HDR_BYTES + sizeof(double) * 2 * (size_t)nranks * cap; }
@@ -75,6 +77,8 @@ extern "C" int32_t jch_ctx_p2p_export(jch_ctx *ctx, int32_t nranks, void *handle
     const size_t bytes = p2p_bytes(nranks, t.cap);
     JCH_HIP(ctx, hipExtMallocWithFlags(&t.local, bytes, hipDeviceMallocFinegrained));
     JCH_HIP(ctx, hipMemset(t.local, 0, bytes));
+    JCH_HIP(ctx, hipMalloc((void **)&t.stats, 64));
+    JCH_HIP(ctx, hipMemset(t.stats, 0, 64));
     JCH_HIP(ctx, hipHostMalloc((void **)&t.host_status, 64, hipHostMallocMapped));
     *t.host_status = 0ull;
     JCH_HIP(ctx, hipDeviceSynchronize());
@@ -95,6 +99,7 @@ void jch_p2p_next(jch_ctx *ctx, p2p_dev *out)
     out->timeout_ticks = t.timeout_ticks;
     out->cap = t.cap;
     out->nranks = t.nranks; out->rank = t.rank;
+    out->stats = (ctx->profiling && t.stats) ? t.stats + 4 * (ctx->coll_phase ? 1 : 0) : nullptr;
 }
 
 static int32_t p2p_launch(jch_ctx *ctx, const double *src, int count, int nslice, int ldz, double *dst)
@@ -171,6 +176,7 @@ void jch_p2p_destroy(jch_ctx *ctx)
     for (int r = 0; r < JCH_P2P_MAXR; ++r)
         if (t.opened[r] && t.peer[r]) (void)hipIpcCloseMemHandle(t.peer[r]);
     if (t.local) (void)hipFree(t.local);
+    if (t.stats) (void)hipFree(t.stats);
     if (t.host_status) (void)hipHostFree(t.host_status);
     t = jch_p2p{};
 }

@@ -12,7 +12,17 @@ struct p2p_dev {
     long long timeout_ticks;        // wall_clock64 ticks (100 MHz)
     size_t cap;                     // doubles per (parity, rank) slot
     int nranks, rank;
+    unsigned long long *stats;      // [4] tick counters of the current phase (null: not profiling): exchange, polling, calls
 };
+// thread 0 brackets an exchange with these (wall_clock64: 100 MHz, constant rate)
+__device__ __forceinline__ long long p2p_stat_begin(const p2p_dev &g, int tid) { return (g.stats && tid == 0) ? wall_clock64() : 0; }
+__device__ __forceinline__ void p2p_stat_end(const p2p_dev &g, int tid, long long t0)
+{
+    if (g.stats && tid == 0) {
+        atomicAdd(g.stats, (unsigned long long)(wall_clock64() - t0));
+        atomicAdd(g.stats + 2, 1ull);
+    }
+}
 
 __device__ __forceinline__ unsigned long long *p2p_flag(char *base, int par, int r)
 {
@@ -41,6 +51,7 @@ __device__ __forceinline__ void p2p_publish_and_wait(const p2p_dev &g, int tid)
             if (ok || wall_clock64() - t0 > g.timeout_ticks) break;
             __builtin_amdgcn_s_sleep(4);
         }
+        if (g.stats) atomicAdd(g.stats + 1, (unsigned long long)(wall_clock64() - t0));   // (summed over the nranks pollers)
         if (!ok) {
             __hip_atomic_store(p2p_status(mine), g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(g.host_status, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -519,19 +519,22 @@ __global__ __launch_bounds__(256) void k_reduce_kpart(const double *__restrict__
 // Pivot quality: qual <- max_j |means_j - pivot_j| / spread_j (spread = the sample standard deviation k_pivot_rows saw);
 // the rounding error of the raw formulation grows with the square of that ratio, so the fit checks it when it fetches
 // its results and falls back to the centred copy when the pivot turned out to be far from the means (fit.hip).
-__global__ __launch_bounds__(256) void k_extract_means(double *__restrict__ K, int qpad, int p, int col, const double *__restrict__ pivot,
+__global__ __launch_bounds__(256) void k_extract_means(double *__restrict__ K, int qpad, int p, int col, const double *pivot,
                                                        double *__restrict__ means, double *__restrict__ mshift,
                                                        const double *__restrict__ spread2, double *__restrict__ qual, int q,
-                                                       double *__restrict__ ones_out)
+                                                       double *ones_out)
 {
+    // (`pivot` and `ones_out` ALIAS in raw mode — neither is __restrict__, and the entry is read into a register before
+    // the slot is overwritten)
     const int j = blockIdx.x * 256 + threadIdx.x;
+    const double pv = j < p + q ? pivot[j] : 0.0;
     // raw mode, fit.hip: `pivot` is the scale vector's storage ([pivot (p) | Y means (q)]); once this kernel has read its
     // entry it turns the slot into the divisor 1 the rest of the fit expects there, and the Y means move next to the X
     // means (ones_out == pivot's storage, or null)
-    if (ones_out && j >= p && j < p + q) { means[j] = pivot[j]; ones_out[j] = 1.0; }
+    if (ones_out && j >= p && j < p + q) { means[j] = pv; ones_out[j] = 1.0; }
     if (j < p) {
         const double dm = K[(size_t)j * qpad + col];
-        means[j] = pivot[j] + dm;
+        means[j] = pv + dm;
         mshift[j] = dm;
         K[(size_t)j * qpad + col] = 0.0;
         if (ones_out) ones_out[j] = 1.0;

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         __syncthreads();
         if (*bail_s) return;
         __syncthreads();
+        const long long ts0 = p2p_stat_begin(g.px, tid);
         for (int c = tid; c < mz; c += FT) {
             double s = 0.0;
             if (g.nslice == 1) s = zsrc[c];
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             for (int r = 0; r < g.px.nranks; ++r) s += p2p_load_slot(p2p_slot(mine, par, r, g.px.nranks, g.px.cap) + c);
             ztl[c] = s;
         }
+        p2p_stat_end(g.px, tid, ts0);
         for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
     } else if (g.do_a) {
         for (int c = tid; c < mz; c += FT) {

@@ -27,7 +27,7 @@ SYMBOLS = (
     "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
     "jch_predict", "jch_loopback_group_create", "jch_loopback_group_destroy", "jch_ctx_comm_init_loopback",
     "jch_ctx_p2p_export", "jch_ctx_p2p_import", "jch_ctx_p2p_enable", "jch_plskern_fit_scaled", "jch_col_stats",
-    "jch_ctx_get_counter",
+    "jch_ctx_get_counter", "jch_ctx_allreduce_probe",
 )
 
 
@@ -45,7 +45,12 @@ class PlsDesc(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("fit_ms", C.c_double), ("prologue_ms", C.c_double), ("sweep_ms", C.c_double),
                 ("smallstate_ms", C.c_double), ("sweep_launches", C.c_int32), ("nlv", C.c_int32),
-                ("sweep_bytes", C.c_double)]
+                ("sweep_bytes", C.c_double), ("collective_ms", C.c_double), ("prologue_collective_ms", C.c_double),
+                ("collective_wait_ms", C.c_double), ("collective_calls", C.c_int32), ("collective_transport", C.c_int32)]
+
+
+TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_INBOX, TRANSPORT_INBOX_FUSED, TRANSPORT_LOOPBACK = 0, 1, 2, 3, 4
+TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "inbox kernel", 3: "inbox fused into the small-state kernel", 4: "loopback (test harness)"}
 
 
 _lib = None
@@ -94,6 +99,7 @@ def load():
     L.jch_ctx_set_profiling.argtypes = [vp, i32]
     L.jch_ctx_get_profile.argtypes = [vp, C.POINTER(Profile)]
     L.jch_ctx_get_counter.argtypes = [vp, i32, C.POINTER(i64)]
+    L.jch_ctx_allreduce_probe.argtypes = [vp, i32, dp, i64, i32, C.POINTER(C.c_double)]
     for name in SYMBOLS:
         if name != "jch_last_error":
             getattr(L, name).restype = i32
@@ -173,6 +179,15 @@ class Context:
         v = C.c_int64(0)
         self.check(load().jch_ctx_get_counter(self._h, which, C.byref(v)))
         return int(v.value)
+
+    def allreduce_probe(self, vec, transport: int = TRANSPORT_NONE, iters: int = 20):
+        """Collective diagnostic (include/jchemo_hip.h jch_ctx_allreduce_probe): returns (sum over ranks of `vec`, average
+        microseconds per all-reduce through `transport`)."""
+        import numpy as np
+        v = np.ascontiguousarray(np.asarray(vec, dtype=np.float64)).copy()
+        us = C.c_double(0.0)
+        self.check(load().jch_ctx_allreduce_probe(self._h, transport, v.ctypes.data, v.size, iters, C.byref(us)))
+        return v, float(us.value)
 
     def profile(self) -> Profile:
         pr = Profile()

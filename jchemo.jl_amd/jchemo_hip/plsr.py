@@ -585,6 +585,8 @@ def query_shard(m: int, rank: int, world: int):
 def _merge_lwplsr_parts(parts) -> "LwplsrPred":
     """Re-assemble the per-replica results (in rank order) into the result of the unsplit call."""
     parts = [p_ for p_ in parts if p_ is not None]
+    if not parts:    # m = 0: every replica's slice was empty
+        return LwplsrPred(np.empty((0, 0)), np.empty((0, 0), dtype=np.int32), np.empty((0, 0)), np.empty((0, 0)))
     single = not isinstance(parts[0].pred, list)
     if single:
         pred = np.concatenate([p_.pred for p_ in parts], axis=0)
@@ -603,6 +605,8 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, r
     every rank, gathered in rank order with `gather` (default: torch.distributed.all_gather_object on the default
     process group; any callable part -> list of parts will do, e.g. an MPI allgather)."""
     if world is not None and world > 1:
+        if rank is None:
+            raise ValueError("lwplsr predict: `world` > 1 needs this process' `rank`")
         X = ensure_mat(X)
         lo, hi = query_shard(X.shape[0], int(rank), int(world))
         part = None

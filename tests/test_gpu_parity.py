@@ -273,6 +273,32 @@ def test_lwplsr_constant_neighbourhood(J, ctx):
     assert np.allclose(pred, ref["pred"][:, 0, :], rtol=1e-8, atol=1e-10)
 
 
+def test_lwplsr_nan_query_row(J, ctx):
+    """A missing value in ONE query row: its scores, hence all its distances, are NaN and no training row ever beats the
+    bar.  The reference's arithmetic gives that query NaN predictions (predict on a NaN row) and leaves the others alone;
+    the library must do the same and must not gather from the sentinel index (GPU memory fault)."""
+    n, p, m = 3000, 40, 9
+    X = CO.fill_uniform(20250112, n, p)
+    Xq = CO.fill_uniform(20250115, m, p)
+    y = X[:, :4] @ np.array([1.0, -2.0, 0.5, 3.0]) + 0.05 * CO.fill_uniform(20250113, n, 1)[:, 0]
+    kw = dict(nlvdis=6, metric="mahal", h=1.0, k=60, nlv=4)
+    fm = J.lwplsr(X, y, ctx=ctx, **kw)
+    good = J.predict(fm, Xq, nlv=range(0, 5), ctx=ctx)
+    Xbad = Xq.copy(); Xbad[4, 7] = np.nan
+    res = J.predict(fm, Xbad, nlv=range(0, 5), ctx=ctx)
+    assert res.listnn.min() >= 0 and res.listnn.max() < n            # no sentinel reaches the caller
+    assert np.all(np.isnan(res.listd[4]))
+    keep = np.arange(m) != 4
+    for a in range(5):
+        assert np.array_equal(res.pred[a][keep], good.pred[a][keep])    # the other queries: bit-identical
+        if a > 0:
+            assert np.all(np.isnan(res.pred[a][4]))
+    assert np.array_equal(res.listnn[keep], good.listnn[keep])
+    # an all-NaN query block and a NaN among the TRAINING scores' rows must not fault either
+    res2 = J.predict(fm, np.full((3, p), np.nan), nlv=2, ctx=ctx)
+    assert res2.listnn.min() >= 0 and res2.listnn.max() < n
+
+
 def test_full_size_cfg2_vs_oracle(J):
     """BASELINE.json configs[1] at FULL size (n = 1e6, p = 500, q = 10, nlv = 25, Float64, device-resident): the
     north-star parity statement itself — sign-aligned T, P, C within 1e-6 relative Frobenius of the CPU oracle on
