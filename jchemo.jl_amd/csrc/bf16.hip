@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "jch_internal.h"
 
@@ -385,6 +386,183 @@ __global__ __launch_bounds__(256) void k_reduce_kpart_b(const double *__restrict
     double s = 0.0;
     for (int b = 0; b < nbx; ++b) s += Kpart[(size_t)b * stride + e];
     K[e] = s;
+}
+
+// ---------------------------------------------------------------- K2pb (round 3): ROW-PANEL prologue for bf16 storage
+// The recipe of the f64 k_center_xty_panel (prologue.hip) re-derived for 2-byte elements, where two things change:
+//   * a whole TH-row x 512-column tile of raw bf16 fits in LDS (64 x 508 x 2 B = 65 KB), so the row-major copy leaves as
+//     COMPLETE rows: the rows of a tile are consecutive in the copy, i.e. one tile = one contiguous 63 KB region written
+//     with 16-B stores — no 128-B row pieces straddling two lines any more (the tile kernel's stores were 1.16x the
+//     algorithmic bytes: profiles/r02_pmc_bf16_traffic.txt);
+//   * the MFMA A-operand needs no LDS at all: lane l loads 8 consecutive rows (16 B) of column 16 wv + (l & 15), rows
+//     32 h + 8 (l >> 4) + e, and the product step (h, e) takes element e of load h as A[m = l & 15][k = l >> 4]; the B operand
+//     d .* yc is built ONCE per row tile in registers with the same row mapping (k = l >> 4 -> row 32 h + 8 (l >> 4) + e).
+//     A wave multiplies exactly the 16 columns it loaded, so nothing but the final transposition goes through LDS and
+//     the only block barriers are the two around the row-major store of a tile.
+// One block walks the row tiles b, b + G, b + 2G, ... (interleaved, as in the f64 panel); all loads of the NEXT tile (the
+// X pieces one by one as their registers are consumed, the Y / weight vectors first) are in flight while the current one
+// is converted, multiplied and stored.  Handles FULL tiles only (rows [0, nfull), nfull % TH == 0); the ragged tail
+// goes to k_center_xty_bf16_v8.  q <= 16, 16-B aligned columns / weights.
+typedef unsigned long long v2u64b __attribute__((ext_vector_type(2)));
+// SKIP (measurement only, results then wrong by design): 1 = no products, 2 = no LDS tile / row-major stores
+template <int NT, int NH, bool SCAL, int SKIP>
+__global__ __launch_bounds__(256, NH <= 2 ? 2 : 1) void k_center_xty_bf16_panel(
+    const bf16_t *__restrict__ Xc, int64_t ldx, const bf16_t *__restrict__ Yc, int64_t ldy, const double *__restrict__ d, int64_t nfull,
+    int p, int q, const double *__restrict__ mom, const double *__restrict__ scl, bf16_t *__restrict__ Xr, int ldr,
+    double *__restrict__ Yr, double *__restrict__ Kpart, int kp_rows, int ones_col)
+{
+    constexpr int TH = 32 * NH;
+    constexpr int NB = TH / 16;                                 // B entries built per thread and row tile
+    // LDS row pitch in elements, a compile-time constant (row offsets become instruction immediates): 512 + 4 -> pitch / 2 == 2
+    // (mod 4) words: the four row groups of a wave's 2-byte column stores fall into four different 16-word bank windows, and
+    // rows stay 8-B aligned for the b64 reads of the store phase.  Columns [wcols, wcols + 4) of a row are a dump area.
+    constexpr int pitch = 516;
+    extern __shared__ __attribute__((aligned(16))) double bp_lds[];
+    double *Bs = bp_lds;                                        // [8 NH][64]: B operand of the tile, one 64-lane row per product step
+    double *cm_s = Bs + 8 * NH * 64;                            // [512] column shifts of this column group
+    double *cs_s = cm_s + 512;                                  // [512] column divisors (SCAL only)
+    bf16_t *xt = reinterpret_cast<bf16_t *>(SCAL ? cs_s + 512 : cs_s);   // [TH][pitch] raw tile, row-major
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, cidx = lane & 15;
+    const int cg0 = blockIdx.y * 512;
+    const int wcols = min(ldr - cg0, 512);                      // columns of this group in the copy (multiple of 8)
+    const int64_t istep = (int64_t)gridDim.x * TH;
+    for (int c = tid; c < 512; c += 256) {
+        const int j = cg0 + c;
+        cm_s[c] = j < p ? mom[j] : 0.0;
+        if (SCAL) cs_s[c] = j < p ? scl[j] : 1.0;
+    }
+    // ---- B operand d .* yc (and the weights in the ones column), built cooperatively once per row tile: thread -> y column
+    //      tid & 15, rows (tid >> 4) + 16 k; lands in Bs in the order the product steps read it (step (h, e), lane 16 g + n
+    //      <-> row 32 h + 8 g + e, y column n); the same threads store the centred Y rows (Yr, 512 contiguous bytes a wave)
+    const int ycol = tid & 15, yc_ = min(ycol, q - 1);
+    const double ym = ycol < q ? mom[p + ycol] : 0.0;
+    const double ysd = (SCAL && ycol < q) ? scl[p + ycol] : 1.0;
+    bf16_t yraw[NB];
+    double draw[NB];
+    auto issue_b = [&](int64_t i0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const size_t row = (size_t)(i0 + (tid >> 4) + 16 * k);
+            yraw[k] = Yc[row + (size_t)yc_ * (size_t)ldy];
+            draw[k] = d[row];
+        }
+    };
+    auto build_b = [&](int64_t i0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int row = (tid >> 4) + 16 * k;
+            double yv = 0.0;
+            if (ycol < q) {
+                yv = (double)bf2f(yraw[k]) - ym;
+                if (SCAL) yv /= ysd;
+            }
+            if (blockIdx.y == 0) Yr[(size_t)(i0 + row) * 16 + ycol] = yv;
+            // raw mode: the pad column `ones_col` carries the weights -> that column of X'D[Yc | 1] = sum_i d_i (x_i - pivot)
+            Bs[(8 * (row >> 5) + (row & 7)) * 64 + 16 * ((row >> 3) & 3) + ycol] = ycol == ones_col ? draw[k] : draw[k] * yv;
+        }
+    };
+    v4f64 acc[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+    // X loads in flight: a ring of RING 64-column pieces (piece ct lives in slot ct % RING; when it has been consumed the slot
+    // receives piece ct + RING — of the same tile, or of the block's next tile): 4 x 8 KB per block ahead of the arithmetic
+    constexpr int RING = NT < 4 ? NT : 4;
+    v4u32 R[RING][NH];
+    const int jlane = cg0 + 16 * wv + cidx;
+    auto issue_piece = [&](int64_t i0, int ct) {                // (columns past p: clamped into the matrix, masked when consumed)
+        const size_t coff = (size_t)min(jlane + 64 * ct, p - 1) * (size_t)ldx;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            R[ct % RING][h] = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(Xc + (size_t)(i0 + 32 * h + 8 * g) + coff));
+    };
+    int64_t i0 = (int64_t)blockIdx.x * TH;
+    if (i0 < nfull) {
+        issue_b(i0);
+#pragma unroll
+        for (int ct = 0; ct < RING; ++ct) issue_piece(i0, ct);
+        build_b(i0);
+    }
+    __syncthreads();   // cm_s / cs_s / Bs
+    auto tile = [&](auto has_next, int64_t i0) {
+        if (decltype(has_next)::value) issue_b(i0 + istep);     // (consumed after the products of this tile)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            // straight-line code, no branch per element (a basic block per product kept the scheduler from overlapping the
+            // conversions with the matrix pipe): dead columns (>= p: pad columns of the copy, clamped loads of a short last
+            // piece) are masked to +0 — their shift is 0, their divisor 1 —, lanes past the group's width store into the
+            // dump columns of the LDS row
+            const int cc = 64 * ct + 16 * wv + cidx;             // column within the group
+            const unsigned lmask = cg0 + cc < p ? 0xffffffffu : 0u;
+            const double cm = cm_s[cc & 511];
+            const double cs = SCAL ? cs_s[cc & 511] : 1.0;
+            bf16_t *xw = xt + 8 * g * pitch + (cc < wcols ? cc : wcols + (cc & 3));
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const unsigned w4[4] = {R[ct % RING][h].x & lmask, R[ct % RING][h].y & lmask, R[ct % RING][h].z & lmask, R[ct % RING][h].w & lmask};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned w = w4[e >> 1];
+                    if (!(SKIP & 2)) xw[(32 * h + e) * pitch] = (bf16_t)((e & 1) ? (w >> 16) : w);
+                    double a = (double)__uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16)) - cm;
+                    if (SCAL) a /= cs;
+                    if (!(SKIP & 1)) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(8 * h + e) * 64 + lane], acc[ct], 0, 0, 0);
+                }
+            }
+            if (ct + RING < NT) issue_piece(i0, ct + RING);                                      // (folded: the loop is unrolled)
+            else if (decltype(has_next)::value) issue_piece(i0 + istep, ct + RING - NT);
+        }
+        __syncthreads();   // tile complete in LDS; every wave is done reading Bs
+        if (decltype(has_next)::value) build_b(i0 + istep);
+        // ---- the tile leaves as complete rows: wave wv stores rows wv, wv + 4, ...; 16 B per lane
+        if (!(SKIP & 2)) {
+            const int c16n = wcols >> 3;
+#pragma unroll 4
+            for (int row = wv; row < TH; row += 4) {
+                for (int c16 = lane; c16 < c16n; c16 += 64) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xt + row * pitch + 8 * c16);
+                    const v2u64b v = {src[0], src[1]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<v2u64b *>(Xr + (size_t)(i0 + row) * (size_t)ldr + cg0 + 8 * c16));
+                }
+            }
+        }
+        __syncthreads();   // the tile may be overwritten; Bs of the next tile is published
+    };
+    for (; i0 + istep < nfull; i0 += istep) tile(std::true_type{}, i0);
+    if (i0 < nfull) tile(std::false_type{}, i0);
+    // D[m][n]: n = lane & 15 (y column), m = (lane >> 4) + 4 reg (x column within the wave's 16)
+    double *kp = Kpart + ((size_t)blockIdx.x * kp_rows) * 16;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int jj = 64 * ct + 16 * wv + g + 4 * reg;
+            if (jj < 512 && cg0 + jj < kp_rows) kp[(size_t)(cg0 + jj) * 16 + cidx] = acc[ct][reg];
+        }
+    }
+}
+
+// fixed-order sum of the per-block XtY partials [nbx][kp_rows][16] (several hundred slots): 4 groups of blocks per entry with
+// 4 independent chains each, combined in group order (same scheme as k_reduce_kpart_wide, prologue.hip)
+__global__ __launch_bounds__(256) void k_reduce_kpart_bw(const double *__restrict__ Kpart, int nbx, int kp_rows, int p, int qpad,
+                                                         double *__restrict__ K)
+{
+    __shared__ double sc[4][64];
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const size_t stride = (size_t)kp_rows * qpad;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (e < p * qpad) {
+        int b = g;
+        for (; b + 12 < nbx; b += 16) {
+            s0 += Kpart[(size_t)b * stride + e]; s1 += Kpart[(size_t)(b + 4) * stride + e];
+            s2 += Kpart[(size_t)(b + 8) * stride + e]; s3 += Kpart[(size_t)(b + 12) * stride + e];
+        }
+        for (; b < nbx; b += 4) s0 += Kpart[(size_t)b * stride + e];
+    }
+    sc[g][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && e < p * qpad) K[e] = (sc[0][el] + sc[1][el]) + (sc[2][el] + sc[3][el]);
 }
 
 // Sum R per-lane partials s[0..R) over the 64 lanes of a wave and return all R totals in every lane.
@@ -859,6 +1037,54 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         double *Kpart = (double *)ctx->kpart.ptr;
         dim3 grid(nbx, ptiles, ygroups);
         const bool v8 = ldx % 8 == 0 && ((uintptr_t)Xc) % 16 == 0 && !getenv("JCH_BF16_SCALAR_PROLOGUE");
+        // row-panel kernel (round 3, default): q <= 16, 16-B aligned X / Y columns and weights, at least one full row tile
+        // (measurement knobs, read on every call so that one process can compare the variants)
+        const char *e_pn = getenv("JCH_BF16_K2_PANEL"), *e_nh = getenv("JCH_BF16_K2_NH"), *e_pb = getenv("JCH_BF16_K2_PBPC");
+        const int k2panel = e_pn ? atoi(e_pn) : 1, k2nh = e_nh ? atoi(e_nh) : 2, k2pbpc = e_pb ? atoi(e_pb) : 0;
+        const int NHv = k2nh == 4 ? 4 : 2, THv = 32 * NHv;
+        const int64_t nfull = (n / THv) * THv;
+        const bool panel = k2panel && v8 && qpad == 16 && ldy % 8 == 0 && ((uintptr_t)Yc) % 16 == 0 && ((uintptr_t)dn) % 16 == 0 && nfull > 0;
+        if (panel) {
+            const int ncg = (ldr_b + 511) / 512;                       // 512-column groups (blockIdx.y)
+            const int wmax = std::min(ldr_b, 512), ntile = (wmax + 63) / 64;
+            const int NTv = ntile <= 1 ? 1 : (ntile <= 2 ? 2 : (ntile <= 4 ? 4 : 8));
+            const int bpc = k2pbpc > 0 ? k2pbpc : (NHv == 2 ? 2 : 1);
+            int G = std::max(1, ctx->cus * bpc / ncg);
+            G = (int)std::min<int64_t>(G, nfull / THv);
+            const int kpr = ncg * 512;
+            const bool tail = nfull < n;
+            JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)(G + 1) * kpr * 16));
+            Kpart = (double *)ctx->kpart.ptr;
+            const size_t lds = sizeof(double) * (8 * NHv * 64 + (d.scal ? 1024 : 512)) + sizeof(bf16_t) * (size_t)THv * 516 + 16;
+            const double *momp = raw_b ? s.scl : s.mom;
+            const int onesc = raw_b ? q : -1;
+#define JCH_K2PB_S(NT, NH, SC, SK) do { \
+                static jch_per_device_once once_; \
+                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_center_xty_bf16_panel<NT, NH, SC, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
+                hipLaunchKernelGGL((k_center_xty_bf16_panel<NT, NH, SC, SK>), dim3(G, ncg), dim3(256), lds, ctx->stream, Xc, ldx, Yc, ldy, dn, nfull, p, q, momp, s.scl, \
+                                   Xr, ldr_b, Yr, Kpart, kpr, onesc); } while (0)
+#define JCH_K2PB(NT, NH, SC) JCH_K2PB_S(NT, NH, SC, 0)
+#define JCH_K2PB_NT(NH, SC) do { if (NTv == 1) JCH_K2PB(1, NH, SC); else if (NTv == 2) JCH_K2PB(2, NH, SC); else if (NTv == 4) JCH_K2PB(4, NH, SC); else JCH_K2PB(8, NH, SC); } while (0)
+            if (NHv == 2 && NTv == 8 && !d.scal && (k2skip & 3)) {   // measurement variants of the headline instantiation
+                if ((k2skip & 3) == 1) JCH_K2PB_S(8, 2, false, 1); else if ((k2skip & 3) == 2) JCH_K2PB_S(8, 2, false, 2); else JCH_K2PB_S(8, 2, false, 3);
+            } else
+            if (NHv == 2) { if (d.scal) JCH_K2PB_NT(2, true); else JCH_K2PB_NT(2, false); }
+            else { if (d.scal) JCH_K2PB_NT(4, true); else JCH_K2PB_NT(4, false); }
+#undef JCH_K2PB_NT
+#undef JCH_K2PB
+#undef JCH_K2PB_S
+            JCH_HIP(ctx, hipGetLastError());
+            if (tail) {   // the last n % TH rows: the tile kernel on that row range, its partial in slot G
+                const int64_t nt = n - nfull;
+                dim3 tgrid(1, ptiles, 1);
+                double *kslot = Kpart + (size_t)G * kpr * 16;
+                if (d.scal) hipLaunchKernelGGL(k_center_xty_bf16_v8<true>, tgrid, dim3(256), 0, ctx->stream, Xc + nfull, ldx, Yc + nfull, ldy, dn + nfull, nt, p, q,
+                                               s.mom, s.scl, Xr + (size_t)nfull * ldr_b, ldr_b, Yr + (size_t)nfull * qpad, qpad, kslot, kpr, -1, k2skip);
+                else hipLaunchKernelGGL(k_center_xty_bf16_v8<false>, tgrid, dim3(256), 0, ctx->stream, Xc + nfull, ldx, Yc + nfull, ldy, dn + nfull, nt, p, q,
+                                        momp, s.scl, Xr + (size_t)nfull * ldr_b, ldr_b, Yr + (size_t)nfull * qpad, qpad, kslot, kpr, onesc, k2skip);
+            }
+            hipLaunchKernelGGL(k_reduce_kpart_bw, dim3((p * qpad + 63) / 64), dim3(256), 0, ctx->stream, Kpart, G + (tail ? 1 : 0), kpr, p, qpad, s.K);
+        } else
         if (v8 && d.scal) hipLaunchKernelGGL(k_center_xty_bf16_v8<true>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
                                              s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows, -1, k2skip);
         else if (v8) hipLaunchKernelGGL(k_center_xty_bf16_v8<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q,
@@ -867,7 +1093,7 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
                                        s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
         else hipLaunchKernelGGL(k_center_xty_bf16<false>, grid, dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom,
                                 s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
-        hipLaunchKernelGGL(k_reduce_kpart_b, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad, s.K);
+        if (!panel) hipLaunchKernelGGL(k_reduce_kpart_b, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad, s.K);
         JCH_TRY(jch_allreduce_f64(ctx, s.K, (size_t)p * qpad));
         if (raw_b) {   // means = pivot + K[:, q]; Y means next to them; divisors = 1
             hipLaunchKernelGGL(k_extract_means_b, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, s.K, qpad, p, q, s.scl, s.mom);

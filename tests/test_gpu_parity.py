@@ -1091,3 +1091,49 @@ def test_raw_mode_falls_back_to_centred_copy_when_the_pivot_is_poor(pattern, J, 
         for f in FIELDS:
             assert O.rel_fro(getattr(cen, f), getattr(raw, f) * s) < 1e-9, f
     _cmp(O.plskern(X, Y, nlv=nlv), raw, tol=1e-8)
+
+
+@pytest.mark.parametrize("shape", [(6400, 500, 10, 6, False), (6477, 504, 15, 5, False), (2048 + 9, 40, 16, 4, False), (5000, 130, 3, 5, True),
+                                  (3333, 1000, 2, 4, False), (64, 24, 1, 3, False), (4160, 777, 7, 4, True)])
+@pytest.mark.parametrize("nh", [2, 4])
+def test_bf16_row_panel_prologue_matches_tile_kernel(shape, nh, J):
+    """Round 3: the row-panel bf16 prologue (k_center_xty_bf16_panel: complete rows out of an LDS tile, MFMA operands straight
+    from the load registers) against the round-1 tile kernel on the same device data: the fp64 statistics, X'DY (seen through
+    the first weight vector) and the raw row-major copy (seen through the whole fit) must agree; also vs the oracle on the
+    rounded inputs.  Shapes: full tiles only / ragged tail / one piece (NT = 1) / q = 16 (no spare ones column) / scal /
+    two 512-column groups / n == one tile / odd piece count."""
+    import os
+    import torch
+    n, p, q, nlv, scal = shape
+    ld = (n + 7) // 8 * 8
+    X = CO.fill_uniform(20250112, n, p); Y = CO.fill_uniform(20250113, n, q)
+    Xb = J.colmajor_empty(ld, p, dtype=torch.bfloat16)[:n]; Xb.copy_(torch.from_numpy(X))
+    Yb = J.colmajor_empty(ld, q, dtype=torch.bfloat16)[:n]; Yb.copy_(torch.from_numpy(Y))
+    w = 0.25 + O.splitmix64_uniform(7, 0, n) if scal else None
+    tctx = J.Context(0, stream="torch")
+    keep = {k_: os.environ.get(k_) for k_ in ("JCH_BF16_K2_PANEL", "JCH_BF16_K2_NH")}
+    try:
+        os.environ["JCH_BF16_K2_PANEL"] = "0"
+        old = J.plskern(Xb, Yb, w, nlv=nlv, scal=scal, ctx=tctx)
+        os.environ["JCH_BF16_K2_PANEL"] = "1"; os.environ["JCH_BF16_K2_NH"] = str(nh)
+        new = J.plskern(Xb, Yb, w, nlv=nlv, scal=scal, ctx=tctx)
+    finally:
+        for k_, v_ in keep.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
+    for f in ("xmeans", "ymeans", "xscales", "yscales"):
+        assert O.rel_fro(getattr(old, f), getattr(new, f)) < 1e-13, f
+    s = O.sign_align(old.W, new.W)
+    assert O.rel_fro(old.W[:, 0], new.W[:, 0] * s[0]) < 1e-11                    # w_1 is a function of X'DY alone
+    for f in ("P", "C", "W", "R"):
+        assert O.rel_fro(getattr(old, f), getattr(new, f) * s) < 1e-5, f          # (fp32 sweeps amplify 1e-16 differences of K)
+    assert O.rel_fro(old.T.cpu().numpy(), new.T.cpu().numpy() * s) < 1e-5
+    ref = CO.plskern(Xb.to(torch.float64).cpu().numpy(), Yb.to(torch.float64).cpu().numpy(), w, nlv=nlv, scal=scal)
+    s = O.sign_align(ref.W, new.W)
+    assert O.rel_fro(ref.xmeans, new.xmeans) < 1e-12
+    for f in ("P", "C", "W", "R"):
+        assert O.rel_fro(getattr(ref, f), getattr(new, f) * s) < 1e-3, f
+    assert O.rel_fro(ref.T, new.T.cpu().numpy() * s) < 1e-3
+    tctx.close()
