@@ -218,8 +218,10 @@ JCH_API int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int6
  *   k neighbours (clamped to n), h / tol: weight shape and floor; scal; nlv range nlv_lo..nlv_hi (contiguous)
  *   pred  m x le x q (le = nlv_hi - nlv_lo + 1), query-major: pred[(i*le + a)*q + y]              [HOST]
  *   ind_out (m x k, 0-based, row-major), dist_out, w_out (m x k): optional                       [HOST]
- * 1 <= q <= 16 (one workgroup per query holds the k x p slab, the p x q kernel matrix and its q x q eigen-solver; the
- * call fails with JCH_EINVAL when k, p and q together exceed the 150 KB of LDS that workgroup may use);
+ * 1 <= q <= 16.  Two local-fit kernels: for k <= 208, q <= 8 and wide rows the fit runs in NEIGHBOUR space — the k x k Gram
+ * matrix of the gathered rows, built on the matrix cores in one pass and held in registers (lwplsr_kspace.hip; same T, C
+ * and predictions up to rounding) —, otherwise one workgroup per query sweeps the k x p slab once per LV (that kernel
+ * fails with JCH_EINVAL when k, p and q together exceed the 150 KB of LDS the workgroup may use);
  * the constant-y shortcut of src/locwlv.jl:25-28 applies to q == 1 only, as in the reference.
  */
 JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
@@ -227,6 +229,22 @@ JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtra
                                    const double *Zq, int64_t ldzq, int64_t dd, const double *Xq, int64_t m, int64_t ldxq,
                                    int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi,
                                    double *pred, int32_t *ind_out, double *dist_out, double *w_out);
+
+/* ---- persistent model state of kNN-LWPLSR: the reference's `Lwplsr` object (src/lwplsr.jl:1-12) is fitted once
+ * (`lwplsr`, :114-131) and predicted from many times (`predict`, :134-166).  jch_lwplsr_prepare keeps the model-constant
+ * device data — the row-major copy of Xtrain the neighbour gathers read, Ytrain, the (whitened) training scores Ztrain — in
+ * a handle; jch_lwplsr_predict_prepared is jch_lwplsr_predict without those three arguments and without their per-call
+ * copies; jch_lwplsr_release frees the handle.  The handle belongs to the ctx's device; the inputs of prepare are not
+ * referenced after it returns.  Same shape limits and errors as jch_lwplsr_predict. */
+typedef struct jch_lwplsr_model jch_lwplsr_model;
+JCH_API int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
+                                   const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt, int64_t dd,
+                                   jch_lwplsr_model **model_out);
+JCH_API int32_t jch_lwplsr_predict_prepared(jch_ctx *ctx, const jch_lwplsr_model *model, int32_t loc, const double *Zq, int64_t ldzq,
+                                            const double *Xq, int64_t m, int64_t ldxq, int32_t k, double h, double tol, int32_t scal,
+                                            int32_t nlv_lo, int32_t nlv_hi, double *pred, int32_t *ind_out, double *dist_out,
+                                            double *w_out);
+JCH_API int32_t jch_lwplsr_release(jch_ctx *ctx, jch_lwplsr_model *model);
 
 /* jch_weighted_cov — S = (A - 1 mu')' D (A - 1 mu') (d x d, d <= 64), D = diag(weights / sum); weights NULL = ones:
  * `Statistics.cov(Xtrain, corrected = false)` of getknn's Mahalanobis branch (src/getknn.jl:38).  A n x d [loc];

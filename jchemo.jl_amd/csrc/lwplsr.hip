@@ -11,11 +11,13 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <new>
 #include <vector>
 
 #include "jch_internal.h"
 #include "lv_device.h"
 #include "rowsum_dev.h"
+#include "lwplsr_dev.h"
 
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
@@ -255,16 +257,8 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
     }
 }
 
-// ---------------------------------------------------------------- K8: batched local weighted plskern (q <= 8)
-struct locw_args {
-    const double *Xrm; int ldr; int p;      // row-major training X (uncentred)
-    const double *Y; int64_t ldy; int q;    // training Y (column-major n x q)
-    const double *Xq; int64_t ldxq; int m;  // queries, column-major m x p
-    const int *ind; const double *w; int k; // neighbours / weights [m][k]
-    int scal, nlv_lo, nlv_hi;
-    double *scratch; size_t slab;           // per-block slab: Xg [k][ldr], P [nlv][ldr], R [nlv][ldr]
-    double *pred;                           // [m][le][q], le = nlv_hi - nlv_lo + 1
-};
+// ---------------------------------------------------------------- K8: batched local weighted plskern (q <= 16)
+// (struct locw_args: lwplsr_dev.h)
 
 // block sum of NV values held one per thread-array slot: wave shuffles, then the 4 wave partials through LDS.
 // out[v] valid in every thread after the call.  scratch: >= 4 * NV doubles.
@@ -701,56 +695,38 @@ static int32_t launch_locw(jch_ctx *ctx, locw_args &g)
 }
 
 // ---------------------------------------------------------------- C ABI
-extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
-                                      const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt,
-                                      const double *Zq, int64_t ldzq, int64_t dd, const double *Xq, int64_t m, int64_t ldxq,
-                                      int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi,
-                                      double *pred, int32_t *ind_out, double *dist_out, double *w_out)
+// The model-constant part of a prediction: what `lwplsr(X, Y; ...)` holds (src/lwplsr.jl:1-12, 114-131) in the form the
+// kernels want it — the row-major copy of Xtrain for the 4 KB-contiguous neighbour gathers, device copies of Ytrain and of
+// the (whitened) training scores.  Built once by jch_lwplsr_prepare and reused by every jch_lwplsr_predict_prepared call;
+// the one-shot jch_lwplsr_predict builds the same thing in the ctx workspace on every call.
+struct jch_lwplsr_model {
+    int device = 0;
+    int64_t n = 0, p = 0, q = 0, dd = 0;
+    int ldr = 0;
+    double *Xrm = nullptr;   // [n][ldr]
+    double *Y = nullptr;     // n x q, column-major, ld n
+    double *Zt = nullptr;    // n x dd, column-major, ld n
+};
+
+static void lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t n, int p, double *Xrm, int ldr)
 {
-    if (!ctx) return JCH_EINVAL;
-    if (!Xtrain || !Ytrain || !Ztrain || !Zq || !Xq || !pred || n < 1 || p < 1 || m < 1 || dd < 1 || k < 1 || nlv_lo < 0 ||
-        nlv_hi < nlv_lo || ldx < n || ldy < n || ldzt < n || ldzq < m || ldxq < m)
-        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad arguments");
-    if (q < 1 || q > 16) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: the batched local-PLS kernel handles 1 <= q <= 16 (got q=%lld)", (long long)q);
-    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad loc");
-    if (p > JCH_SWEEP_MAXP) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: p > %d not supported", JCH_SWEEP_MAXP);
-    if (k > n) k = (int32_t)n;                                    // src/getknn.jl:33
-    if (k > KNN_CAP - 256) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k > %d not supported", KNN_CAP - 256);
-    if (nlv_hi > 48) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: nlv > 48 not supported");
-    JCH_HIP(ctx, hipSetDevice(ctx->device));
-    const int ldr = ((int)p + 1) & ~1, le = nlv_hi - nlv_lo + 1;
-    // ---- stage host inputs
-    const double *dX = Xtrain, *dY = Ytrain, *dZt = Ztrain, *dZq = Zq, *dXq = Xq;
-    int64_t ldxd = ldx, ldyd = ldy, ldztd = ldzt, ldzqd = ldzq, ldxqd = ldxq;
-    if (loc == JCH_LOC_HOST) {
-        const size_t need = sizeof(double) * ((size_t)n * p + (size_t)n * q + (size_t)n * dd + (size_t)m * dd + (size_t)m * p);
-        JCH_TRY(jch_reserve(ctx, ctx->xq, need));
-        double *b = (double *)ctx->xq.ptr;
-        auto up = [&](const double *src, int64_t rows, int64_t cols, int64_t ld, const double *&dst, int64_t &ldd) -> int32_t {
-            if (ld == rows) JCH_HIP(ctx, hipMemcpyAsync(b, src, sizeof(double) * (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream));
-            else JCH_HIP(ctx, hipMemcpy2DAsync(b, sizeof(double) * rows, src, sizeof(double) * ld, sizeof(double) * rows, cols, hipMemcpyHostToDevice, ctx->stream));
-            dst = b; ldd = rows; b += (size_t)rows * cols;
-            return JCH_OK;
-        };
-        JCH_TRY(up(Xtrain, n, p, ldx, dX, ldxd)); JCH_TRY(up(Ytrain, n, q, ldy, dY, ldyd)); JCH_TRY(up(Ztrain, n, dd, ldzt, dZt, ldztd));
-        JCH_TRY(up(Zq, m, dd, ldzq, dZq, ldzqd)); JCH_TRY(up(Xq, m, p, ldxq, dXq, ldxqd));
-    }
-    // ---- workspace: row-major X, neighbour lists, predictions
-    JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
+    const int ptiles = (ldr + 63) / 64;
+    const int64_t nchunks = (n + 63) / 64;
+    int nbx = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, (ctx->cus * 4 + ptiles - 1) / ptiles));
+    hipLaunchKernelGGL(k_to_rowmajor, dim3(nbx, ptiles), dim3(256), 0, ctx->stream, dX, ldxd, n, p, Xrm, ldr);
+}
+
+// kNN + weights + batched local fits on device-resident pieces; results to the host.  Xrm / dY / dZt: the model; dZq, dXq: the queries.
+static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64_t p, const double *dY, int64_t q, int64_t ldyd,
+                      const double *dZt, int64_t ldztd, const double *dZq, int64_t ldzqd, int64_t dd, const double *dXq, int64_t m,
+                      int64_t ldxqd, int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi, double *pred,
+                      int32_t *ind_out, double *dist_out, double *w_out, hipEvent_t ev0)
+{
+    const int le = nlv_hi - nlv_lo + 1;
     JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * ((size_t)m * k * 2 + (size_t)m * le * q) + sizeof(int) * (size_t)m * k + 256));
-    double *Xrm = (double *)ctx->xr.ptr;
     double *ddist = (double *)ctx->gemm_out.ptr, *dw = ddist + (size_t)m * k, *dpred = dw + (size_t)m * k;
     int *dind = (int *)(dpred + (size_t)m * le * q);
-    ctx->ev_used = 0;
-    ctx->prof = jch_profile{};
-    hipEvent_t ev0 = jch_ev(ctx), ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // profiling: copy | kNN + weights | local fits
-    {
-        const int ptiles = (ldr + 63) / 64;
-        const int64_t nchunks = (n + 63) / 64;
-        int nbx = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, (ctx->cus * 4 + ptiles - 1) / ptiles));
-        hipLaunchKernelGGL(k_to_rowmajor, dim3(nbx, ptiles), dim3(256), 0, ctx->stream, dX, ldxd, n, (int)p, Xrm, ldr);
-    }
-    ev1 = jch_ev(ctx);
+    hipEvent_t ev1 = jch_ev(ctx), ev2 = nullptr, ev3 = nullptr;   // profiling: (copy) | kNN + weights | local fits
     {
         knn_args a;
         a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
@@ -776,6 +752,11 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         g.Xrm = Xrm; g.ldr = ldr; g.p = (int)p; g.Y = dY; g.ldy = ldyd; g.q = (int)q; g.Xq = dXq; g.ldxq = ldxqd; g.m = (int)m;
         g.ind = dind; g.w = dw; g.k = k; g.scal = scal; g.nlv_lo = nlv_lo; g.nlv_hi = nlv_hi; g.pred = dpred;
         g.scratch = nullptr; g.slab = 0;
+        { const char *e = getenv("JCH_LOCW_DBG"); g.dbg = e ? atoi(e) : 0; }
+        // neighbour-space kernel (lwplsr_kspace.hip: the gathered rows are read ONCE, the fit runs on their Gram matrix held in
+        // registers) when the shape fits it; the p-space kernel (one sweep of the slab per LV) otherwise
+        if (jch_locw_kspace_supported(g)) JCH_TRY(jch_launch_locw_kspace(ctx, g));
+        else
         if (ldr <= 128) JCH_TRY(launch_locw<1>(ctx, g));
         else if (ldr <= 256) JCH_TRY(launch_locw<2>(ctx, g));
         else if (ldr <= 512) JCH_TRY(launch_locw<4>(ctx, g));
@@ -792,7 +773,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     if (ctx->profiling && ev0 && ev1 && ev2 && ev3) {
         // jch_profile of a prediction call: fit_ms = device time of the three stages, prologue_ms = row-major copy + kNN +
         // weights, sweep_ms = the batched local fits (ONE launch), sweep_bytes = the gathered neighbour rows m k ldr 8
-        // (algorithmic bytes per query = k p 8), smallstate_ms = the row-major copy alone
+        // (algorithmic bytes per query = k p 8), smallstate_ms = the row-major copy alone (0 with a prepared model)
         float a = 0.f, b = 0.f, c = 0.f;
         (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2); (void)hipEventElapsedTime(&c, ev2, ev3);
         jch_profile &pr = ctx->prof;
@@ -800,6 +781,136 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         pr.sweep_launches = 1; pr.nlv = nlv_hi; pr.sweep_bytes = (double)m * k * ldr * 8.0;
     }
     return JCH_OK;
+}
+
+static int32_t lw_check(jch_ctx *ctx, const char *who, int64_t n, int64_t p, int64_t q, int64_t dd, int64_t m, int32_t &k, int32_t nlv_lo, int32_t nlv_hi)
+{
+    if (n < 1 || p < 1 || m < 1 || dd < 1 || k < 1 || nlv_lo < 0 || nlv_hi < nlv_lo) return jch_fail(ctx, JCH_EINVAL, "%s: bad arguments", who);
+    if (q < 1 || q > 16) return jch_fail(ctx, JCH_EINVAL, "%s: the batched local-PLS kernel handles 1 <= q <= 16 (got q=%lld)", who, (long long)q);
+    if (p > JCH_SWEEP_MAXP) return jch_fail(ctx, JCH_EINVAL, "%s: p > %d not supported", who, JCH_SWEEP_MAXP);
+    if (k > n) k = (int32_t)n;                                    // src/getknn.jl:33
+    if (k > KNN_CAP - 256) return jch_fail(ctx, JCH_EINVAL, "%s: k > %d not supported", who, KNN_CAP - 256);
+    if (nlv_hi > 48) return jch_fail(ctx, JCH_EINVAL, "%s: nlv > 48 not supported", who);
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
+                                      const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt,
+                                      const double *Zq, int64_t ldzq, int64_t dd, const double *Xq, int64_t m, int64_t ldxq,
+                                      int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi,
+                                      double *pred, int32_t *ind_out, double *dist_out, double *w_out)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!Xtrain || !Ytrain || !Ztrain || !Zq || !Xq || !pred || ldx < n || ldy < n || ldzt < n || ldzq < m || ldxq < m)
+        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad arguments");
+    JCH_TRY(lw_check(ctx, "jch_lwplsr_predict", n, p, q, dd, m, k, nlv_lo, nlv_hi));
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: bad loc");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const int ldr = ((int)p + 1) & ~1;
+    // ---- stage host inputs
+    const double *dX = Xtrain, *dY = Ytrain, *dZt = Ztrain, *dZq = Zq, *dXq = Xq;
+    int64_t ldxd = ldx, ldyd = ldy, ldztd = ldzt, ldzqd = ldzq, ldxqd = ldxq;
+    if (loc == JCH_LOC_HOST) {
+        const size_t need = sizeof(double) * ((size_t)n * p + (size_t)n * q + (size_t)n * dd + (size_t)m * dd + (size_t)m * p);
+        JCH_TRY(jch_reserve(ctx, ctx->xq, need));
+        double *b = (double *)ctx->xq.ptr;
+        auto up = [&](const double *src, int64_t rows, int64_t cols, int64_t ld, const double *&dst, int64_t &ldd) -> int32_t {
+            if (ld == rows) JCH_HIP(ctx, hipMemcpyAsync(b, src, sizeof(double) * (size_t)rows * cols, hipMemcpyHostToDevice, ctx->stream));
+            else JCH_HIP(ctx, hipMemcpy2DAsync(b, sizeof(double) * rows, src, sizeof(double) * ld, sizeof(double) * rows, cols, hipMemcpyHostToDevice, ctx->stream));
+            dst = b; ldd = rows; b += (size_t)rows * cols;
+            return JCH_OK;
+        };
+        JCH_TRY(up(Xtrain, n, p, ldx, dX, ldxd)); JCH_TRY(up(Ytrain, n, q, ldy, dY, ldyd)); JCH_TRY(up(Ztrain, n, dd, ldzt, dZt, ldztd));
+        JCH_TRY(up(Zq, m, dd, ldzq, dZq, ldzqd)); JCH_TRY(up(Xq, m, p, ldxq, dXq, ldxqd));
+    }
+    // ---- the model-constant piece, in the ctx workspace (rebuilt on every call: use jch_lwplsr_prepare to keep it)
+    JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
+    double *Xrm = (double *)ctx->xr.ptr;
+    ctx->ev_used = 0;
+    ctx->prof = jch_profile{};
+    hipEvent_t ev0 = jch_ev(ctx);
+    lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, Xrm, ldr);
+    return lw_run(ctx, Xrm, ldr, n, p, dY, q, ldyd, dZt, ldztd, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol, scal, nlv_lo, nlv_hi, pred,
+                  ind_out, dist_out, w_out, ev0);
+}
+
+extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
+                                      const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt, int64_t dd,
+                                      jch_lwplsr_model **model_out)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!model_out) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_prepare: model_out is NULL");
+    *model_out = nullptr;
+    if (!Xtrain || !Ytrain || !Ztrain || n < 1 || p < 1 || q < 1 || q > 16 || dd < 1 || ldx < n || ldy < n || ldzt < n || p > JCH_SWEEP_MAXP)
+        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_prepare: bad arguments (1 <= q <= 16, p <= %d)", JCH_SWEEP_MAXP);
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_prepare: bad loc");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    jch_lwplsr_model *mo = new (std::nothrow) jch_lwplsr_model();
+    if (!mo) return jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_prepare: host allocation failed");
+    mo->device = ctx->device; mo->n = n; mo->p = p; mo->q = q; mo->dd = dd; mo->ldr = ((int)p + 1) & ~1;
+    auto fail = [&](int32_t st) { (void)hipFree(mo->Xrm); (void)hipFree(mo->Y); (void)hipFree(mo->Zt); delete mo; return st; };
+    if (hipMalloc((void **)&mo->Xrm, sizeof(double) * (size_t)n * mo->ldr) != hipSuccess || hipMalloc((void **)&mo->Y, sizeof(double) * (size_t)n * q) != hipSuccess ||
+        hipMalloc((void **)&mo->Zt, sizeof(double) * (size_t)n * dd) != hipSuccess)
+        return fail(jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_prepare: device allocation failed (%lld x %lld training rows)", (long long)n, (long long)p));
+    const hipMemcpyKind kind = loc == JCH_LOC_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    auto copy2d = [&](double *dst, const double *src, int64_t cols, int64_t ld) {
+        return hipMemcpy2DAsync(dst, sizeof(double) * n, src, sizeof(double) * ld, sizeof(double) * n, cols, kind, ctx->stream);
+    };
+    if (copy2d(mo->Y, Ytrain, q, ldy) != hipSuccess || copy2d(mo->Zt, Ztrain, dd, ldzt) != hipSuccess)
+        return fail(jch_fail(ctx, JCH_EHIP, "jch_lwplsr_prepare: copy of Y / scores failed"));
+    const double *dX = Xtrain;
+    int64_t ldxd = ldx;
+    if (loc == JCH_LOC_HOST) {   // stage the column-major X once, transpose on the device
+        int32_t st = jch_reserve(ctx, ctx->xstage, sizeof(double) * (size_t)n * p);
+        if (st != JCH_OK) return fail(st);
+        if (hipMemcpy2DAsync(ctx->xstage.ptr, sizeof(double) * n, Xtrain, sizeof(double) * ldx, sizeof(double) * n, p, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return fail(jch_fail(ctx, JCH_EHIP, "jch_lwplsr_prepare: copy of X failed"));
+        dX = (const double *)ctx->xstage.ptr; ldxd = n;
+    }
+    lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, mo->Xrm, mo->ldr);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(jch_fail(ctx, JCH_EHIP, "jch_lwplsr_prepare: row-major copy failed"));
+    *model_out = mo;
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_lwplsr_release(jch_ctx *ctx, jch_lwplsr_model *model)
+{
+    if (!model) return JCH_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(model->Xrm); (void)hipFree(model->Y); (void)hipFree(model->Zt);
+    delete model;
+    return JCH_OK;
+}
+
+extern "C" int32_t jch_lwplsr_predict_prepared(jch_ctx *ctx, const jch_lwplsr_model *model, int32_t loc, const double *Zq, int64_t ldzq,
+                                               const double *Xq, int64_t m, int64_t ldxq, int32_t k, double h, double tol, int32_t scal,
+                                               int32_t nlv_lo, int32_t nlv_hi, double *pred, int32_t *ind_out, double *dist_out, double *w_out)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!model || !Zq || !Xq || !pred || ldzq < m || ldxq < m) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: bad arguments");
+    if (model->device != ctx->device) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: the model lives on device %d, the ctx on %d", model->device, ctx->device);
+    JCH_TRY(lw_check(ctx, "jch_lwplsr_predict_prepared", model->n, model->p, model->q, model->dd, m, k, nlv_lo, nlv_hi));
+    if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: bad loc");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t p = model->p, dd = model->dd;
+    const double *dZq = Zq, *dXq = Xq;
+    int64_t ldzqd = ldzq, ldxqd = ldxq;
+    if (loc == JCH_LOC_HOST) {
+        JCH_TRY(jch_reserve(ctx, ctx->xq, sizeof(double) * ((size_t)m * dd + (size_t)m * p)));
+        double *b = (double *)ctx->xq.ptr;
+        JCH_HIP(ctx, hipMemcpy2DAsync(b, sizeof(double) * m, Zq, sizeof(double) * ldzq, sizeof(double) * m, dd, hipMemcpyHostToDevice, ctx->stream));
+        JCH_HIP(ctx, hipMemcpy2DAsync(b + (size_t)m * dd, sizeof(double) * m, Xq, sizeof(double) * ldxq, sizeof(double) * m, p, hipMemcpyHostToDevice, ctx->stream));
+        dZq = b; ldzqd = m; dXq = b + (size_t)m * dd; ldxqd = m;
+    }
+    ctx->ev_used = 0;
+    ctx->prof = jch_profile{};
+    hipEvent_t ev0 = jch_ev(ctx);
+    return lw_run(ctx, model->Xrm, model->ldr, model->n, p, model->Y, model->q, model->n, model->Zt, model->n, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol,
+                  scal, nlv_lo, nlv_hi, pred, ind_out, dist_out, w_out, ev0);
 }
 
 // Weighted (uncorrected) covariance of the columns of A (n x d, d <= 64): S = (A - 1 mu')' D (A - 1 mu'), the

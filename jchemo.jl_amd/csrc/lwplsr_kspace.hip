@@ -1,0 +1,620 @@
+// K8g — batched local weighted plskern in NEIGHBOUR SPACE (round 3): the local fits of predict(::Lwplsr)
+// (src/locwlv.jl:9-48: one weighted plskern on the k neighbour rows + 1-row predictions per query, src/plskern.jl:106-178,
+// 226-238) with ONE pass over the gathered rows instead of one per latent variable.
+//
+// Every p-vector of the local fit lies in the row space of the centred (scaled) neighbour block Xc (k x p, k = 200 at cfg5,
+// p = 500): K = Xc'A with A = D Yc (k x q, deflated as A <- A - (D t) c'), w = Xc'om, r = Xc'rho, and the fit only ever
+// needs inner products of rows — the k x k Gram matrix G = Xc Xc' and g = Xc xq_c:
+//     M  = A'H               (q x q Gram of K = Xc'A;  H = G A maintained as H <- H - (G D t) c')
+//     v  = dominant eigenvector of M (q == 1: 1),  nrm = sqrt(v'M v) = ||K v||
+//     om = A v / nrm,  s = H v / nrm = Xc w                                        (src/plskern.jl:150-155)
+//     beta_j = t_j'D s / tt_j,  t = s - sum_j beta_j t_j  (= Xc r: the r-recursion of :156-161 applied to the scores)
+//     tau = g'om - sum_j beta_j tau_j  (= xq_c . r),  tt = t'D t,  c = A't / tt    (:162-166)
+//     prediction_a = prediction_{a-1} + tau c .* ysd                               (:226-238 on the one query row)
+// The rows are taken about a PIVOT — the query row itself, which sits in the middle of its neighbours — so the raw Gram matrix
+// G0 = Z Z', Z = (X[s, :] - 1 xq') / sd, carries no cancellation, and the centring is applied implicitly:
+//     u = G0 d,  mm = d'u,   G x = G0 x - u (1'x) - 1 (u'x - mm 1'x),   g = -u + mm 1        (xq - pivot = 0)
+// (numpy prototype against the oracle at cfg5-like data: predictions equal to 4e-13 at 15 LVs, q = 1 and 3, scal on / off.)
+//
+// Layout: one 256-thread workgroup per query (four waves, one per SIMD, 512 registers each).  G0 is built on the matrix cores (v_mfma_f64_16x16x4, the SAME LDS operand
+// array serves as A and as B: G0 is a SYRK) from 32-column stages of the gathered rows that are staged through LDS once and
+// shared by the four waves; its 16 x 16 tiles (upper triangle: 91 for 13 row blocks) never leave the accumulator registers —
+// every wave owns three or four whole block rows, 21 ... 24 tiles — and every later product G0 x is taken straight from
+// them (a row's tiles are accumulated first, then ONE DPP row sum per register; the transposed use of a tile goes through a
+// cross-row butterfly; five fixed-order partials per entry -> deterministic).  HBM traffic per query: the k gathered rows,
+// once (0.8 MB at cfg5; the p-space kernel streamed them 15 + 3 times: profiles/r02_pmc_lwplsr_cfg5.txt).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "jch_internal.h"
+#include "lv_device.h"
+#include "rowsum_dev.h"
+#include "lwplsr_dev.h"
+
+#define KS_NT 256        // threads per workgroup: 4 waves, ONE per SIMD (512 registers each)
+#define KS_NW 4
+#define KS_KB 13         // 16-row blocks of the Gram matrix: k <= 208 (smaller k is zero-padded)
+#define KS_KP (16 * KS_KB)
+#define KS_ND 7          // tile classes delta = J - I (mod 13) = 0 .. 6: every unordered pair of row blocks exactly once
+#define KS_EXT (KS_KB + KS_ND - 1)   // row blocks of the cyclic extension (blocks 13 .. 18 repeat blocks 0 .. 5)
+#define KS_KPX (16 * KS_EXT)
+#define KS_RS (KS_KPX + 1)   // rows of an LDS stage block (odd: the 32-B lane pairs of a row store spread over all banks)
+#define KS_TPW (4 * KS_ND)   // accumulator slots per wave: slot 4 delta + i <-> tile (I = res_delta + 4 i, J = I + delta)
+#define KS_CS 16         // columns per LDS stage
+#define KS_NR 7          // load rounds per stage: 4 waves x 8 rows per round
+#define KS_MAXNLV 48
+
+// The accumulator tiles are pinned to AccVGPRs through the operand constraint: left to itself the allocator carried them
+// through the stage loop in architectural registers and copied all 8 words in and out around every product.
+#define KS_MFMA(acc_, a_, b_) asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
+typedef double v2f64k __attribute__((ext_vector_type(2)));
+typedef double v4f64k __attribute__((ext_vector_type(4)));
+
+// Tile ownership.  The 91 tiles of the upper triangle are the pairs (I, (I + delta) mod 13), I = 0 .. 12, delta = 0 .. 6.  Class
+// delta is dealt to the waves by I: wave w owns the I with I mod 4 == (w - delta) mod 4, i.e. I = res + 4 i — 23 / 23 / 23 / 22
+// tiles, and (the point of the construction) tile coordinates that are the SAME compile-time offsets in every wave on top of
+// seven wave-dependent bases: one instruction stream for the four waves, every LDS address an immediate.  J = I + delta is
+// taken in the cyclic extension (blocks 13 .. 18 = blocks 0 .. 5), so no modulo appears in an address.
+__device__ __forceinline__ int ks_res(int wv, int delta) { return (wv - delta) & 3; }
+
+__device__ __forceinline__ double ks_rowsum16(double v)   // sum over the 16 lanes of a DPP row, result in every lane
+{
+    v += jch_dpp<0x128>(v);   // row_ror:8
+    v += jch_dpp<0x124>(v);   // row_ror:4
+    v += jch_dpp<0x122>(v);   // row_ror:2
+    v += jch_dpp<0x121>(v);   // row_ror:1
+    return v;
+}
+
+// sum over the 64 lanes without LDS traffic: DPP inside the 16-lane rows, then the four row totals through v_readlane
+__device__ __forceinline__ double ks_wave_sum(double v)
+{
+    v = ks_rowsum16(v);
+    return (jch_readlane(v, 0) + jch_readlane(v, 16)) + (jch_readlane(v, 32) + jch_readlane(v, 48));
+}
+// Sums of FOUR per-lane values over the 16 lanes of a DPP row in 5 DPP steps instead of 16 (the transposing reduction of
+// rowsum_dev.h one level deeper): on return the lane with (bit 3, bit 2) = (b, c) of its row index holds the total of r[2 c + b].
+__device__ __forceinline__ double ks_rowsum16x4(const double (&r)[4], int l15)
+{
+    const bool b3 = (l15 & 8) != 0, b2 = (l15 & 4) != 0;
+    double u = b3 ? r[1] : r[0], v = b3 ? r[0] : r[1];
+    u += jch_dpp<0x128>(v);                          // row_ror:8 == lane ^ 8: u = partial of r[b3]
+    double u2 = b3 ? r[3] : r[2], v2 = b3 ? r[2] : r[3];
+    u2 += jch_dpp<0x128>(v2);                        // partial of r[2 + b3]
+    double t = b2 ? u2 : u;
+    const double z = b2 ? u : u2;
+    t += jch_dpp<0x141>(z);                          // row_half_mirror (flips bits 0..2): partial of r[2 b2 + b3]
+    t += jch_dpp<0xB1>(t);                           // quad_perm [1,0,3,2]
+    t += jch_dpp<0x4E>(t);                           // quad_perm [2,3,0,1]
+    return t;
+}
+// Sums over the four lane ROWS (lanes l, l ^ 16, l ^ 32, l ^ 48) of four values at once (v_permlane32_swap / v_permlane16_swap):
+// on return row 0 holds the sums of c0, row 1 of c2, row 2 of c1, row 3 of c3.
+__device__ __forceinline__ double ks_colsum4(double c0, double c1, double c2, double c3)
+{
+    jch_fold32(c0, c1);
+    jch_fold32(c2, c3);
+    jch_fold16(c0, c2);
+    return c0;
+}
+
+// block sums of NV values (one partial per thread and value): in-wave sums, then the 4 wave partials through LDS in a fixed
+// order.  red: >= 4 * NV doubles.  Result valid in every thread.
+template <int NV>
+__device__ __forceinline__ void ks_block_sums(double (&v)[NV], double *red)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ks_wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wv * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i]);
+}
+
+struct ks_lds {   // offsets in doubles
+    int stage, T, ypR, ypC, dl, A, H, gv, uv, xv, sv, red, ys, vl, eig, beta, tauh, tth, idx, total;
+};
+__host__ __device__ inline ks_lds ks_layout(int Q, int nlv)
+{
+    ks_lds L;
+    int o = 0;
+    // T history and the product partials alias the stage buffers (free after the Gram phase)
+    L.stage = o; L.T = o; L.ypR = o + nlv * KS_KP; L.ypC = L.ypR + KS_NW * KS_TPW * 16;
+    int need = 2 * (KS_CS / 4) * KS_RS * 4;                // two stage buffers [4 column quads][KS_RS rows][4]
+    if (nlv * KS_KP + 2 * KS_NW * KS_TPW * 16 > need) need = nlv * KS_KP + 2 * KS_NW * KS_TPW * 16;
+    o += need;
+    L.dl = o; o += KS_KPX;                                 // (x vectors of the products carry the cyclic extension)
+    L.xv = o; o += KS_KPX;
+    L.A = o; o += KS_KP * Q;
+    L.H = o; o += KS_KP * Q;
+    L.gv = o; o += KS_KP; L.uv = o; o += KS_KP; L.sv = o; o += KS_KP;
+    L.red = o; o += 4 * (Q * (Q + 1) / 2 + Q + 2) + 16;
+    L.ys = o; o += 4 * Q;
+    L.vl = o; o += 16;
+    L.eig = o; o += 5 * Q * (Q + 2) + 2 * (Q + 2) + 8;
+    L.beta = o; o += KS_MAXNLV; L.tauh = o; o += KS_MAXNLV; L.tth = o; o += KS_MAXNLV;
+    L.idx = o; o += KS_KP / 2 + 1;
+    L.total = o;
+    return L;
+}
+
+template <int Q>
+__global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kap = lane >> 4, l15 = lane & 15;
+    const int p = g.p, ldr = g.ldr, k = g.k, q = g.q;
+    constexpr int KP = KS_KP, RS = KS_RS;
+    const ks_lds L = ks_layout(Q, g.nlv_hi);
+    double *stage = lds + L.stage, *Th = lds + L.T, *ypR = lds + L.ypR, *ypC = lds + L.ypC;
+    double *dl = lds + L.dl, *Am = lds + L.A, *Hm = lds + L.H, *gv = lds + L.gv, *uv = lds + L.uv, *xv = lds + L.xv;
+    double *sv = lds + L.sv, *red = lds + L.red, *ys = lds + L.ys, *vl = lds + L.vl;
+    double *beta = lds + L.beta, *tauh = lds + L.tauh, *tth = lds + L.tth;
+    int *idx = reinterpret_cast<int *>(lds + L.idx);
+    constexpr int lda = Q + 2;
+    double *G0m = lds + L.eig, *E0 = G0m + Q * lda, *E1 = E0 + Q * lda, *V0 = E1 + Q * lda, *V1 = V0 + Q * lda, *csl = V1 + Q * lda;
+    double *ymean = ys, *ysd = ys + Q, *prun = ys + 2 * Q, *cvec = ys + 3 * Q;
+    const int le = g.nlv_hi - g.nlv_lo + 1;
+    const int nlvloc = min(min(k, p), g.nlv_hi);
+    const int nstage = (ldr + KS_CS - 1) / KS_CS;
+    double *sgl = g.scratch + (size_t)blockIdx.x * g.slab;   // [ldr] local column stds (scal only)
+    v4f64k acc[KS_TPW];
+    int resd[KS_ND];                    // wave-dependent base row block (mod 4) of every tile class
+#pragma unroll
+    for (int dlt = 0; dlt < KS_ND; ++dlt) resd[dlt] = ks_res(wv, dlt);
+    const int c8 = lane & 7, r8 = lane >> 3;   // stage-load role: column pair 2 c8 of row 8 wv + r8 (+ 32 per round)
+
+#define KS_STAMP(i) do { if ((g.dbg & 2) && tid == 0 && blockIdx.x == 0 && qi == 0) sgl[i] = (double)wall_clock64(); } while (0)
+    for (int qi = blockIdx.x; qi < g.m; qi += gridDim.x) {
+        __syncthreads();
+        KS_STAMP(0);
+        // ---- weights (mweight), neighbour ids, Y rows, Y means / stds; A = D Yc
+        double s0 = 0.0;
+        for (int e = tid; e < k; e += KS_NT) { idx[e] = (g.dbg & 1) ? e : g.ind[(size_t)qi * k + e]; s0 += g.w[(size_t)qi * k + e]; }
+        {
+            double t1[1] = {s0};
+            ks_block_sums<1>(t1, red);
+            s0 = t1[0];
+        }
+        const double sw = s0;
+        double yrow[Q];
+        double dme = 0.0;
+        {
+            double sy[Q];
+#pragma unroll
+            for (int y = 0; y < Q; ++y) { sy[y] = 0.0; yrow[y] = 0.0; }
+            double ymin = __builtin_inf(), ymax = -__builtin_inf();
+            if (tid < KP) {
+                const int e = tid;
+                dme = e < k ? g.w[(size_t)qi * k + e] / sw : 0.0;
+                dl[e] = dme;
+                if (e < KS_KPX - KP) dl[KP + e] = dme;      // cyclic extension (blocks 13 .. 18 = blocks 0 .. 5)
+                if (e < k) {
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) {
+                        yrow[y] = y < q ? g.Y[(size_t)idx[e] + (size_t)y * (size_t)g.ldy] : 0.0;
+                        sy[y] += dme * yrow[y];
+                    }
+                    ymin = ymax = yrow[0];
+                }
+            }
+            ks_block_sums<Q>(sy, red);
+            if (tid < Q) ymean[tid] = sy[tid];
+            // constant-y shortcut, univariate y only (src/locwlv.jl:25-28)
+            for (int o = 32; o > 0; o >>= 1) { ymin = fmin(ymin, __shfl_xor(ymin, o, 64)); ymax = fmax(ymax, __shfl_xor(ymax, o, 64)); }
+            __syncthreads();
+            if (lane == 0) { red[wv] = ymin; red[8 + wv] = ymax; }
+            __syncthreads();
+            double gmin = red[0], gmax = red[8];
+#pragma unroll
+            for (int w8 = 1; w8 < KS_NW; ++w8) { gmin = fmin(gmin, red[w8]); gmax = fmax(gmax, red[8 + w8]); }
+            __syncthreads();
+            if (q == 1 && gmin == gmax) {
+                for (int a = tid; a < le; a += KS_NT) g.pred[(size_t)qi * le + a] = gmin;
+                continue;
+            }
+        }
+        {
+            double vv[Q];
+#pragma unroll
+            for (int y = 0; y < Q; ++y) { const double z = yrow[y] - ymean[y]; vv[y] = g.scal ? dme * z * z : 0.0; }
+            ks_block_sums<Q>(vv, red);
+            if (tid < Q) { ysd[tid] = (g.scal && tid < q) ? sqrt(vv[tid]) : 1.0; prun[tid] = ymean[tid]; }
+            __syncthreads();
+            if (tid < KP)
+#pragma unroll
+                for (int y = 0; y < Q; ++y) {
+                    const double z = yrow[y] - ymean[y];
+                    Am[tid * Q + y] = (y < q && tid < k) ? dme * (g.scal ? z / ysd[y] : z) : 0.0;
+                }
+            if (tid < q && g.nlv_lo == 0) g.pred[((size_t)qi * le) * q + tid] = ymean[tid];   // nlv = 0: the intercept alone
+        }
+        __syncthreads();
+
+        // ---- gathered rows in 16-column stages: thread (wave, lane) owns column pair 2 c8 of rows 32 rr + 8 wv + r8
+        const int colst = 2 * c8;
+        v2f64k xr[KS_NR], pv, sq = {1.0, 1.0};
+        auto issue = [&](int cs) {
+            const int col = min(KS_CS * cs + colst, ldr - 2);
+#pragma unroll
+            for (int rr = 0; rr < KS_NR; ++rr) {
+                const int e = min(32 * rr + 8 * wv + r8, k - 1);
+                xr[rr] = *reinterpret_cast<const v2f64k *>(g.Xrm + (size_t)idx[e] * ldr + col);
+            }
+            pv.x = g.Xq[(size_t)qi + (size_t)min(col, p - 1) * (size_t)g.ldxq];
+            pv.y = g.Xq[(size_t)qi + (size_t)min(col + 1, p - 1) * (size_t)g.ldxq];
+            if (g.scal) {   // written by other waves of this workgroup a moment ago: agent-scope loads (not through this CU's L1)
+                sq.x = __hip_atomic_load(sgl + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sq.y = __hip_atomic_load(sgl + col + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        if (g.scal) {
+            // local column stds about the local means (uncorrected, weighted: src/utility.jl:314-323), one extra sweep over the rows:
+            // var_j = sum_i d_i z_ij^2 - (sum_i d_i z_ij)^2 with z about the pivot (|mean - pivot| is of the order of the spread)
+            for (int cs = 0; cs < nstage; ++cs) {
+                issue(cs);
+                v2f64k s1 = {0.0, 0.0}, s2 = {0.0, 0.0};
+#pragma unroll
+                for (int rr = 0; rr < KS_NR; ++rr) {
+                    const int e = 32 * rr + 8 * wv + r8;
+                    const double d = e < k ? dl[e] : 0.0;
+                    const double zx = xr[rr].x - pv.x, zy = xr[rr].y - pv.y;
+                    s1.x += d * zx; s1.y += d * zy; s2.x += d * zx * zx; s2.y += d * zy * zy;
+                }
+                // 32 partials per column (4 waves x 8 row groups) through the (still unused) stage area
+                double *cp = stage + ((wv * 8 + r8) * KS_CS + colst) * 2;
+                cp[0] = s1.x; cp[1] = s2.x; cp[2] = s1.y; cp[3] = s2.y;
+                __syncthreads();
+                if (tid < KS_CS) {
+                    double a1 = 0.0, a2 = 0.0;
+                    for (int c = 0; c < 8 * KS_NW; ++c) { a1 += stage[(c * KS_CS + tid) * 2]; a2 += stage[(c * KS_CS + tid) * 2 + 1]; }
+                    const int j = KS_CS * cs + tid;
+                    if (j < ldr) __hip_atomic_store(sgl + j, j < p ? sqrt(fmax(a2 - a1 * a1, 0.0)) : 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS_TPW; ++s) acc[s] = v4f64k{0.0, 0.0, 0.0, 0.0};
+        auto put = [&](int cs, double *buf) {   // registers -> LDS stage [column quad][row][4], rows about the pivot (and scaled)
+            const int col = KS_CS * cs + colst;
+            const bool c0 = col < p, c1 = col + 1 < p;
+#pragma unroll
+            for (int rr = 0; rr < KS_NR; ++rr) {
+                const int e = 32 * rr + 8 * wv + r8;
+                if (e < KP) {                                     // (the seventh round covers rows 192 .. 223)
+                    v2f64k z;
+                    z.x = (e < k && c0) ? xr[rr].x - pv.x : 0.0;
+                    z.y = (e < k && c1) ? xr[rr].y - pv.y : 0.0;
+                    if (g.scal) { z.x /= sq.x; z.y /= sq.y; }     // (uniform branch: no divisions on the scal = false path)
+                    double *dst = buf + (((c8 >> 1) * RS + e) << 2) + 2 * (c8 & 1);
+                    *reinterpret_cast<v2f64k *>(dst) = z;
+                    if (e < KS_KPX - KP) *reinterpret_cast<v2f64k *>(dst + 4 * KP) = z;   // cyclic copy of row blocks 0 .. 5
+                }
+            }
+        };
+        KS_STAMP(1);
+        issue(0);
+        put(0, stage);
+        if (nstage > 1) issue(1);
+        __syncthreads();
+        for (int cs = 0; cs < nstage; ++cs) {
+            const double *buf = stage + (cs & 1) * ((KS_CS / 4) * RS * 4);
+            // G0 += Z_stage Z_stage': 4 k-steps of 4 columns; operand lane (m = l15 -> row, kap -> column), the same LDS array
+            // serves as A and as B; tile (I, I + delta) reads row blocks res + 4 i and res + 4 i + delta (cyclic extension)
+            {
+                const double *bl = buf + kap + (l15 << 2);
+                // the 21 tiles every wave has (i = 0 .. 2 of the seven classes): ONE basic block, the operands of k-step ks + 1 are
+                // requested before the products of k-step ks are issued (one wave per SIMD: nothing else hides the LDS latency)
+                double oa[2][3 * KS_ND], ob[2][3 * KS_ND];
+                auto fetch = [&](int ks, int par) {
+#pragma unroll
+                    for (int dlt = 0; dlt < KS_ND; ++dlt) {
+                        const double *bd = bl + ks * (RS * 4) + resd[dlt] * 64;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            oa[par][3 * dlt + i] = bd[i * 256];
+                            if (dlt) ob[par][3 * dlt + i] = bd[i * 256 + dlt * 64];
+                        }
+                    }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS_CS / 4; ++ks) {
+                    if (ks + 1 < KS_CS / 4) fetch(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                    for (int dlt = 0; dlt < KS_ND; ++dlt)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+                            KS_MFMA(acc[4 * dlt + i], oa[ks & 1][3 * dlt + i], dlt ? ob[ks & 1][3 * dlt + i] : oa[ks & 1][3 * dlt + i]);
+                }
+                // the tile with row block 12 exists in a class only for the wave whose res is 0 (one or two classes per wave)
+#pragma unroll
+                for (int dlt = 0; dlt < KS_ND; ++dlt) {
+                    if (resd[dlt] == 0) {                          // wave-uniform
+                        const double *bd = bl + 3 * 256;
+#pragma unroll
+                        for (int ks = 0; ks < KS_CS / 4; ++ks) {
+                            const double aI = bd[ks * (RS * 4)], aJ = dlt ? bd[ks * (RS * 4) + dlt * 64] : aI;
+                            KS_MFMA(acc[4 * dlt + 3], aI, aJ);
+                        }
+                    }
+                }
+            }
+            if (cs + 1 < nstage) {
+                put(cs + 1, stage + ((cs + 1) & 1) * ((KS_CS / 4) * RS * 4));   // (its loads were issued a stage ago)
+                if (cs + 2 < nstage) issue(cs + 2);
+            }
+            __syncthreads();
+        }
+
+        // ---- everything else runs on G0 in the registers.  ONE product site, driven by a job counter:
+        //   job 0: u = G0 d (raw), then mm = d'u, g = mm - u;  jobs 1 .. q: H[:, y] = G A[:, y];  job q + 1 + a: LV a — scores,
+        //   loadings, prediction, then z = G (D t) for the deflation of H
+        double mm = 0.0, tme = 0.0, dte = 0.0;
+        KS_STAMP(2);
+        for (int job = 0;; ++job) {
+            if (job == q + 1) KS_STAMP(3);
+            if (job == q + 2) KS_STAMP(4);
+            const int a = job - (q + 1);
+            const double *x = xv;
+            if (job == 0) x = dl;
+            else if (job <= q) {
+                if (tid < KP) {
+                    const double v = Am[tid * Q + (job - 1)];
+                    xv[tid] = v;
+                    if (tid < KS_KPX - KP) xv[KP + tid] = v;
+                }
+            }
+            else {
+                // ---------------- LV a (src/plskern.jl:149-175 in neighbour space, see the header)
+                double nrm;
+                if constexpr (Q > 1) {
+                    constexpr int NE = Q * (Q + 1) / 2;
+                    double ge[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) ge[e] = 0.0;
+                    if (tid < KP) {
+                        double ar[Q], hr[Q];
+#pragma unroll
+                        for (int y = 0; y < Q; ++y) { ar[y] = Am[tid * Q + y]; hr[y] = Hm[tid * Q + y]; }
+                        int e = 0;
+#pragma unroll
+                        for (int y1 = 0; y1 < Q; ++y1)
+#pragma unroll
+                            for (int y2 = y1; y2 < Q; ++y2) ge[e++] = 0.5 * (ar[y1] * hr[y2] + ar[y2] * hr[y1]);   // M = A'H, symmetrised
+                    }
+                    ks_block_sums<NE>(ge, red);
+                    for (int e = tid; e < 5 * Q * lda; e += KS_NT) G0m[e] = 0.0;
+                    __syncthreads();
+                    if (tid == 0) {
+                        int e = 0;
+                        for (int y1 = 0; y1 < Q; ++y1)
+                            for (int y2 = y1; y2 < Q; ++y2) { G0m[y1 * lda + y2] = ge[e]; G0m[y2 * lda + y1] = ge[e]; ++e; }
+                    }
+                    __syncthreads();
+                    if (wv == 0) {
+                        if (!dominant_by_squaring<Q>(q, lda, G0m, E0, E1, vl, nullptr)) {
+                            for (int e = lane; e < Q * lda; e += 64) E0[e] = G0m[e];
+                            wavesync();
+                            jacobi_wave(q, lda, E0, E1, V0, V1, csl, vl, nullptr);
+                        }
+                    }
+                    __syncthreads();
+                    double vmv = 0.0;
+#pragma unroll
+                    for (int y1 = 0; y1 < Q; ++y1)
+#pragma unroll
+                        for (int y2 = 0; y2 < Q; ++y2) vmv += vl[y1] * G0m[y1 * lda + y2] * vl[y2];
+                    nrm = sqrt(vmv);
+                } else {
+                    double t1[1] = {tid < KP ? Am[tid] * Hm[tid] : 0.0};
+                    ks_block_sums<1>(t1, red);
+                    nrm = sqrt(t1[0]);
+                }
+                // om = A v / nrm, s = H v / nrm; g'om
+                double gom = 0.0;
+                if (tid < KP) {
+                    double o = 0.0, sv_ = 0.0;
+                    if constexpr (Q == 1) { o = Am[tid]; sv_ = Hm[tid]; }
+                    else {
+#pragma unroll
+                        for (int y = 0; y < Q; ++y) { o += Am[tid * Q + y] * vl[y]; sv_ += Hm[tid * Q + y] * vl[y]; }
+                    }
+                    o /= nrm; sv_ /= nrm;
+                    sv[tid] = sv_;
+                    gom = gv[tid] * o;
+                }
+                {
+                    double t1[1] = {gom};
+                    ks_block_sums<1>(t1, red);       // (its barriers publish sv)
+                    gom = t1[0];
+                }
+                // beta_j = t_j'D s / tt_j (wave per finished LV)
+                for (int j = wv; j < a; j += KS_NW) {
+                    double b = 0.0;
+                    for (int i = lane; i < KP; i += 64) b += Th[j * KP + i] * dl[i] * sv[i];
+                    b = ks_wave_sum(b);
+                    if (lane == 0) beta[j] = b / tth[j];
+                }
+                __syncthreads();
+                tme = 0.0; dte = 0.0;
+                if (tid < KP) {
+                    tme = sv[tid];
+                    for (int j = 0; j < a; ++j) tme -= beta[j] * Th[j * KP + tid];
+                    Th[a * KP + tid] = tme;
+                    dte = dl[tid] * tme;
+                    xv[tid] = dte;
+                    if (tid < KS_KPX - KP) xv[KP + tid] = dte;
+                }
+                double tau = gom;
+                for (int j = 0; j < a; ++j) tau -= beta[j] * tauh[j];
+                double sc_[Q + 1];
+                sc_[Q] = dte * tme;
+#pragma unroll
+                for (int y = 0; y < Q; ++y) sc_[y] = tid < KP ? Am[tid * Q + y] * tme : 0.0;
+                ks_block_sums<Q + 1>(sc_, red);
+                const double tt = sc_[Q];
+                if (tid == 0) { tth[a] = tt; tauh[a] = tau; }
+                const int kk = a + 1;
+                if (tid < Q) {
+                    const double c = sc_[tid] / tt;
+                    cvec[tid] = c;
+                    const double pr = prun[tid] + tau * c * ysd[tid];
+                    prun[tid] = pr;
+                    if (tid < q && kk >= g.nlv_lo && kk <= g.nlv_hi) g.pred[((size_t)qi * le + (kk - g.nlv_lo)) * q + tid] = pr;
+                }
+                if (kk >= nlvloc) break;              // (uniform) the last LV needs no deflation
+            }
+            __syncthreads();                          // x (and cvec) published
+            // ---------------- y = G0 x from the accumulator registers, then the centring and the fixed-order combination
+            double px = 0.0, pu = 0.0;
+            for (int i = lane; i < KP; i += 64) { const double xi = x[i]; px += xi; pu += uv[i] * xi; }
+            const double sx = ks_wave_sum(px), ux = ks_wave_sum(pu);
+            // the wave's share, straight from the accumulator registers (D layout: lane (kap, l15), register reg holds
+            // G0[16 I + kap + 4 reg][16 J + l15]).  Rows of block I: the tiles (I, J) x_J of classes delta and delta + 4 share their I
+            // and are accumulated first, then ONE transposing 16-lane reduction per group (ypR[wave][group g = delta & 3, i]);
+            // rows of block J: the tile is also G0[J][I]' — four registers against x_I, then the four lane rows, four tiles per
+            // permlane reduction (ypC[wave][slot]).  Slots with i = 3 exist for res = 0 only: their registers stay zero otherwise.
+            {
+                double *pR = ypR + wv * (KS_TPW * 16), *pC = ypC + wv * (KS_TPW * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {               // classes gq and gq + 4 have the same res, hence the same I
+                        if (i == 3 && resd[gq] != 0) continue;     // (wave-uniform) no such tile: its x entries would lie past the vector
+                        const double *xb = x + resd[gq] * 16 + 64 * i;
+                        double r[4];
+                        {
+                            const double xJ = xb[gq * 16 + l15];
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) r[reg] = acc[4 * gq + i][reg] * xJ;
+                        }
+                        if (gq + 4 < KS_ND) {
+                            const double xJ = xb[(gq + 4) * 16 + l15];
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) r[reg] += acc[4 * (gq + 4) + i][reg] * xJ;
+                        }
+                        const double t = ks_rowsum16x4(r, l15);
+                        if ((l15 & 3) == 0) pR[(4 * gq + i) * 16 + kap + 4 * (2 * ((l15 >> 2) & 1) + (l15 >> 3))] = t;
+                    }
+                }
+                double cp[KS_TPW];
+#pragma unroll
+                for (int dlt = 1; dlt < KS_ND; ++dlt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double *xb = x + resd[dlt] * 16 + 64 * i + kap;
+                        double c = 0.0;
+                        if (i < 3 || resd[dlt] == 0) {             // (wave-uniform)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) c += acc[4 * dlt + i][reg] * xb[4 * reg];
+                        }
+                        cp[4 * dlt + i] = c;
+                    }
+#pragma unroll
+                for (int dlt = 1; dlt < KS_ND; ++dlt) {            // the class's four tiles in one reduction: rows hold i = 0, 2, 1, 3
+                    const double c = ks_colsum4(cp[4 * dlt], cp[4 * dlt + 1], cp[4 * dlt + 2], cp[4 * dlt + 3]);
+                    pC[(4 * dlt + ((kap & 1) * 2 + (kap >> 1))) * 16 + l15] = c;
+                }
+            }
+            __syncthreads();
+            if (tid < KP) {
+                // entry 16 I + ml of G0 x: the seven tiles (I, I + delta) of its row block (four partials: classes delta and delta + 4
+                // were combined by their owner) and the six tiles (I - delta, I) that reach it transposed — 10 terms, fixed order
+                const int I = tid >> 4, ml = tid & 15;
+                double v = 0.0;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) v += ypR[(((I + gq) & 3) * KS_TPW + 4 * gq + (I >> 2)) * 16 + ml];   // owner of (I, delta): wave (I + delta) mod 4
+#pragma unroll
+                for (int dlt = 1; dlt < KS_ND; ++dlt) {
+                    const int Ip = I - dlt + (I < dlt ? KS_KB : 0);
+                    v += ypC[(((Ip + dlt) & 3) * KS_TPW + 4 * dlt + (Ip >> 2)) * 16 + ml];
+                }
+                if (job > 0) v = v - uv[tid] * sx - (ux - mm * sx);                       // G x = G0 x - u (1'x) - 1 (u'x - mm 1'x)
+                v = tid < k ? v : 0.0;
+                if (job == 0) uv[tid] = v;
+                else if (job <= q) Hm[tid * Q + (job - 1)] = v;
+                else {
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) {      // deflation: A <- A - (D t) c', H <- H - (G D t) c'
+                        Am[tid * Q + y] -= dte * cvec[y];
+                        Hm[tid * Q + y] -= v * cvec[y];
+                    }
+                }
+            }
+            if (job == 0) {
+                double t1[1] = {tid < KP ? dl[tid] * uv[tid] : 0.0};   // (own entry: written by this thread above)
+                ks_block_sums<1>(t1, red);
+                mm = t1[0];
+                if (tid < KP) gv[tid] = tid < k ? mm - uv[tid] : 0.0;
+#pragma unroll 1
+                for (int y = q; y < Q; ++y) if (tid < KP) Hm[tid * Q + y] = 0.0;
+            }
+            __syncthreads();
+        }
+        // requested nlv beyond what the local model has: predict clamps to the model's nlv (src/plskern.jl:228-229)
+        __syncthreads();
+        KS_STAMP(5);
+        for (int e = tid; e < (g.nlv_hi - nlvloc) * q; e += KS_NT) {
+            const int kk = nlvloc + 1 + e / q, y = e % q;
+            if (kk >= g.nlv_lo) g.pred[((size_t)qi * le + (kk - g.nlv_lo)) * q + y] = prun[y];
+        }
+    }
+}
+
+bool jch_locw_kspace_supported(const locw_args &g)
+{
+    int mode = 1;
+    if (const char *e = getenv("JCH_LOCW_KSPACE")) mode = atoi(e);   // 0: never, 2: whenever the shape fits (tests)
+    if (mode == 0) return false;
+    if (g.k > KS_KP || g.k < 2 || g.q > 8 || g.nlv_hi > KS_MAXNLV || g.nlv_hi < 1 || g.ldr > JCH_SWEEP_MAXP || g.ldr < 2) return false;
+    const int Q = g.q <= 1 ? 1 : (g.q <= 2 ? 2 : (g.q <= 4 ? 4 : 8));
+    if (sizeof(double) * (size_t)ks_layout(Q, g.nlv_hi).total + 64 > 159 * 1024) return false;
+    if (mode == 2) return true;
+    // the Gram pass costs 208^2 p / 2 matrix flops per query whatever k is (smaller k is zero-padded to 13 row blocks): it pays
+    // against nlv sweeps of a k x p slab when k is most of those 208 rows and the row is wide
+    return g.k >= 128 && g.p >= 128 && g.nlv_hi >= 3;
+}
+
+template <int Q>
+static int32_t launch_ks(jch_ctx *ctx, locw_args &g)
+{
+    const size_t lds = sizeof(double) * (size_t)ks_layout(Q, g.nlv_hi).total + 64;
+    static jch_per_device_once attr;
+    if (!attr.done(ctx->device)) {
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_locw_kspace<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.mark(ctx->device);
+    }
+    const int nb = std::min(g.m, ctx->cus);
+    g.slab = ((size_t)g.ldr + 31) & ~(size_t)31;
+    JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
+    g.scratch = (double *)ctx->xstage.ptr;
+    hipLaunchKernelGGL((k_locw_kspace<Q>), dim3(nb), dim3(KS_NT), lds, ctx->stream, g);
+    JCH_HIP(ctx, hipGetLastError());
+    if (g.dbg & 2) {   // phase stamps of block 0's first query (wall_clock64: 100 MHz)
+        double st[6] = {};
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        JCH_HIP(ctx, hipMemcpy(st, g.scratch, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[jch] k_locw_kspace phases (us): setup %.1f  gram %.1f  u+H %.1f  first LV %.1f  remaining LVs %.1f  (nlv %d)\n", (st[1] - st[0]) * 0.01,
+                (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01, g.nlv_hi);
+    }
+    return JCH_OK;
+}
+
+int32_t jch_launch_locw_kspace(jch_ctx *ctx, locw_args &g)
+{
+    if (g.q <= 1) return launch_ks<1>(ctx, g);
+    if (g.q <= 2) return launch_ks<2>(ctx, g);
+    if (g.q <= 4) return launch_ks<4>(ctx, g);
+    return launch_ks<8>(ctx, g);
+}
