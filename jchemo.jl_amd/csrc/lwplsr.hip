@@ -673,7 +673,10 @@ static int32_t launch_locw_q(jch_ctx *ctx, locw_args &g)
         JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_locw_plskern<KC, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr.mark(ctx->device);
     }
-    if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k / p / q too large for the batched local-PLS kernel");
+    if (lds > 150 * 1024) {   // the slab bookkeeping of this kernel does not fit: the neighbour-space kernel has no such limit in p
+        if (jch_locw_kspace_feasible(g)) return jch_launch_locw_kspace(ctx, g);
+        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: k / p / q too large for the batched local-PLS kernels (k = %d, p = %d, q = %d)", g.k, g.p, g.q);
+    }
     const char *e_bpc = getenv("JCH_LOCW_BPC");   // (measurement knob) blocks per CU of the local-fit kernel
     int nb = std::min(g.m, ctx->cus * ((e_bpc && atoi(e_bpc) > 0) ? atoi(e_bpc) : 2));
     g.slab = ((size_t)g.k * g.ldr + 2 * (size_t)g.nlv_hi * g.ldr + 31) & ~(size_t)31;

@@ -14,6 +14,8 @@ struct locw_args {
     int dbg;                                // measurement switches (JCH_LOCW_DBG; results then wrong by design): 1 = every query gathers rows 0 .. k-1
 };
 
-// lwplsr_kspace.hip: true if the k-space kernel takes this shape (k <= 208, q <= 8, nlv <= 48, p <= 2048)
+// lwplsr_kspace.hip: _feasible: the k-space kernel can take this shape (k <= 208, q <= 8, nlv <= 48, p <= 2048);
+// _supported: ... and is expected to beat the p-space kernel there
+bool jch_locw_kspace_feasible(const locw_args &g);
 bool jch_locw_kspace_supported(const locw_args &g);
 int32_t jch_launch_locw_kspace(jch_ctx *ctx, locw_args &g);

@@ -47,9 +47,10 @@
 #define KS_NR 7          // load rounds per stage: 4 waves x 8 rows per round
 #define KS_MAXNLV 48
 
-// The accumulator tiles are pinned to AccVGPRs through the operand constraint: left to itself the allocator carried them
-// through the stage loop in architectural registers and copied all 8 words in and out around every product.
-#define KS_MFMA(acc_, a_, b_) asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc_) : "v"(a_), "v"(b_))
+// (The builtin, not inline asm: an asm statement hides the instruction from the compiler's hazard recognizer, and back-to-back
+// dependent f64 products on ONE accumulator — the four k-steps of a guarded tile — then lose part of the sum: measured, rows
+// 12 .. 15 of those tiles.  Pinning the tiles to AccVGPRs through an asm constraint bought no time anyway.)
+#define KS_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc_, 0, 0, 0)
 typedef double v2f64k __attribute__((ext_vector_type(2)));
 typedef double v4f64k __attribute__((ext_vector_type(4)));
 
@@ -313,38 +314,18 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             // serves as A and as B; tile (I, I + delta) reads row blocks res + 4 i and res + 4 i + delta (cyclic extension)
             {
                 const double *bl = buf + kap + (l15 << 2);
-                // the 21 tiles every wave has (i = 0 .. 2 of the seven classes): ONE basic block, the operands of k-step ks + 1 are
-                // requested before the products of k-step ks are issued (one wave per SIMD: nothing else hides the LDS latency)
-                double oa[2][3 * KS_ND], ob[2][3 * KS_ND];
-                auto fetch = [&](int ks, int par) {
+#pragma unroll
+                for (int ks = 0; ks < KS_CS / 4; ++ks) {
 #pragma unroll
                     for (int dlt = 0; dlt < KS_ND; ++dlt) {
                         const double *bd = bl + ks * (RS * 4) + resd[dlt] * 64;
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
-                            oa[par][3 * dlt + i] = bd[i * 256];
-                            if (dlt) ob[par][3 * dlt + i] = bd[i * 256 + dlt * 64];
+                            const double aI = bd[i * 256], aJ = dlt ? bd[i * 256 + dlt * 64] : aI;
+                            KS_MFMA(acc[4 * dlt + i], aI, aJ);
                         }
-                    }
-                };
-                fetch(0, 0);
-#pragma unroll
-                for (int ks = 0; ks < KS_CS / 4; ++ks) {
-                    if (ks + 1 < KS_CS / 4) fetch(ks + 1, (ks + 1) & 1);
-#pragma unroll
-                    for (int dlt = 0; dlt < KS_ND; ++dlt)
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-                            KS_MFMA(acc[4 * dlt + i], oa[ks & 1][3 * dlt + i], dlt ? ob[ks & 1][3 * dlt + i] : oa[ks & 1][3 * dlt + i]);
-                }
-                // the tile with row block 12 exists in a class only for the wave whose res is 0 (one or two classes per wave)
-#pragma unroll
-                for (int dlt = 0; dlt < KS_ND; ++dlt) {
-                    if (resd[dlt] == 0) {                          // wave-uniform
-                        const double *bd = bl + 3 * 256;
-#pragma unroll
-                        for (int ks = 0; ks < KS_CS / 4; ++ks) {
-                            const double aI = bd[ks * (RS * 4)], aJ = dlt ? bd[ks * (RS * 4) + dlt * 64] : aI;
+                        if (resd[dlt] == 0) {                      // wave-uniform: row block 12 exists in the class only for res = 0
+                            const double aI = bd[3 * 256], aJ = dlt ? bd[3 * 256 + dlt * 64] : aI;
                             KS_MFMA(acc[4 * dlt + 3], aI, aJ);
                         }
                     }
@@ -553,6 +534,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 }
             }
             if (job == 0) {
+                if ((g.dbg & 4) && blockIdx.x == 0 && qi == 0 && tid < KP) sgl[16 + tid] = uv[tid];   // (debug: u = G0 d of the first query)
                 double t1[1] = {tid < KP ? dl[tid] * uv[tid] : 0.0};   // (own entry: written by this thread above)
                 ks_block_sums<1>(t1, red);
                 mm = t1[0];
@@ -572,15 +554,19 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
     }
 }
 
-bool jch_locw_kspace_supported(const locw_args &g)
+// the shape fits the neighbour-space kernel at all
+bool jch_locw_kspace_feasible(const locw_args &g)
 {
-    int mode = 1;
-    if (const char *e = getenv("JCH_LOCW_KSPACE")) mode = atoi(e);   // 0: never, 2: whenever the shape fits (tests)
-    if (mode == 0) return false;
+    if (const char *e = getenv("JCH_LOCW_KSPACE")) { if (atoi(e) == 0) return false; }   // 0: never
     if (g.k > KS_KP || g.k < 2 || g.q > 8 || g.nlv_hi > KS_MAXNLV || g.nlv_hi < 1 || g.ldr > JCH_SWEEP_MAXP || g.ldr < 2) return false;
     const int Q = g.q <= 1 ? 1 : (g.q <= 2 ? 2 : (g.q <= 4 ? 4 : 8));
-    if (sizeof(double) * (size_t)ks_layout(Q, g.nlv_hi).total + 64 > 159 * 1024) return false;
-    if (mode == 2) return true;
+    return sizeof(double) * (size_t)ks_layout(Q, g.nlv_hi).total + 64 <= 159 * 1024;
+}
+// ... and is expected to be the faster of the two kernels there
+bool jch_locw_kspace_supported(const locw_args &g)
+{
+    if (!jch_locw_kspace_feasible(g)) return false;
+    if (const char *e = getenv("JCH_LOCW_KSPACE")) { if (atoi(e) == 2) return true; }    // 2: whenever the shape fits (tests)
     // the Gram pass costs 208^2 p / 2 matrix flops per query whatever k is (smaller k is zero-padded to 13 row blocks): it pays
     // against nlv sweeps of a k x p slab when k is most of those 208 rows and the row is wide
     return g.k >= 128 && g.p >= 128 && g.nlv_hi >= 3;
@@ -596,11 +582,19 @@ static int32_t launch_ks(jch_ctx *ctx, locw_args &g)
         attr.mark(ctx->device);
     }
     const int nb = std::min(g.m, ctx->cus);
-    g.slab = ((size_t)g.ldr + 31) & ~(size_t)31;
+    g.slab = ((size_t)std::max(g.ldr, 16 + KS_KP) + 31) & ~(size_t)31;
     JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
     g.scratch = (double *)ctx->xstage.ptr;
     hipLaunchKernelGGL((k_locw_kspace<Q>), dim3(nb), dim3(KS_NT), lds, ctx->stream, g);
     JCH_HIP(ctx, hipGetLastError());
+    if (g.dbg & 4) {
+        double u[KS_KP];
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        JCH_HIP(ctx, hipMemcpy(u, g.scratch + 16, sizeof u, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[jch] u =");
+        for (int i = 0; i < KS_KP; ++i) fprintf(stderr, " %.17g", u[i]);
+        fprintf(stderr, "\n");
+    }
     if (g.dbg & 2) {   // phase stamps of block 0's first query (wall_clock64: 100 MHz)
         double st[6] = {};
         JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -1137,3 +1137,51 @@ def test_bf16_row_panel_prologue_matches_tile_kernel(shape, nh, J):
         assert O.rel_fro(getattr(ref, f), getattr(new, f) * s) < 1e-3, f
     assert O.rel_fro(ref.T, new.T.cpu().numpy() * s) < 1e-3
     tctx.close()
+
+
+@pytest.mark.parametrize("case", [dict(n=6000, p=500, m=37, k=200, q=1, nlv=15, scal=False), dict(n=5000, p=333, m=19, k=208, q=1, nlv=12, scal=True),
+                                  dict(n=4000, p=130, m=9, k=150, q=3, nlv=7, scal=False), dict(n=3000, p=257, m=11, k=129, q=8, nlv=6, scal=True),
+                                  dict(n=2500, p=64, m=5, k=31, q=2, nlv=5, scal=False), dict(n=2000, p=40, m=7, k=60, q=1, nlv=48, scal=False),
+                                  dict(n=3000, p=1030, m=6, k=200, q=5, nlv=4, scal=False)])
+def test_lwplsr_kspace_matches_pspace(case, J, ctx):
+    """Round 3: the two local-fit kernels of predict(::Lwplsr) on the same neighbours — the neighbour-space kernel (Gram matrix
+    of the gathered rows on the matrix cores, held in registers: lwplsr_kspace.hip, forced with JCH_LOCW_KSPACE=2) against
+    the p-space kernel (one sweep of the k x p slab per LV: JCH_LOCW_KSPACE=0), and both against the oracle.  Shapes: the
+    cfg5 k and p; k = 208 (all 13 row blocks full) with scal; q = 3 / 8 / 5 (eigen-solver path); k, p not multiples of
+    16 / 32; a small k (zero-padded blocks); nlv = 48 > p (clamped local models); p > 1024."""
+    import os
+    c = case
+    Lsrc = CO.fill_uniform(7, 25, c["p"]) - 0.5
+    X = CO.fill_uniform(5, c["n"], 25) @ Lsrc + 0.05 * CO.fill_uniform(20250112, c["n"], c["p"])
+    Xq = CO.fill_uniform(6, c["m"], 25) @ Lsrc + 0.05 * CO.fill_uniform(20250115, c["m"], c["p"])
+    Y = np.column_stack([X[:, (3 * j) % c["p"]] * (1.0 + 0.3 * j) - X[:, (5 * j + 1) % c["p"]] + np.sin(2 * X[:, (j + 2) % c["p"]])
+                         + 0.05 * CO.fill_uniform(20250113 + j, c["n"], 1)[:, 0] for j in range(c["q"])])
+    kw = dict(nlvdis=6, metric="mahal", h=1.5, k=c["k"], nlv=c["nlv"], scal=c["scal"])
+    rng = range(0, c["nlv"] + 1)
+    keep = os.environ.get("JCH_LOCW_KSPACE")
+    try:
+        os.environ["JCH_LOCW_KSPACE"] = "2"
+        ks = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
+        os.environ["JCH_LOCW_KSPACE"] = "0"
+        if c["p"] > 1024 and c["q"] > 4:    # the p-space kernel's LDS bookkeeping does not fit this shape: it must say so, and the
+            with pytest.raises(J.JchError):  # default dispatch must fall through to the neighbour-space kernel instead of failing
+                J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
+            os.environ.pop("JCH_LOCW_KSPACE")
+            ps = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
+        else:
+            ps = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
+    finally:
+        if keep is None:
+            os.environ.pop("JCH_LOCW_KSPACE", None)
+        else:
+            os.environ["JCH_LOCW_KSPACE"] = keep
+    assert np.array_equal(ps.listnn, ks.listnn) and np.array_equal(ps.listw, ks.listw)     # same neighbours, same weights
+    ref = O.lwplsr_predict(O.lwplsr(X, Y, **kw), Xq, nlv=rng)
+    hi = min(c["nlv"], c["p"], c["k"])
+    for a in range(len(ps.pred)):
+        e_kp = O.rel_fro(ps.pred[a], ks.pred[a])
+        e_or = O.rel_fro(ref["pred"][:, :, a], ks.pred[a])
+        # the late LVs of a 48-LV local model on 60 neighbours are conditioning noise in ANY fp64 implementation: compare what is defined
+        tol_kp, tol_or = (1e-9, 1e-7) if a <= min(hi, 20) else (1e-4, 1e-4)
+        assert e_kp < tol_kp, (a, e_kp)
+        assert e_or < tol_or, (a, e_or)
