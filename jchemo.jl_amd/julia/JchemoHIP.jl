@@ -28,7 +28,9 @@ module JchemoHIP
 using LinearAlgebra
 
 export Plsr, Lwplsr, plskern, plskern!, plsnipals, plsnipals!, plssimp, plssimp!, plsrosa, plsrosa!, plswold, plswold!,
-       lwplsr, transform, coef, predict, explvarx, JchCtx, attach!
+       lwplsr, transform, coef, predict, explvarx, JchCtx, attach!,
+       msep, rmsep, ssr, bias, r2, cor2, mpar, segmkf, segmts, gridscorelv, gridcvlv,
+       Plsrda, dummy, plsrda, Mbplsr, mbplsr, vip, xfit, xresid
 
 const LIB = get(ENV, "JCHEMO_HIP_LIB", joinpath(@__DIR__, "..", "lib", "libjchemo_hip.so"))
 
@@ -246,6 +248,8 @@ _nlv_fit(object) = size(object.P, 2)     # (== nco(object.T) of the reference; P
 
 "`transform(object, X; nlv)` — src/plskern.jl:187-195 on the GPU; `object`: `Jchemo.Plsr` or `JchemoHIP.Plsr`."
 function transform(object, X; nlv = nothing, ctx = default_ctx())
+    hasproperty(object, :lev) && return transform(object.fm, X; nlv = nlv, ctx = ctx)          # Plsrda: src/plsrda.jl:86-88
+    hasproperty(object, :bscales) && return _transform_mbplsr(object, X, nlv, ctx)
     a = _nlv_fit(object)
     nlv = nlv === nothing ? a : min(nlv, a)
     _affine(X, object.xmeans, object.xscales, nlv == a ? object.R : object.R[:, 1:nlv], nothing, ctx)
@@ -265,6 +269,8 @@ end
 PLSR: the whole nlv range in ONE pass over X (the B blocks concatenated)."""
 function predict(object, X; nlv = nothing, ctx = default_ctx())
     hasproperty(object, :metric) && return _predict_lwplsr(object, X, nlv, ctx)
+    hasproperty(object, :lev) && return _predict_plsrda(object, X, nlv, ctx)
+    hasproperty(object, :bscales) && return _predict_mbplsr(object, X, nlv, ctx)
     a = _nlv_fit(object); q = size(object.C, 1)
     rng = nlv === nothing ? (a:a) : (max(0, minimum(nlv)):min(a, maximum(nlv)))
     zs = [coef(object; nlv = k) for k in rng]
@@ -323,33 +329,96 @@ function _cov(A, ctx)             # Statistics.cov(A, corrected = false) on the 
     S
 end
 
+# ---- model-constant device data of an Lwplsr object, prepared once (include/jchemo_hip.h: jch_lwplsr_prepare) -------------
+# The reference fits `Lwplsr` once and predicts from it many times (src/lwplsr.jl:1-12).  `prepare(fm)` keeps the row-major
+# copy of Xtrain, Ytrain and the whitened training scores on the device; `predict(prepared, X)` then only ships the queries.
+mutable struct LwplsrPrepared
+    object                       # the Lwplsr record (either module's)
+    h::Ptr{Cvoid}                # jch_lwplsr_model*
+    qmap                         # query block -> coordinates of the neighbour search
+    dd::Int
+    ctx::JchCtx
+end
+
+"`prepare(object::Lwplsr; ctx)`: device handle of the model-constant data; release with `release!` (or let the GC do it)."
+function prepare(object; ctx = default_ctx())
+    Xt = _in(object.X); Yt = _colocate_mat(_in(object.Y), Xt)
+    n, p = size(Xt); q = size(Yt, 2)
+    Zt, qmap = _knn_train_space(object, Xt, ctx)
+    Zt = _colocate_mat(Zt, Xt)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve Xt Yt Zt check(ctx, ccall((:jch_lwplsr_prepare, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Ref{Ptr{Cvoid}}),
+        ctx.h, _loc(Xt), pointer(Xt), n, p, stride(Xt, 2), pointer(Yt), q, max(stride(Yt, 2), n), pointer(Zt), stride(Zt, 2), size(Zt, 2), r))
+    pm = LwplsrPrepared(object, r[], qmap, size(Zt, 2), ctx)
+    finalizer(release!, pm)
+    pm
+end
+function release!(pm::LwplsrPrepared)
+    pm.h == C_NULL && return nothing
+    ccall((:jch_lwplsr_release, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), C_NULL, pm.h)
+    pm.h = C_NULL
+    nothing
+end
+
+# the space the neighbours are searched in (src/lwplsr.jl:139-150, src/getknn.jl:37-49): training coordinates + query map
+function _knn_train_space(object, Xt, ctx)
+    if object.fm === nothing
+        if object.scal                        # :141-145  scale(object.X, colstd(object.X)) on both sides
+            xs = col_stats(Xt; ctx = ctx).stds
+            Dinv = Matrix(Diagonal(1 ./ xs))
+            Zt = _affine(Xt, nothing, nothing, Dinv, nothing, ctx)
+            qmap = Xq -> _affine(Xq, nothing, nothing, Dinv, nothing, ctx)
+        else
+            Zt = Xt
+            qmap = Xq -> Xq
+        end
+    else
+        fmg = object.fm
+        Zt = _colocate_mat(fmg.T, Xt)
+        qmap = Xq -> transform(fmg, Xq; ctx = ctx)
+    end
+    if object.metric == "mahal"               # src/getknn.jl:37-49
+        S = _cov(Zt, ctx); d = size(S, 1)
+        Uinv = d == 1 ? fill(1 / sqrt(S[1, 1]), 1, 1) : (isposdef(S) ? Matrix(inv(cholesky(Hermitian(S)).U)) : Matrix(Diagonal(1 ./ diag(S))))
+        Zt = _affine(Zt, nothing, nothing, Uinv, nothing, ctx)
+        inner = qmap
+        qmap = Xq -> _affine(inner(Xq), nothing, nothing, Uinv, nothing, ctx)
+    end
+    Zt, qmap
+end
+
+"`predict(pm::LwplsrPrepared, X; nlv)` — src/lwplsr.jl:134-166 on the prepared handle."
+function predict(pm::LwplsrPrepared, X; nlv = nothing)
+    object = pm.object; ctx = pm.ctx
+    X = _in(X); m = size(X, 1); n, p = size(object.X); q = size(object.Y, 2)
+    a = object.nlv
+    rng = nlv === nothing ? (a:a) : (max(minimum(nlv), 0):min(maximum(nlv), a, p))
+    Zq = _colocate_mat(pm.qmap(X), X)
+    k = min(object.k, n); le = length(rng)
+    pred = zeros(q, le, m); ind = zeros(Int32, k, m); dist = zeros(k, m); w = zeros(k, m)   # C layout [m][le][q] == Julia (q, le, m)
+    GC.@preserve Zq X check(ctx, ccall((:jch_lwplsr_predict_prepared, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Int32, Float64, Float64, Int32, Int32, Int32,
+         Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, pm.h, _loc(X), pointer(Zq), stride(Zq, 2), pointer(X), m, stride(X, 2), k, object.h, object.tol, object.scal ? 1 : 0,
+        first(rng), last(rng), pred, ind, dist, w))
+    preds = [permutedims(pred[:, i, :]) for i in 1:le]
+    (pred = le == 1 ? preds[1] : preds, listnn = [Int.(ind[:, i]) .+ 1 for i in 1:m], listd = [dist[:, i] for i in 1:m],
+     listw = [w[:, i] for i in 1:m])
+end
+
 # `predict(object::Lwplsr, X; nlv)` — src/lwplsr.jl:134-166: neighbours, weights and the m local fits in one call.
 function _predict_lwplsr(object, X, nlv, ctx)
     X = _in(X); m = size(X, 1); n, p = size(object.X); q = size(object.Y, 2)
     a = object.nlv
     rng = nlv === nothing ? (a:a) : (max(minimum(nlv), 0):min(maximum(nlv), a, p))
-    # the space the neighbours are searched in (src/lwplsr.jl:139-150)
-    if object.fm === nothing
-        if object.scal                        # :141-145  scale(object.X, colstd(object.X)) on both sides
-            xs = col_stats(object.X; ctx = ctx).stds
-            Dinv = Matrix(Diagonal(1 ./ xs))
-            Zt = _affine(object.X, nothing, nothing, Dinv, nothing, ctx); Zq = _affine(X, nothing, nothing, Dinv, nothing, ctx)
-        else
-            Zt, Zq = object.X, X
-        end
-    else
-        Zt, Zq = object.fm.T, transform(object.fm, X; ctx = ctx)
-    end
-    Zt = _colocate_mat(Zt, X); Zq = _colocate_mat(Zq, X)
-    if object.metric == "mahal"               # src/getknn.jl:37-49
-        S = _cov(Zt, ctx); d = size(S, 1)
-        Uinv = d == 1 ? fill(1 / sqrt(S[1, 1]), 1, 1) : (isposdef(S) ? Matrix(inv(cholesky(Hermitian(S)).U)) : Matrix(Diagonal(1 ./ diag(S))))
-        Zt = _affine(Zt, nothing, nothing, Uinv, nothing, ctx); Zq = _affine(Zq, nothing, nothing, Uinv, nothing, ctx)
-    end
+    Xt = _colocate_mat(_in(object.X), X)
+    Zt, qmap = _knn_train_space(object, Xt, ctx)
+    Zt = _colocate_mat(Zt, X); Zq = _colocate_mat(qmap(X), X)
     k = min(object.k, n); le = length(rng)
     q <= 16 || error("predict(::Lwplsr): the batched kernel handles q <= 16 responses")
     pred = zeros(q, le, m); ind = zeros(Int32, k, m); dist = zeros(k, m); w = zeros(k, m)   # C layout [m][le][q] == Julia (q, le, m)
-    Xt = _colocate_mat(object.X, X); Yt = _colocate_mat(object.Y, X)
+    Yt = _colocate_mat(_in(object.Y), X)
     GC.@preserve Xt Yt Zt Zq X check(ctx, ccall((:jch_lwplsr_predict, LIB), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Int64,
          Int64, Ptr{Float64}, Int64, Int64, Int32, Float64, Float64, Int32, Int32, Int32, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
@@ -395,6 +464,271 @@ function plskern_scaled(X, Y, xscales::Vector{Float64}, yscales = nothing, weigh
     k = Int(got[])
     cut(A) = k == size(A, 2) ? A : A[:, 1:k]
     _record(cut(T), cut(P), cut(R), cut(W), cut(C), k == length(TT) ? TT : TT[1:k], xm, xs, ym, ys, wn, nothing)
+end
+
+# ---- scores from device-side sums (src/scores.jl) ---------------------------------------------------------------------------
+# sums[:, c] = (sum e, sum e^2, sum y e, sum y, sum y^2, rows) of prediction column c = level * q + j over the rows with mask != 0
+function _score_sums(pred, Y, mask, ctx)
+    pred = _in(pred); Y = _colocate_mat(_in(Y), pred)
+    m, ncol = size(pred); q = size(Y, 2)
+    (size(Y, 1) == m && ncol % q == 0) || throw(DimensionMismatch("predictions are $m x $ncol, Y is $(size(Y, 1)) x $q"))
+    mask = mask === nothing ? nothing : _colocate(vec(Float64.(Array(mask))), pred)
+    sums = zeros(6, ncol)
+    GC.@preserve pred Y mask check(ctx, ccall((:jch_score_sums, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, _loc(pred), pointer(pred), m, ncol, stride(pred, 2), pointer(Y), q, max(stride(Y, 2), m),
+        mask === nothing ? Ptr{Float64}(C_NULL) : pointer(mask), sums))
+    reshape(sums, 6, q, ncol ÷ q)            # [stat, response, level]
+end
+
+# one score from the sums: levels x q  (formulas: src/scores.jl:25-32,54-62,155-158,190-196,268,426-429)
+function _score_from_sums(name::Symbol, S)
+    se, see, sye, sy, syy, cnt = (permutedims(S[i, :, :]) for i in 1:6)
+    name === :ssr && return see
+    name === :msep && return see ./ cnt
+    name === :rmsep && return sqrt.(see ./ cnt)
+    name === :bias && return -se ./ cnt
+    name === :r2 && return 1 .- (see ./ cnt) ./ (syy ./ cnt .- (sy ./ cnt) .^ 2)
+    if name === :cor2
+        sp = sy .- se; spp = syy .- 2 .* sye .+ see; spy = syy .- sye          # sums of pred, pred^2, pred * y
+        cv = spy ./ cnt .- (sp ./ cnt) .* (sy ./ cnt)
+        return cv .^ 2 ./ ((spp ./ cnt .- (sp ./ cnt) .^ 2) .* (syy ./ cnt .- (sy ./ cnt) .^ 2))
+    end
+    error("unknown score $name")
+end
+
+"A score of src/scores.jl as a callable: `rmsep(pred, Y)` -> 1 x q; the grid functions recognise it and use device-side sums."
+struct ScoreFun
+    name::Symbol
+end
+(s::ScoreFun)(pred, Y; ctx = default_ctx()) = _score_from_sums(s.name, _score_sums(pred, Y, nothing, ctx))[1:1, :]
+const msep = ScoreFun(:msep); const rmsep = ScoreFun(:rmsep); const ssr = ScoreFun(:ssr)
+const bias = ScoreFun(:bias); const r2 = ScoreFun(:r2); const cor2 = ScoreFun(:cor2)
+
+# ---- grids (src/gridscore.jl, src/gridcv.jl, src/mpar.jl, src/segm.jl) ---------------------------------------------------------
+"`mpar(; kwargs...)` — src/mpar.jl:15-24: all combinations of the parameter values (first keyword fastest), as a NamedTuple of vectors."
+function mpar(; kwargs...)
+    nam = keys(kwargs); vals = [v isa AbstractVector || v isa AbstractRange || v isa Tuple ? collect(v) : [v] for v in values(kwargs)]
+    combs = vec(collect(Iterators.product(vals...)))
+    NamedTuple{Tuple(nam)}(Tuple([c[i] for c in combs] for i in 1:length(nam)))
+end
+"`segmkf(n, K; rep = 1)` — src/segm.jl:44-57."
+function segmkf(n::Integer, K::Integer; rep = 1)
+    map(1:rep) do _
+        perm = _randperm(n)
+        [sort(perm[j:K:n]) for j in 1:K]
+    end
+end
+"`segmts(n, m; rep = 1)` — src/segm.jl:135-149."
+segmts(n::Integer, m::Integer; rep = 1) = [[sort(_randperm(n)[1:m])] for _ in 1:rep]
+_randperm(n) = sortperm(rand(n))
+_nlv_range(nlv, p) = max(0, minimum(nlv)):min(p, maximum(nlv))
+_pars_rows(pars) = pars === nothing ? [NamedTuple()] : [NamedTuple{keys(pars)}(Tuple(v[i] for v in values(pars))) for i in 1:length(first(values(pars)))]
+
+# m x (length(rng) * q) predictions [pred_rng[1] | pred_rng[2] | ...]: ONE pass over X for the scores, then a GEMM on the scores
+function _pred_matrix(fm, X, rng, ctx)
+    q = size(fm.C, 1); kmax = maximum(rng); a = _nlv_fit(fm)
+    Bc = zeros(max(kmax, 1), length(rng) * q)
+    for (ai, k) in enumerate(rng)
+        k > 0 && (Bc[1:k, (ai - 1) * q + 1:ai * q] = (fm.C[:, 1:k] .* fm.yscales)')
+    end
+    Tq = kmax == 0 ? _affine(X, nothing, nothing, zeros(size(fm.R, 1), 1), nothing, ctx) : transform(fm, X; nlv = min(kmax, a), ctx = ctx)
+    _affine(Tq, nothing, nothing, Bc[1:size(Tq, 2), :], repeat(fm.ymeans, length(rng)), ctx)
+end
+
+function _grid_table(pars, rng, res)
+    rows = _pars_rows(pars)
+    cols = (nlv = repeat(collect(rng), length(rows)),)
+    if pars !== nothing
+        cols = merge(cols, NamedTuple{keys(pars)}(Tuple([r[nm] for r in rows for _ in rng] for nm in keys(pars))))
+    end
+    merge(cols, (res = res,))
+end
+
+"""
+    gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars = nothing, verbose = false)
+
+src/gridscore.jl:167-221: one fit at `maximum(nlv)` per parameter combination, the predictions of the whole nlv range from ONE
+pass over `X`, the scores from device-side sums.  Returns the columns of the reference's DataFrame as a NamedTuple
+`(nlv, <pars...>, res)` with `res` (ncomb * le_nlv) x q, combination-major (`DataFrame(...)` of it gives the reference's table).
+"""
+function gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars = nothing, verbose = false, ctx = default_ctx())
+    pars === nothing || !(:nlv in keys(pars)) || error("Argument `pars` must not contain `nlv`")
+    rng = _nlv_range(nlv, size(ensure_mat(Xtrain), 2))
+    verbose && println(pars === nothing ? "-- Nb. combinations = 0." : "-- Nb. combinations = $(length(_pars_rows(pars)))")
+    blocks = Matrix{Float64}[]
+    for kw in _pars_rows(pars)
+        verbose && pars !== nothing && println(pairs(kw)...)
+        fm = fun(Xtrain, Ytrain; nlv = maximum(rng), kw...)
+        if score isa ScoreFun && hasproperty(fm, :TT) && !hasproperty(fm, :lev)
+            push!(blocks, _score_from_sums(score.name, _score_sums(_pred_matrix(fm, X, rng, ctx), Y, nothing, ctx)))
+        else                                   # any score(pred, Y) / any model with a `predict`
+            pr = predict(fm, X; nlv = rng).pred
+            pr = length(rng) == 1 ? [pr] : pr
+            push!(blocks, reduce(vcat, [reshape(collect(score(z, Y)), 1, :) for z in pr]))
+        end
+    end
+    verbose && println("-- End.")
+    _grid_table(pars, rng, reduce(vcat, blocks))
+end
+
+"""
+    gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false)
+
+src/gridcv.jl:187-228.  The reference copies `rmrow(X, s)` for every segment; here X stays where it is: each fold is ONE
+weighted fit with weight 0 on the held-out rows (same means, X'DY and loadings as the fit on the remaining rows), whose scores on
+the held-out rows already are their transformed rows, so the predictions for every nlv are a GEMM on the n x nlv scores.
+`score`: one of `msep, rmsep, ssr, bias, r2, cor2`; `fun`: a PLS fit of this module taking `(X, Y, weights; nlv, ...)`.
+Returns `(nlv, <pars...>, res, res_rep)`: `res` the mean over replications and segments, `res_rep[rep][segm]` the per-fold tables.
+"""
+function gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false, ctx = default_ctx())
+    score isa ScoreFun || error("gridcvlv: score must be one of msep, rmsep, ssr, bias, r2, cor2")
+    pars === nothing || !(:nlv in keys(pars)) || error("Argument `pars` must not contain `nlv`")
+    X = _in(X); Y = _colocate_mat(_in(Y), X); n, p = size(X); q = size(Y, 2)
+    rng = _nlv_range(nlv, p)
+    res_rep = Vector{Vector{Matrix{Float64}}}()
+    for (i, listsegm) in enumerate(segm)
+        verbose && print("/ repl=", i, " ")
+        zres = Matrix{Float64}[]
+        for (j, s) in enumerate(listsegm)
+            verbose && print("segm=", j, " ")
+            held = zeros(n); held[s] .= 1.0
+            w = 1.0 .- held
+            kfit = min(maximum(rng), n - length(s))                # the reference clamps with the TRAINING rows
+            blocks = Matrix{Float64}[]
+            for kw in _pars_rows(pars)
+                fm = fun(X, Y, w; nlv = kfit, kw...)
+                k = _nlv_fit(fm)
+                Bc = zeros(k, length(rng) * q)
+                for (ai, a) in enumerate(rng)
+                    kk = min(a, k)
+                    kk > 0 && (Bc[1:kk, (ai - 1) * q + 1:ai * q] = (fm.C[:, 1:kk] .* fm.yscales)')
+                end
+                Pm = _affine(fm.T, nothing, nothing, Bc, repeat(fm.ymeans, length(rng)), ctx)
+                push!(blocks, _score_from_sums(score.name, _score_sums(Pm, Y, held, ctx)))
+            end
+            push!(zres, reduce(vcat, blocks))
+        end
+        push!(res_rep, zres)
+    end
+    verbose && println("/ End.")
+    allfolds = reduce(vcat, res_rep)
+    merge(_grid_table(pars, rng, sum(allfolds) ./ length(allfolds)), (res_rep = res_rep,))
+end
+
+# ---- PLSR-DA (src/plsrda.jl) -----------------------------------------------------------------------------------------------------
+struct Plsrda                     # fallback record, fields of the reference's struct (src/plsrda.jl:1-5)
+    fm; lev; ni
+end
+"`dummy(y)` — src/utility.jl:509-519: `(Y = n x nlev 0/1 table, lev = sorted levels)`."
+function dummy(y)
+    y = vec(Array(y)); lev = sort(unique(y))
+    (Y = Float64.(y .== permutedims(lev)), lev = lev)
+end
+"`plsrda(X, y, weights = ones(n); nlv, scal = false)` — src/plsrda.jl:71-77: `plskern` on the dummy table of the classes."
+function plsrda(X, y, weights = nothing; nlv, scal = false, ctx = default_ctx())
+    res = dummy(y); yv = vec(Array(y))
+    ni = [count(==(l), yv) for l in res.lev]
+    X = _in(X)
+    fm = plskern(X, _colocate_mat(res.Y, X), weights; nlv = nlv, scal = scal, ctx = ctx)
+    J = jchemo_module()
+    (J !== nothing && fm isa getfield(J, :Plsr)) ? Base.invokelatest(getfield(J, :Plsrda), fm, res.lev, ni) : Plsrda(fm, res.lev, ni)
+end
+# `predict(object::Plsrda, X; nlv)` — src/plsrda.jl:95-120
+function _predict_plsrda(object, X, nlv, ctx)
+    a = _nlv_fit(object.fm)
+    rng = nlv === nothing ? (a:a) : (max(minimum(nlv), 0):min(maximum(nlv), a))
+    post = predict(object.fm, X; nlv = rng, ctx = ctx).pred
+    posts = length(rng) == 1 ? [post] : post
+    preds = [reshape(object.lev[[argmax(view(Array(z), i, :)) for i in 1:size(z, 1)]], :, 1) for z in posts]
+    length(rng) == 1 ? (pred = preds[1], posterior = posts[1]) : (pred = preds, posterior = posts)
+end
+
+# ---- multiblock PLSR (src/mbplsr.jl, src/mbplswest.jl:220-254) ------------------------------------------------------------------
+struct Mbplsr                     # fields of the reference's struct (src/mbplsr.jl:1-12)
+    fm; T; R; C; bscales; xmeans; xscales; ymeans; yscales; weights
+end
+_hcat(Xbl) = reduce(hcat, [_in(b) for b in Xbl])
+"""
+    mbplsr(Xbl, Y, weights = ones(n); nlv, bscal = "none", scal = false)
+
+src/mbplsr.jl:64-113.  The reference materialises every centred / scaled / block-scaled block; here the blocks are concatenated
+RAW and the whole scaling is ONE vector of column divisors (column std x block scale) handed to `jch_plskern_fit_scaled`.
+"""
+function mbplsr(Xbl, Y, weights = nothing; nlv, bscal = "none", scal = false, ctx = default_ctx())
+    bscal in ("none", "frob") || error("bscal must be \"none\" or \"frob\"")
+    X = _hcat(Xbl); Y = _colocate_mat(_in(Y), X)
+    widths = [size(ensure_mat(b), 2) for b in Xbl]; edges = cumsum([0; widths])
+    st = col_stats(X, weights; ctx = ctx)
+    blk(v, k) = v[edges[k] + 1:edges[k + 1]]
+    xscales = [scal ? blk(st.stds, k) : ones(widths[k]) for k in 1:length(widths)]
+    bscales = bscal == "frob" ? [sqrt(sum((blk(st.stds, k) ./ xscales[k]) .^ 2)) for k in 1:length(widths)] : ones(length(widths))
+    div = reduce(vcat, [xscales[k] .* bscales[k] for k in 1:length(widths)])
+    ysd = scal ? col_stats(Y, weights; ctx = ctx).stds : nothing
+    fm = plskern_scaled(X, Y, div, ysd, weights; nlv = nlv, ctx = ctx)
+    xmeans = [blk(fm.xmeans, k) for k in 1:length(widths)]
+    # the reference's inner fit sees pre-scaled data with scal = false: its record carries zero means and unit scales
+    inner = _record(fm.T, fm.P, fm.R, fm.W, fm.C, fm.TT, zero(fm.xmeans), one.(fm.xscales), zero(fm.ymeans), one.(fm.yscales), fm.weights, nothing)
+    Mbplsr(inner, fm.T, fm.R, fm.C, bscales, xmeans, xscales, copy(fm.ymeans), copy(fm.yscales), fm.weights)
+end
+# `transform(object::Mbplsr, Xbl; nlv)` — src/mbplswest.jl:220-231 as one device GEMM on the raw concatenation
+function _transform_mbplsr(object, Xbl, nlv, ctx)
+    a = size(object.R, 2); k = nlv === nothing ? a : min(nlv, a)
+    div = reduce(vcat, [object.xscales[i] .* object.bscales[i] for i in 1:length(object.xscales)])
+    _affine(_hcat(Xbl), reduce(vcat, object.xmeans), div, object.R[:, 1:k], nothing, ctx)
+end
+# `predict(object::Mbplsr, Xbl; nlv)` — src/mbplswest.jl:239-254: ymeans .+ T[:, 1:nlv] * C[:, 1:nlv]' (no `yscales`, as the reference)
+function _predict_mbplsr(object, Xbl, nlv, ctx)
+    a = size(object.R, 2); q = size(object.C, 1)
+    rng = nlv === nothing ? (a:a) : (max(0, minimum(nlv)):min(a, maximum(nlv)))
+    T = _transform_mbplsr(object, Xbl, nothing, ctx)
+    Bc = zeros(a, length(rng) * q)
+    for (i, k) in enumerate(rng)
+        k > 0 && (Bc[1:k, (i - 1) * q + 1:i * q] = object.C[:, 1:k]')
+    end
+    out = _affine(T, nothing, nothing, Bc, repeat(object.ymeans, length(rng)), ctx)
+    preds = [out[:, (i - 1) * q + 1:i * q] for i in 1:length(rng)]
+    (pred = length(rng) == 1 ? preds[1] : preds,)
+end
+
+# ---- vip / xfit / xresid (src/vip.jl:62-107, src/xfit.jl:37-93) ---------------------------------------------------------------
+"`vip(object; nlv)` — src/vip.jl:62-89: from W, C and TT = t'Dt (p x nlv host glue)."
+function vip(object; nlv = nothing)
+    a = _nlv_fit(object); p = size(object.W, 1); k = nlv === nothing ? a : min(nlv, a)
+    W2 = object.W[:, 1:k] .^ 2
+    sst = vec(sum(object.C[:, 1:k] .^ 2, dims = 1)) .* object.TT[1:k]          # tr(C_a C_a') t_a'D t_a
+    A = vec(sum(sst' .* W2, dims = 2))
+    (imp = sqrt.(A ./ (sum(sst) / p)), W2 = W2, sst = sst)
+end
+"`vip(object, Y; nlv)` — src/vip.jl:91-107: the redundancies rd(Y, T, weights) from ONE weighted covariance of [Y | T] on the device."
+function vip(object, Y; nlv = nothing, ctx = default_ctx())
+    a = _nlv_fit(object); p = size(object.W, 1); k = nlv === nothing ? a : min(nlv, a)
+    T = object.T[:, 1:k]; Y = _colocate_mat(_in(Y), T); q = size(Y, 2)
+    q + k <= 64 || error("vip(object, Y): q + nlv > 64 is not supported")
+    A_ = hcat(Y, T); n = size(A_, 1); w = _colocate(object.weights, A_)
+    S = zeros(q + k, q + k)
+    GC.@preserve A_ w check(ctx, ccall((:jch_weighted_cov, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, _loc(A_), pointer(A_), n, q + k, stride(A_, 2), pointer(w), S, Ptr{Float64}(C_NULL)))
+    # rd(Y, T, weights) (src/angles.jl:97-105): mean over the responses of the squared weighted correlations cor(y_j, t_a)^2
+    cyt = S[1:q, q + 1:q + k]; vy = diag(S)[1:q]; vt = diag(S)[q + 1:q + k]
+    rdd = vec(sum(cyt .^ 2 ./ (vy .* vt'), dims = 1)) ./ q
+    W2 = object.W[:, 1:k] .^ 2
+    Aimp = vec(sum(rdd' .* W2, dims = 2))
+    (imp = sqrt.(Aimp ./ (sum(rdd) / p)), W2 = W2, rdd = rdd)
+end
+"`xfit(object, X; nlv)` — src/xfit.jl:37-56: the scores pass over X, then a GEMM on the m x nlv scores, original scale."
+function xfit(object, X; nlv = nothing, ctx = default_ctx())
+    a = _nlv_fit(object); k = nlv === nothing ? a : min(nlv, a); p = size(object.P, 1)
+    k == 0 && return _affine(X, nothing, nothing, zeros(p, p), object.xmeans, ctx)
+    Tq = transform(object, X; nlv = k, ctx = ctx)
+    _affine(Tq, nothing, nothing, Matrix((object.P[:, 1:k] .* object.xscales)'), object.xmeans, ctx)
+end
+"`xresid(object, X; nlv)` — src/xfit.jl:86-93: E = X - xfit(X) = cscale(X) (I - R_k P_k') diag(xscales), one device GEMM."
+function xresid(object, X; nlv = nothing, ctx = default_ctx())
+    a = _nlv_fit(object); k = nlv === nothing ? a : min(nlv, a); p = size(object.P, 1)
+    M = Matrix{Float64}(I, p, p) - object.R[:, 1:k] * object.P[:, 1:k]'
+    _affine(X, object.xmeans, object.xscales, M .* object.xscales', nothing, ctx)
 end
 
 # ---- P2P inbox transport (include/jchemo_hip.h): export -> all-gather the handles (MPI) -> import -> agree -> enable
