@@ -4,6 +4,9 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "jch_internal.h"
 
@@ -74,6 +77,85 @@ float ev_ms(hipEvent_t a, hipEvent_t b)
     return 0.f;
 }
 
+// Host-resident outputs: the score columns go back WHILE the fit runs.  T[:, a] is final as soon as sweep a has finished, so a
+// helper thread waits for that sweep's event and copies the column into the caller's array on a stream of its own — the
+// 0.2 GB transfer of cfg2 and, more to the point, the first-touch page faults of a freshly allocated n x nlv host array
+// (~18 ms: the caller's array is pageable) disappear behind the remaining sweeps.  The fit thread only records events; it
+// never waits on the copies until the end (a pageable D2H issued from the fit thread itself would block it, and the GPU
+// would idle between latent variables).
+class t_column_copier {
+public:
+    t_column_copier(jch_ctx *ctx, double *host_T, const double *dev_T, int64_t n, int ncols)
+        : ctx_(ctx), host_(host_T), dev_(dev_T), n_(n)
+    {
+        if (!host_T || ncols < 1 || getenv("JCH_HOST_T_OVERLAP_OFF")) return;
+        if (hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess) { cs_ = nullptr; return; }
+        ev_.resize((size_t)ncols, nullptr);
+        for (auto &e : ev_)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; release(); return; }
+        active_ = true;
+        th_ = std::thread([this] { run(); });
+    }
+    ~t_column_copier() { finish(false); }
+    bool active() const { return active_; }
+    // column a is final once everything enqueued on the ctx stream so far has run
+    void column_done(int a)
+    {
+        if (!active_ || a < 0 || a >= (int)ev_.size()) return;
+        (void)hipEventRecord(ev_[(size_t)a], ctx_->stream);
+        { std::lock_guard<std::mutex> lk(m_); ready_ = a + 1; }
+        cv_.notify_one();
+    }
+    // wait for the copies of columns [0, ncols) (ok = false: give up, e.g. on an error path); returns false if a copy failed
+    bool finish(bool ok, int ncols = 0)
+    {
+        if (!active_) return true;
+        { std::lock_guard<std::mutex> lk(m_); stop_at_ = ok ? ncols : 0; stop_ = true; }
+        cv_.notify_one();
+        th_.join();
+        active_ = false;
+        release();
+        return !failed_;
+    }
+
+private:
+    void run()
+    {
+        (void)hipSetDevice(ctx_->device);
+        int done = 0;
+        for (;;) {
+            int upto;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return ready_ > done || stop_; });
+                upto = stop_ ? std::min(ready_, stop_at_) : ready_;
+                if (stop_ && done >= upto) return;
+            }
+            for (; done < upto; ++done) {
+                if (hipEventSynchronize(ev_[(size_t)done]) != hipSuccess ||
+                    hipMemcpyAsync(host_ + (size_t)done * (size_t)n_, dev_ + (size_t)done * (size_t)n_, sizeof(double) * (size_t)n_, hipMemcpyDeviceToHost, cs_) != hipSuccess ||
+                    hipStreamSynchronize(cs_) != hipSuccess)
+                    failed_ = true;
+            }
+        }
+    }
+    void release()
+    {
+        for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+        ev_.clear();
+        if (cs_) (void)hipStreamDestroy(cs_);
+        cs_ = nullptr;
+    }
+    jch_ctx *ctx_; double *host_; const double *dev_; int64_t n_;
+    hipStream_t cs_ = nullptr;
+    std::vector<hipEvent_t> ev_;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    int ready_ = 0, stop_at_ = 0;
+    bool stop_ = false, active_ = false, failed_ = false;
+};
+
 // raw-mode pivot check: |means - pivot| / spread above this sends the fit to the centred copy (error ~ ratio^2 * eps)
 constexpr double JCH_PIVOT_MAX_RATIO = 64.0;
 
@@ -129,6 +211,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     if (!host && io.T) Tdev = io.T;
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
+    t_column_copier tcopy(ctx, (host && d.dtype == JCH_F64) ? io.T : nullptr, Tdev, n, nlv_cap);
     const size_t small_bytes = 256 * 21 + sizeof(double) * 16 * 2048 + sizeof(double) * (64 + (size_t)p + (size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
                                                          (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
@@ -300,6 +383,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (kern_like) {
             JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.rs ? s.rs : s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice, raw_mode ? s.mshift : nullptr));
+            tcopy.column_done(a);
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;   // rank-independent message size (a small shard may use 1 slice; the rest hold zeros)
             // ONE collective per LV: [zp (p), tt].  With the inbox transport and the fast small-state kernel it happens
             // INSIDE that kernel (no launch of its own); otherwise here (RCCL / inbox kernel / loopback).
@@ -316,6 +400,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             if (pend_p) JCH_TRY(jch_launch_sweep_lazy(ctx, Xr, n, ldr, dn, s.w, Yr, qpad, tcol, s.zt, ldz, max_slices, &nslice, pend_p, npend,
                                                       defer_m - 1, Tdev + (size_t)pend_a0 * (size_t)n, n));
             else JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
+            tcopy.column_done(a);
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;
             ++x_reads;
             if (fuse_inbox) {   // [zp_raw, tt, c_raw] reduced inside the phase-A kernel
@@ -367,7 +452,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         return JCH_OK;
     };
     if (host) {
-        JCH_TRY(d2h(io.T, Tdev, (size_t)n * nlv));
+        // (the score columns have been travelling since their sweeps finished; algorithm #2 writes T in one GEMM at the end)
+        if (!tcopy.active() || variant2) JCH_TRY(d2h(io.T, Tdev, (size_t)n * nlv));
         JCH_TRY(d2h(io.weights_norm, dn, (size_t)n));
         if (inplace) {
             JCH_TRY(d2h_matrix(ctx, (double *)io.X, Xc, n, p, io.ldx));
@@ -375,6 +461,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         }
     }
     JCH_TRY(fetch_small(nlv));   // (ends with the stream sync of the whole fit)
+    if (tcopy.active() && !tcopy.finish(!variant2, nlv)) return jch_fail(ctx, JCH_EHIP, "%s: copying the scores to the host failed", who);
     JCH_TRY(jch_p2p_check(ctx));
     if (raw_mode && !(qual_host <= JCH_PIVOT_MAX_RATIO)) {
         // the sampled pivot was far from the means (sorted / trending / blank leading rows): the raw formulation would

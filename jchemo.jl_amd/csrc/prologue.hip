@@ -446,6 +446,24 @@ __global__ __launch_bounds__(256, 2) void k_center_xty_panel(double *__restrict_
                 }
                 if (sub + 1 == NSUB) {
                     // ---- row-major store of the whole tile: one wave-instruction = 1 KiB (TW = 128: one row; TW = 64: two rows)
+                    if constexpr (TW > 128) {
+                        // whole-row tile (round 3 experiment, TH = 32 x TW = 512): the tile's rows are complete rows of the copy, i.e. ONE
+                        // contiguous 128 KB region per tile; wave wv stores rows wv, wv + 4, ..., a quarter row per instruction
+                        if (!(dbg_skip & 2)) {
+                            for (int r = wv; r < TH; r += 4) {
+                                const int64_t irow = i0 + r;
+#pragma unroll
+                                for (int c2 = lane; c2 < TW / 2; c2 += 64) {
+                                    const int j = cg0 + 2 * c2;
+                                    const v2f64p v = *reinterpret_cast<const v2f64p *>(xt + r * PT + 2 * c2);
+                                    if (irow < rend && j < ldr) {
+                                        if (dbg_skip & 4) *reinterpret_cast<v2f64p *>(Xr + (size_t)irow * (size_t)ldr + j) = v;
+                                        else __builtin_nontemporal_store(v, reinterpret_cast<v2f64p *>(Xr + (size_t)irow * (size_t)ldr + j));
+                                    }
+                                }
+                            }
+                        }
+                    } else
                     if (!(dbg_skip & 2)) {
                         constexpr int LPR = TW / 2;                  // lanes per row (16 B each)
                         constexpr int RPI = 64 / LPR;                // rows per wave-instruction
@@ -611,14 +629,15 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
         JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * 16));
         double *Kpart = (double *)ctx->kpart.ptr;
         dim3 grid(nbx, groups);
-        const int th = th_sel == 128 ? 128 : 64;
-        const int tw = env_int("JCH_K2_TW", 64) == 128 ? 128 : 64;
+        const bool wholerow = th_sel == 32;                     // TH = 32 x TW = 512: complete rows leave the LDS tile (experiment)
+        const int th = wholerow ? 32 : (th_sel == 128 ? 128 : 64);
+        const int tw = wholerow ? 512 : (env_int("JCH_K2_TW", 64) == 128 ? 128 : 64);
         const size_t lds = sizeof(double) * ((size_t)th * (tw + 2) + 1024 + (th > 64 ? (size_t)th * 16 : 0));
         static jch_per_device_once attr_once;
         if (!attr_once.done(ctx->device)) {
 #define JCH_K2P_ATTR(TH, TW, WB, SC) JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_center_xty_panel<TH, TW, WB, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
 #define JCH_K2P_ATTR4(TH, TW) JCH_K2P_ATTR(TH, TW, false, false); JCH_K2P_ATTR(TH, TW, false, true); JCH_K2P_ATTR(TH, TW, true, false); JCH_K2P_ATTR(TH, TW, true, true)
-            JCH_K2P_ATTR4(128, 64); JCH_K2P_ATTR4(64, 64); JCH_K2P_ATTR4(64, 128); JCH_K2P_ATTR4(128, 128);
+            JCH_K2P_ATTR4(128, 64); JCH_K2P_ATTR4(64, 64); JCH_K2P_ATTR4(64, 128); JCH_K2P_ATTR4(128, 128); JCH_K2P_ATTR4(32, 512);
 #undef JCH_K2P_ATTR4
 #undef JCH_K2P_ATTR
             attr_once.mark(ctx->device);
@@ -627,7 +646,7 @@ int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc,
                                                    mom, scl, Xr, ldr, Yr, Kpart, kp_rows, ones_col, dbg_skip)
 #define JCH_K2P_TH(TH, TW) do { if (writeback && scal) JCH_K2P(TH, TW, true, true); else if (writeback) JCH_K2P(TH, TW, true, false); \
                                 else if (scal) JCH_K2P(TH, TW, false, true); else JCH_K2P(TH, TW, false, false); } while (0)
-        if (th == 128 && tw == 128) JCH_K2P_TH(128, 128); else if (th == 128) JCH_K2P_TH(128, 64); else if (tw == 128) JCH_K2P_TH(64, 128); else JCH_K2P_TH(64, 64);
+        if (wholerow) JCH_K2P_TH(32, 512); else if (th == 128 && tw == 128) JCH_K2P_TH(128, 128); else if (th == 128) JCH_K2P_TH(128, 64); else if (tw == 128) JCH_K2P_TH(64, 128); else JCH_K2P_TH(64, 64);
 #undef JCH_K2P_TH
 #undef JCH_K2P
         hipLaunchKernelGGL(k_reduce_kpart_wide, dim3((p * 16 + 63) / 64), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, 16, K);
