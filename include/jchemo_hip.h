@@ -106,10 +106,15 @@ typedef struct jch_pls_desc {
     int32_t inplace; /* 1 = `plskern!` / `plsnipals!` semantics: X and Y are overwritten with their
                         centred/scaled (plsnipals: and deflated) versions; 0 = `plskern` (inputs untouched,
                         the reference's copy at plskern.jl:108 never materialises) */
-    int32_t reserved; /* 0 = the reference's algorithm (improved kernel #1, one sweep over X per LV); 1 = OPT-IN
-                         kernel algorithm #2 (X'DX once, no pass over X and no collective in the LV loop; plskern,
-                         q <= 16, p <= 2048): same results up to rounding */
+    int32_t reserved; /* option bits.  0 = the reference's algorithm (improved kernel #1, one sweep over X per LV);
+                         bit 0 (1) = OPT-IN kernel algorithm #2 (X'DX once, no pass over X and no collective in the LV
+                         loop; plskern, q <= 16, p <= 2048): same results up to rounding;
+                         JCH_WOLD_REF_ZERO_WEIGHT_NAN (jch_plswold_fit only): see below */
 } jch_pls_desc;
+/* jch_plswold_fit: give the rows with weight 0 NaN scores, as the reference does (src/plswold.jl:107 divides by sqrt(w) = 0).
+ * Default (bit clear): finite scores t_i = x_i' r for those rows — what a cross-validation fold with zero weights on its
+ * held-out rows needs (gridcvlv). */
+#define JCH_WOLD_REF_ZERO_WEIGHT_NAN 2
 
 /*
  * jch_plskern_fit — replaces `plskern!` / `plskern` (src/plskern.jl:106-178): weight normalisation
@@ -158,9 +163,9 @@ JCH_API int32_t jch_col_stats(jch_ctx *ctx, int32_t loc, const double *X, int64_
  * jch_plswold_fit — `plswold!` / `plswold` (src/plswold.jl:30-111): NIPALS with the inner power iteration; `tol` and
  *   `maxit` as the reference's keywords (defaults sqrt(eps), 200); niter (nlv, HOST, as Float64 like :71) receives the
  *   number of inner passes per LV.  The reference seeds each LV's first convergence check with `rand(p)` (:78), which
- *   can never pass; that check is skipped here.  Rows with zero weight get finite scores here (the reference divides
- *   by sqrt(w) = 0 at :107 and returns NaN for them).  inplace = 1 hands back X, Y deflated AND carrying the row
- *   metric sqrt(w) (:57-58).
+ *   can never pass; that check is skipped here.  Rows with zero weight get finite scores by default (the reference divides
+ *   by sqrt(w) = 0 at :107 and returns NaN for them; desc->reserved |= JCH_WOLD_REF_ZERO_WEIGHT_NAN reproduces that).
+ *   inplace = 1 hands back X, Y deflated AND carrying the row metric sqrt(w) (:57-58).
  * plssimp / plswold run their LDS-resident small-state kernels when q <= 16, p <= 2048 and the p x q state fits in LDS,
  * and a generic kernel (state in global memory, q <= 64, any p) otherwise; Float64 only. */
 JCH_API int32_t jch_plssimp_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,

@@ -16,6 +16,15 @@ __global__ __launch_bounds__(256) void k_fill_const(double *__restrict__ v, int 
     if (j < m) v[j] = c;
 }
 
+// plswold with JCH_WOLD_REF_ZERO_WEIGHT_NAN: the reference's `Tx .= (1 ./ sqrtw) .* Tx` (src/plswold.jl:107) turns the scores of a
+// zero-weight row into 0 * Inf = NaN
+__global__ __launch_bounds__(256) void k_nan_zero_weight_rows(double *__restrict__ T, int64_t n, int nlv, const double *__restrict__ d)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && d[i] == 0.0)
+        for (int a = 0; a < nlv; ++a) T[(size_t)i + (size_t)a * (size_t)n] = __builtin_nan("");
+}
+
 namespace {
 
 struct fit_io {
@@ -211,7 +220,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     if (!host && io.T) Tdev = io.T;
     else { JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)n * nlv_cap)); Tdev = (double *)ctx->tbuf.ptr; }
 
-    t_column_copier tcopy(ctx, (host && d.dtype == JCH_F64) ? io.T : nullptr, Tdev, n, nlv_cap);
+    t_column_copier tcopy(ctx, (host && d.dtype == JCH_F64 && !(algo == ALGO_WOLD && (d.reserved & JCH_WOLD_REF_ZERO_WEIGHT_NAN))) ? io.T : nullptr, Tdev, n, nlv_cap);
     const size_t small_bytes = 256 * 21 + sizeof(double) * 16 * 2048 + sizeof(double) * (64 + (size_t)p + (size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
                                                          (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128);
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
@@ -357,7 +366,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
 
     // ---- LV loop
     const size_t sweep_ev0 = ctx->ev_used;
-    const bool variant2 = d.reserved == 1;
+    const bool variant2 = (d.reserved & 1) != 0;
+    const bool wold_ref_nan = algo == ALGO_WOLD && (d.reserved & JCH_WOLD_REF_ZERO_WEIGHT_NAN) != 0;
     int x_reads = 0, x_writes = 0;   // plsnipals-shaped loops: whole passes over the working copy (profile: bytes actually moved)
     if (variant2) {   // OPT-IN kernel algorithm #2 (kern2.hip): Gram once, LV loop without X and without collectives
         if (algo != ALGO_KERN || !fast) return jch_fail(ctx, JCH_EINVAL, "%s: variant 2 needs plskern with q <= 16 and p <= %d", who, JCH_SWEEP_MAXP);
@@ -435,6 +445,10 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             }
         }
     }
+    }
+    if (wold_ref_nan) {   // (the overlapped column copies are off for this flag: the scores are edited after the loop)
+        hipLaunchKernelGGL(k_nan_zero_weight_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, Tdev, n, nlv, dn);
+        JCH_HIP(ctx, hipGetLastError());
     }
     if (algo == ALGO_ROSA) JCH_TRY(jch_launch_rosa_orthw(ctx, s.W, p, nlv));   // src/plsrosa.jl:77-79
     if (algo == ALGO_NIPALS || algo == ALGO_WOLD || algo == ALGO_ROSA) JCH_TRY(jch_launch_nipals_R(ctx, s, p, nlv));   // R = W inv(P'W)

@@ -222,13 +222,13 @@ def plsnipals_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optiona
     return _fit("jch_plsnipals_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
 
 
-def _copy_fit(entry, X, Y, weights, nlv, scal, ctx, wold=None):
+def _copy_fit(entry, X, Y, weights, nlv, scal, ctx, wold=None, variant=0):
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
         _addr_ld(X); _addr_ld(Y)
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
-    return _fit(entry, X, Y, weights, nlv, scal, False, ctx, wold=wold)
+    return _fit(entry, X, Y, weights, nlv, scal, False, ctx, wold=wold, variant=variant)
 
 
 def plssimp(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
@@ -254,16 +254,22 @@ def plsrosa_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[
 _SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
 
 
+WOLD_REF_ZERO_WEIGHT_NAN = 2   # include/jchemo_hip.h JCH_WOLD_REF_ZERO_WEIGHT_NAN
+
+
 def plswold(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,
-            ctx: Optional[Context] = None) -> Plsr:
-    """`plswold` — src/plswold.jl:30-34; `niter` (inner passes per LV) as :93."""
-    return _copy_fit("jch_plswold_fit", X, Y, weights, nlv, scal, ctx, wold=(tol, maxit))
+            zero_weight_nan: bool = False, ctx: Optional[Context] = None) -> Plsr:
+    """`plswold` — src/plswold.jl:30-34; `niter` (inner passes per LV) as :93.  `zero_weight_nan = True` reproduces the
+    reference's NaN scores for rows whose weight is 0 (:107); the default keeps them finite (t_i = x_i' r), which is what
+    lets a cross-validation fold be ONE weighted fit (gridcvlv)."""
+    return _copy_fit("jch_plswold_fit", X, Y, weights, nlv, scal, ctx, wold=(tol, maxit), variant=WOLD_REF_ZERO_WEIGHT_NAN if zero_weight_nan else 0)
 
 
 def plswold_(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,
-             ctx: Optional[Context] = None) -> Plsr:
+             zero_weight_nan: bool = False, ctx: Optional[Context] = None) -> Plsr:
     """`plswold!` — src/plswold.jl:36-111: X, Y end up centred/scaled, carrying the row metric sqrt(w) and deflated."""
-    return _fit("jch_plswold_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx, wold=(tol, maxit))
+    return _fit("jch_plswold_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx, wold=(tol, maxit),
+                variant=WOLD_REF_ZERO_WEIGHT_NAN if zero_weight_nan else 0)
 
 
 # ---------------------------------------------------------------------------------- accessors

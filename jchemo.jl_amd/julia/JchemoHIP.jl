@@ -150,7 +150,7 @@ for alg in (:plskern, :plsnipals, :plssimp, :plsrosa)
 end
 
 # sym: :plskern | :plsnipals | :plssimp | :plsrosa (one C signature) or :plswold (tol, maxit, niter in addition)
-function _fit(sym::Symbol, X, Y, weights, nlv, scal, inplace, ctx::JchCtx; tol = sqrt(eps(1.)), maxit = 200)
+function _fit(sym::Symbol, X, Y, weights, nlv, scal, inplace, ctx::JchCtx; tol = sqrt(eps(1.)), maxit = 200, options = 0)
     n, p = size(X); q = size(Y, 2)
     size(Y, 1) == n || throw(DimensionMismatch("X has $n rows, Y has $(size(Y, 1))"))
     # min(n, p, nlv) as src/plskern.jl:116 — exactly the columns the library fills on one GPU, so T is handed back as
@@ -159,7 +159,7 @@ function _fit(sym::Symbol, X, Y, weights, nlv, scal, inplace, ctx::JchCtx; tol =
     T = _similar(X, n, kmax); wn = _similar(X, n)
     P = zeros(p, kmax); R = zeros(p, kmax); W = zeros(p, kmax); C = zeros(q, kmax); TT = zeros(kmax)
     xm = zeros(p); xs = zeros(p); ym = zeros(q); ys = zeros(q); niter = zeros(kmax)
-    desc = Ref(PlsDesc(n, p, q, nlv, scal ? 1 : 0, 0, _loc(X), inplace ? 1 : 0, 0))
+    desc = Ref(PlsDesc(n, p, q, nlv, scal ? 1 : 0, 0, _loc(X), inplace ? 1 : 0, options))
     got = Ref{Int32}(0)
     GC.@preserve X Y weights T wn begin
         w = weights === nothing ? Ptr{Float64}(C_NULL) : pointer(weights)
@@ -222,10 +222,16 @@ plsrosa!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plsrosa, X, Y, _w(weights, X), nlv, scal, true, ctx)
 "`plswold` — src/plswold.jl:30-34; `niter` filled as :93."
 plswold(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
-    _fit(:plswold, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; tol = tol, maxit = maxit)
+    _fit(:plswold, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; tol = tol, maxit = maxit, options = _wold_options[])
 "`plswold!` — src/plswold.jl:36-111."
 plswold!(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
-    _fit(:plswold, X, Y, _w(weights, X), nlv, scal, true, ctx; tol = tol, maxit = maxit)
+    _fit(:plswold, X, Y, _w(weights, X), nlv, scal, true, ctx; tol = tol, maxit = maxit, options = _wold_options[])
+# jch_pls_desc.reserved for plswold: 0 (default) = finite scores for zero-weight rows (what a zero-weight CV fold needs);
+# 2 = JCH_WOLD_REF_ZERO_WEIGHT_NAN, the reference's NaN (src/plswold.jl:107).  A module switch, not a keyword: the keyword list of
+# `plswold` stays the reference's (src/plswold.jl:30-31), so higher-order callers can pass it through unchanged.
+const _wold_options = Ref{Int32}(0)
+"`wold_zero_weight_nan!(true)`: `plswold` gives rows with weight 0 NaN scores as the reference does; `false` (default): finite."
+wold_zero_weight_nan!(on::Bool) = (_wold_options[] = on ? Int32(2) : Int32(0); on)
 
 # out = ((X - 1*shift') ./ scale') * B .+ bias'   (shift, scale, B, bias on the host; X and out where X lives)
 function _affine(X, shift, scale, B::Matrix{Float64}, bias, ctx)

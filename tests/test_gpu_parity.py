@@ -1185,3 +1185,33 @@ def test_lwplsr_kspace_matches_pspace(case, J, ctx):
         tol_kp, tol_or = (1e-9, 1e-7) if a <= min(hi, 20) else (1e-4, 1e-4)
         assert e_kp < tol_kp, (a, e_kp)
         assert e_or < tol_or, (a, e_or)
+
+
+def test_plswold_zero_weight_rows_both_modes(J, ctx):
+    """src/plswold.jl:107 `Tx .= (1 ./ sqrtw) .* Tx`: the reference returns NaN scores for rows whose weight is 0 (0 * Inf).  Default
+    here: finite scores t_i = x_i' r for such rows (what zero-weight cross-validation folds need); `zero_weight_nan = True`
+    (desc->reserved |= JCH_WOLD_REF_ZERO_WEIGHT_NAN) reproduces the reference.  Everything else is identical in the two modes."""
+    n, p, q, nlv = 400, 30, 3, 5
+    X = O.rand_matrix(3, n, p); Y = O.rand_matrix(4, n, q)
+    w = 0.5 + O.splitmix64_uniform(11, 0, n)
+    zero = np.array([5, 17, 123, 399]); w[zero] = 0.0
+    a = J.plswold(X, Y, w, nlv=nlv, ctx=ctx)
+    b = J.plswold(X, Y, w, nlv=nlv, zero_weight_nan=True, ctx=ctx)
+    keep = np.ones(n, bool); keep[zero] = False
+    assert np.all(np.isfinite(a.T))
+    assert np.all(np.isnan(b.T[zero])) and np.all(np.isfinite(b.T[keep]))
+    assert np.array_equal(a.T[keep], b.T[keep])
+    for f in ("P", "R", "W", "C", "TT", "xmeans", "niter"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    # default mode: the scores of the zero-weight rows are their transformed rows
+    assert O.rel_fro(J.transform(a, X[zero], ctx=ctx), a.T[zero]) < 1e-10
+    # oracle (which mirrors the reference's arithmetic incl. the division by sqrt(w)) on the positive-weight rows
+    ref = O.plswold(X[keep], Y[keep], w[keep], nlv=nlv)
+    s = O.sign_align(ref.W, b.W)
+    assert O.rel_fro(ref.T, b.T[keep] * s) < 1e-8 and O.rel_fro(ref.P, b.P * s) < 1e-8
+    # device-resident inputs take the same path
+    import torch
+    Xd = J.colmajor_empty(n, p); Xd.copy_(torch.from_numpy(X)); Yd = J.colmajor_empty(n, q); Yd.copy_(torch.from_numpy(Y))
+    c = J.plswold(Xd, Yd, torch.from_numpy(w).cuda(), nlv=nlv, zero_weight_nan=True, ctx=ctx)
+    Tc = c.T.cpu().numpy()
+    assert np.all(np.isnan(Tc[zero])) and np.array_equal(Tc[keep], b.T[keep])
