@@ -46,12 +46,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 T
 README_PLSKERN_LVS = 25 / 8.100469   # README.md:90-91: plskern n=1e6 p=500 q=10 nlv=25 in 8.10 s (i9-10885H)
 
 
-PMC_FILE = "profiles/r02_pmc_sweep.json"
+PMC_FILE = "profiles/r03_pmc_sweep.json"
 
 
 def pmc_traffic(algo, n_local, p):
-    """HBM bytes per sweep launch from the COMMITTED PMC pass (profiles/r02_pmc_sweep.json: FETCH_SIZE x2 gfx950 correction
-    + WRITE_SIZE, separate rocprofv3 passes, tools/final_pmc_r02.sh), scaled by rows when this rank holds a different
+    """HBM bytes per sweep launch from the COMMITTED PMC pass (profiles/r03_pmc_sweep.json: FETCH_SIZE x2 gfx950 correction
+    + WRITE_SIZE, separate rocprofv3 passes, tools/final_profiles_r03.sh), scaled by rows when this rank holds a different
     share.  Not measured in the bench run itself (counters need the profiler); None for shapes without a committed pass."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
