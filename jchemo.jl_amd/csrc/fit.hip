@@ -2,6 +2,7 @@
 // Everything between the first and the last kernel of a fit is enqueued on ctx->stream with no host sync
 // (single GPU); a multi-GPU fit syncs once in the prologue to learn the global row count.
 #include <stdlib.h>
+#include <time.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -189,6 +190,11 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     ctx->ev_used = 0;
     ctx->prof = jch_profile{};
     jch_coll_reset(ctx);
+    // JCH_HOST_TIMING=1: host-side timeline of a fit on host arrays (stderr): where the wall time of the secondary metric goes
+    static const bool host_timing = getenv("JCH_HOST_TIMING") != nullptr;
+    auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tl0 = now_ms();
+    double tl_h2d = tl0, tl_enq = tl0, tl_sync = tl0;
 
     // ---- inputs on the device (column-major as handed over)
     double *Xc = (double *)io.X, *Yc = (double *)io.Y;
@@ -206,6 +212,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             wdev = (const double *)ctx->wstage.ptr;
         }
     }
+    if (host && host_timing) { (void)hipStreamSynchronize(ctx->stream); tl_h2d = now_ms(); }
     // ---- working copies and small state
     const int nlv_cap = (int)std::min<int64_t>(d.nlv, p);  // upper bound before the global-n clamp
     if (d.dtype == JCH_F64) {
@@ -474,7 +481,9 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             JCH_TRY(d2h_matrix(ctx, (double *)io.Y, Yc, n, q, io.ldy));
         }
     }
+    tl_enq = now_ms();
     JCH_TRY(fetch_small(nlv));   // (ends with the stream sync of the whole fit)
+    tl_sync = now_ms();
     if (tcopy.active() && !tcopy.finish(!variant2, nlv)) return jch_fail(ctx, JCH_EHIP, "%s: copying the scores to the host failed", who);
     JCH_TRY(jch_p2p_check(ctx));
     if (raw_mode && !(qual_host <= JCH_PIVOT_MAX_RATIO)) {
@@ -485,6 +494,9 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         return fit_impl(ctx, io, algo, false);
     }
     if (io.nlv_out) *io.nlv_out = nlv;
+    if (host && host_timing)
+        fprintf(stderr, "[jch] host-arrays fit: H2D %.1f ms | enqueue %.1f ms | device drain + small outputs %.1f ms | score columns still in flight %.1f ms | total %.1f ms\n",
+                tl_h2d - tl0, tl_enq - tl_h2d, tl_sync - tl_enq, now_ms() - tl_sync, now_ms() - tl0);
     if (s.dbg) {
         std::vector<double> h(nlv + 1);
         (void)hipMemcpy(h.data(), s.dbg, sizeof(double) * (nlv + 1), hipMemcpyDeviceToHost);
