@@ -54,14 +54,15 @@ __global__ __launch_bounds__(256) void k_to_rowmajor(const double *__restrict__ 
 #define KNN_RB 4        // 256-row chunks of the training scores in flight per trip
 #define KNN_CB 8        // score columns loaded together
 
-// bitonic sort of `cap` (a power of two <= KNN_CAP) (key, idx) pairs in LDS, ascending by (key, idx); 256 threads
+// bitonic sort of `cap` (a power of two <= KNN_CAP) (key, idx) pairs in LDS, ascending by (key, idx); NT threads
+template <int NT>
 __device__ static void bitonic_sort_n(double *key, int *idx, int cap)
 {
     const int tid = threadIdx.x;
     for (int size = 2; size <= cap; size <<= 1) {
         for (int stride = size >> 1, ls = 31 - __builtin_clz(size >> 1); stride > 0; stride >>= 1, --ls) {
             __syncthreads();
-            for (int t = tid; t < cap / 2; t += 256) {
+            for (int t = tid; t < cap / 2; t += NT) {
                 // (shifts, not t / stride and t % stride: a runtime integer division is ~40 instructions on this ISA and was
                 // 3/4 of the sort's time)
                 const int lo = ((t >> ls) << (ls + 1)) | (t & (stride - 1)), hi = lo + stride;
@@ -75,7 +76,6 @@ __device__ static void bitonic_sort_n(double *key, int *idx, int cap)
     }
     __syncthreads();
 }
-__device__ static void bitonic_sort_cap(double *key, int *idx) { bitonic_sort_n(key, idx, KNN_CAP); }
 __device__ __forceinline__ int knn_pow2_at_least(int v) { int c = 64; while (c < v) c <<= 1; return c; }
 
 struct knn_args {
@@ -91,36 +91,41 @@ struct knn_args {
     int *cidx;     // [m][nseg][k]
 };
 
-__global__ __launch_bounds__(256) void k_knn_scan(knn_args g)
+// NT threads per workgroup, QB queries per workgroup (every loaded training value serves QB queries).  <256, 4>: two workgroups
+// per CU (default); <512, 8> (round 3, JCH_KNN_WIDE=1): ONE workgroup of eight waves per CU — the same waves in flight, half the
+// L2 traffic (the kernel reads the whole score matrix once per query group: 16 MB x 250 groups at cfg5) — measured SLOWER, see the
+// launcher.
+template <int NT, int QB>
+__global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *bkey = lds;                                            // [QB][CAP]
-    int *bidx = reinterpret_cast<int *>(bkey + KNN_QB * KNN_CAP);  // [QB][CAP]
-    double *zq = reinterpret_cast<double *>(bidx + KNN_QB * KNN_CAP);  // [QB][dd]
-    double *tau = zq + KNN_QB * g.dd;                              // [QB]
-    int *cnt = reinterpret_cast<int *>(tau + KNN_QB);              // [QB]
+    int *bidx = reinterpret_cast<int *>(bkey + QB * KNN_CAP);  // [QB][CAP]
+    double *zq = reinterpret_cast<double *>(bidx + QB * KNN_CAP);  // [QB][dd]
+    double *tau = zq + QB * g.dd;                              // [QB]
+    int *cnt = reinterpret_cast<int *>(tau + QB);              // [QB]
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * KNN_QB;
-    const int nq = min(KNN_QB, g.m - q0);
-    for (int e = tid; e < KNN_QB * g.dd; e += 256) {
+    const int q0 = blockIdx.x * QB;
+    const int nq = min(QB, g.m - q0);
+    for (int e = tid; e < QB * g.dd; e += NT) {
         const int qq = e / g.dd, c = e - qq * g.dd;
         zq[e] = qq < nq ? g.Zq[(size_t)(q0 + qq) + (size_t)c * (size_t)g.ldzq] : 0.0;
     }
-    if (tid < KNN_QB) { tau[tid] = __builtin_inf(); cnt[tid] = 0; }
+    if (tid < QB) { tau[tid] = __builtin_inf(); cnt[tid] = 0; }
     __syncthreads();
     const int k = g.k;
-    // KNN_RB chunks of 256 training rows per trip: all their loads go out together (the kernel is bound by the latency of the
+    // KNN_RB chunks of NT training rows per trip: all their loads go out together (the kernel is bound by the latency of the
     // score matrix in L2 / MALL with 4 waves per CU), then the chunks are offered to the candidate buffers one after the
     // other, exactly as if they had been read one at a time (round 2: 4.1 -> 1.3 ms per 1000 queries at cfg5)
-    // this block's segment of the training rows (multiples of 256 rows; the last one takes the rest)
-    const int64_t seg_rows = ((g.n + g.nseg - 1) / g.nseg + 255) / 256 * 256;
+    // this block's segment of the training rows (multiples of NT rows; the last one takes the rest)
+    const int64_t seg_rows = ((g.n + g.nseg - 1) / g.nseg + NT - 1) / NT * NT;
     const int64_t row_lo = (int64_t)blockIdx.y * seg_rows, row_hi = min(g.n, row_lo + seg_rows);
-    for (int64_t base = row_lo; base < row_hi; base += 256 * KNN_RB) {
-        double d2[KNN_RB][KNN_QB];
+    for (int64_t base = row_lo; base < row_hi; base += NT * KNN_RB) {
+        double d2[KNN_RB][QB];
 #pragma unroll
         for (int r = 0; r < KNN_RB; ++r)
 #pragma unroll
-            for (int qq = 0; qq < KNN_QB; ++qq) d2[r][qq] = 0.0;
+            for (int qq = 0; qq < QB; ++qq) d2[r][qq] = 0.0;
         // KNN_CB score columns x KNN_RB row chunks = 32 loads per thread go out before the first is used (written as a plain
         // loop the compiler waited for each column's 4 loads before it issued the next: 20 round trips per trip instead of 3)
         for (int c0 = 0; c0 < g.dd; c0 += KNN_CB) {
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void k_knn_scan(knn_args g)
                 const size_t coff = (size_t)min(c0 + cc, g.dd - 1) * (size_t)g.ldzt;
 #pragma unroll
                 for (int r = 0; r < KNN_RB; ++r) {
-                    const int64_t i = base + 256 * r + tid;
+                    const int64_t i = base + NT * r + tid;
                     x[cc][r] = g.Zt[(size_t)(i < row_hi ? i : g.n - 1) + coff];
                 }
             }
@@ -140,19 +145,19 @@ __global__ __launch_bounds__(256) void k_knn_scan(knn_args g)
 #pragma unroll
                     for (int r = 0; r < KNN_RB; ++r)
 #pragma unroll
-                        for (int qq = 0; qq < KNN_QB; ++qq) { const double e = x[cc][r] - zq[qq * g.dd + c0 + cc]; d2[r][qq] += e * e; }
+                        for (int qq = 0; qq < QB; ++qq) { const double e = x[cc][r] - zq[qq * g.dd + c0 + cc]; d2[r][qq] += e * e; }
                 }
         }
 #pragma unroll
         for (int r = 0; r < KNN_RB; ++r) {
-            const int64_t i = base + 256 * r + tid;
-            if (base + 256 * r >= row_hi) break;            // block-uniform
-            double tq[KNN_QB];                               // one LDS round trip for the four bars instead of one per test
+            const int64_t i = base + NT * r + tid;
+            if (base + NT * r >= row_hi) break;            // block-uniform
+            double tq[QB];                               // one LDS round trip for the four bars instead of one per test
 #pragma unroll
-            for (int qq = 0; qq < KNN_QB; ++qq) tq[qq] = tau[qq];
+            for (int qq = 0; qq < QB; ++qq) tq[qq] = tau[qq];
             if (i < row_hi) {
 #pragma unroll
-                for (int qq = 0; qq < KNN_QB; ++qq)
+                for (int qq = 0; qq < QB; ++qq)
                     if (qq < nq && (d2[r][qq] < tq[qq] || (d2[r][qq] == tq[qq] && cnt[qq] < k))) {
                         const int pos = atomicAdd(&cnt[qq], 1);
                         bkey[qq * KNN_CAP + pos] = d2[r][qq];
@@ -160,18 +165,18 @@ __global__ __launch_bounds__(256) void k_knn_scan(knn_args g)
                     }
             }
             __syncthreads();
-            int cq[KNN_QB];
+            int cq[QB];
 #pragma unroll
-            for (int qq = 0; qq < KNN_QB; ++qq) cq[qq] = cnt[qq];
+            for (int qq = 0; qq < QB; ++qq) cq[qq] = cnt[qq];
             // every wave must have taken its snapshot before any wave's next chunk bumps the counters: the compaction
             // below contains barriers, so the decision has to be the same in all four waves
             __syncthreads();
 #pragma unroll
-            for (int qq = 0; qq < KNN_QB; ++qq) {
-                if (qq < nq && cq[qq] > KNN_CAP - 256) {   // compact: keep the k best, raise the bar (block-uniform decision)
+            for (int qq = 0; qq < QB; ++qq) {
+                if (qq < nq && cq[qq] > KNN_CAP - NT) {   // compact: keep the k best, raise the bar (block-uniform decision)
                     const int c0 = cq[qq];
-                    for (int e = c0 + tid; e < KNN_CAP; e += 256) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
-                    bitonic_sort_cap(bkey + qq * KNN_CAP, bidx + qq * KNN_CAP);
+                    for (int e = c0 + tid; e < KNN_CAP; e += NT) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
+                    bitonic_sort_n<NT>(bkey + qq * KNN_CAP, bidx + qq * KNN_CAP, KNN_CAP);
                     if (tid == 0) { cnt[qq] = k; tau[qq] = bkey[qq * KNN_CAP + k - 1]; }
                     __syncthreads();
                 }
@@ -184,11 +189,11 @@ __global__ __launch_bounds__(256) void k_knn_scan(knn_args g)
         const int cap = knn_pow2_at_least(c0);
         double *key = bkey + qq * KNN_CAP;
         int *idx = bidx + qq * KNN_CAP;
-        for (int e = c0 + tid; e < cap; e += 256) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
-        bitonic_sort_n(key, idx, cap);
+        for (int e = c0 + tid; e < cap; e += NT) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
+        bitonic_sort_n<NT>(key, idx, cap);
         double *ok = g.ckey + ((size_t)(q0 + qq) * g.nseg + blockIdx.y) * k;
         int *oi = g.cidx + ((size_t)(q0 + qq) * g.nseg + blockIdx.y) * k;
-        for (int e = tid; e < k; e += 256) { ok[e] = e < c0 ? key[e] : __builtin_inf(); oi[e] = e < c0 ? idx[e] : 0x7fffffff; }
+        for (int e = tid; e < k; e += NT) { ok[e] = e < c0 ? key[e] : __builtin_inf(); oi[e] = e < c0 ? idx[e] : 0x7fffffff; }
     }
 }
 
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
     const double *ck = g.ckey + (size_t)qi * ncand;
     const int *ci = g.cidx + (size_t)qi * ncand;
     for (int e = tid; e < cap; e += 256) { key[e] = e < ncand ? ck[e] : __builtin_inf(); idx[e] = e < ncand ? ci[e] : 0x7fffffff; }
-    bitonic_sort_n(key, idx, cap);
+    bitonic_sort_n<256>(key, idx, cap);
     const int kk = (int)min<int64_t>(k, g.n);
     int *oi = g.ind + (size_t)qi * k;
     double *od = g.dist + (size_t)qi * k, *ow = g.w + (size_t)qi * k;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
         key[e] = v;
         idx[e] = e;
     }
-    bitonic_sort_n(key, idx, cap2);
+    bitonic_sort_n<256>(key, idx, cap2);
     const double zmad = 1.4826 * ((kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]));
     const double cutoff = med + g.cri * zmad;
     __syncthreads();
@@ -734,19 +739,31 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         knn_args a;
         a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
         a.h = h; a.cri = 4.0; a.tol = tol; a.ind = dind; a.dist = ddist; a.w = dw;
-        const size_t lds = (sizeof(double) + sizeof(int)) * KNN_QB * KNN_CAP + sizeof(double) * (KNN_QB * (size_t)dd + KNN_QB) + sizeof(int) * KNN_QB + 64;
+        // JCH_KNN_WIDE=1 (measurement knob, round 3): eight queries per 512-thread workgroup — half the L2 traffic, the same waves per
+        // CU.  Measured at cfg5: 1.62 ms with 3 row segments, 1.05 with 2, against 0.87 for four queries per 256-thread workgroup:
+        // the scan is not bound by the L2 bytes but by its dependent steps (threshold tests, LDS appends, barriers, sorts), which
+        // eight waves share one candidate bookkeeping for.  Default: off.
+        const char *e_w = getenv("JCH_KNN_WIDE");
+        const bool wide = k <= KNN_CAP - 512 && e_w && atoi(e_w) == 1 && m > 4;
+        const int qb = wide ? 8 : KNN_QB, nt = wide ? 512 : 256;
+        const size_t lds = (sizeof(double) + sizeof(int)) * qb * KNN_CAP + sizeof(double) * (qb * (size_t)dd + qb) + sizeof(int) * qb + 64;
         if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: score dimension %lld too large", (long long)dd);
         // row segments: as many as keep every segment at >= 4 trips and the merged candidate lists inside one sort (nseg * k <= KNN_CAP)
         // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
         // its own compaction sorts)
-        int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_CAP / k), n / (4 * 256 * KNN_RB)));
+        int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_CAP / k), n / (4 * nt * KNN_RB)));
         if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_CAP / k));
         a.nseg = nseg;
         JCH_TRY(jch_reserve(ctx, ctx->gemm_b, (sizeof(double) + sizeof(int)) * (size_t)m * nseg * k + 256));
         a.ckey = (double *)ctx->gemm_b.ptr; a.cidx = (int *)(a.ckey + (size_t)m * nseg * k);
         static jch_per_device_once attr;
-        if (!attr.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.mark(ctx->device); }
-        hipLaunchKernelGGL(k_knn_scan, dim3((unsigned)((m + KNN_QB - 1) / KNN_QB), nseg), dim3(256), lds, ctx->stream, a);
+        if (!attr.done(ctx->device)) {
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<256, KNN_QB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr.mark(ctx->device);
+        }
+        if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8), nseg), dim3(512), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB), nseg), dim3(256), lds, ctx->stream, a);
         hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
     }
     ev2 = jch_ev(ctx);
