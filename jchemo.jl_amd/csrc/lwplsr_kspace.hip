@@ -16,7 +16,7 @@
 //     u = G0 d,  mm = d'u,   G x = G0 x - u (1'x) - 1 (u'x - mm 1'x),   g = -u + mm 1        (xq - pivot = 0)
 // (numpy prototype against the oracle at cfg5-like data: predictions equal to 4e-13 at 15 LVs, q = 1 and 3, scal on / off.)
 //
-// Layout: one 256-thread workgroup per query (four waves, one per SIMD, 512 registers each).  G0 is built on the matrix cores (v_mfma_f64_16x16x4, the SAME LDS operand
+// Layout: one 512-thread workgroup per query (eight waves, two per SIMD, 256 registers each).  G0 is built on the matrix cores (v_mfma_f64_16x16x4, the SAME LDS operand
 // array serves as A and as B: G0 is a SYRK) from 32-column stages of the gathered rows that are staged through LDS once and
 // shared by the four waves; its 16 x 16 tiles (upper triangle: 91 for 13 row blocks) never leave the accumulator registers —
 // every wave owns three or four whole block rows, 21 ... 24 tiles — and every later product G0 x is taken straight from
@@ -34,17 +34,20 @@
 #include "rowsum_dev.h"
 #include "lwplsr_dev.h"
 
-#define KS_NT 256        // threads per workgroup: 4 waves, ONE per SIMD (512 registers each)
-#define KS_NW 4
+#define KS_NT 512        // threads per workgroup: 8 waves, TWO per SIMD — a single wave can issue one v_mfma_f64_16x16x4 per 64
+                         // cycles, the matrix pipe takes one per 32 (tools/mfma_f64_rate.hip: 73 vs 157 TFLOP/s chip-wide), and the
+                         // second wave's products also cover the first one's LDS waits, stage stores and barriers
+#define KS_NW 8
+#define KS_SPC 2         // accumulator slots per tile class and wave: I = res + 8 i, i = 0, 1
 #define KS_KB 13         // 16-row blocks of the Gram matrix: k <= 208 (smaller k is zero-padded)
 #define KS_KP (16 * KS_KB)
 #define KS_ND 7          // tile classes delta = J - I (mod 13) = 0 .. 6: every unordered pair of row blocks exactly once
 #define KS_EXT (KS_KB + KS_ND - 1)   // row blocks of the cyclic extension (blocks 13 .. 18 repeat blocks 0 .. 5)
 #define KS_KPX (16 * KS_EXT)
 #define KS_RS (KS_KPX + 1)   // rows of an LDS stage block (odd: the 32-B lane pairs of a row store spread over all banks)
-#define KS_TPW (4 * KS_ND)   // accumulator slots per wave: slot 4 delta + i <-> tile (I = res_delta + 4 i, J = I + delta)
+#define KS_TPW (KS_SPC * KS_ND)   // accumulator slots per wave: slot 2 delta + i <-> tile (I = res_delta + 8 i, J = I + delta)
 #define KS_CS 16         // columns per LDS stage
-#define KS_NR 7          // load rounds per stage: 4 waves x 8 rows per round
+#define KS_NR 4          // load rounds per stage: 8 waves x 8 rows per round
 #define KS_MAXNLV 48
 
 // (The builtin, not inline asm: an asm statement hides the instruction from the compiler's hazard recognizer, and back-to-back
@@ -55,11 +58,11 @@ typedef double v2f64k __attribute__((ext_vector_type(2)));
 typedef double v4f64k __attribute__((ext_vector_type(4)));
 
 // Tile ownership.  The 91 tiles of the upper triangle are the pairs (I, (I + delta) mod 13), I = 0 .. 12, delta = 0 .. 6.  Class
-// delta is dealt to the waves by I: wave w owns the I with I mod 4 == (w - delta) mod 4, i.e. I = res + 4 i — 23 / 23 / 23 / 22
-// tiles, and (the point of the construction) tile coordinates that are the SAME compile-time offsets in every wave on top of
-// seven wave-dependent bases: one instruction stream for the four waves, every LDS address an immediate.  J = I + delta is
-// taken in the cyclic extension (blocks 13 .. 18 = blocks 0 .. 5), so no modulo appears in an address.
-__device__ __forceinline__ int ks_res(int wv, int delta) { return (wv - delta) & 3; }
+// delta is dealt to the waves by I: wave w owns the I with I mod 8 == (w - delta) mod 8, i.e. I = res + 8 i (i = 1 only for
+// res <= 4) — 11 or 12 tiles per wave, and (the point of the construction) tile coordinates that are the SAME compile-time offsets
+// in every wave on top of seven wave-dependent bases: one instruction stream for the eight waves, every LDS address an
+// immediate.  J = I + delta is taken in the cyclic extension (blocks 13 .. 18 = blocks 0 .. 5): no modulo in an address.
+__device__ __forceinline__ int ks_res(int wv, int delta) { return (wv - delta) & (KS_NW - 1); }
 
 __device__ __forceinline__ double ks_rowsum16(double v)   // sum over the 16 lanes of a DPP row, result in every lane
 {
@@ -102,8 +105,8 @@ __device__ __forceinline__ double ks_colsum4(double c0, double c1, double c2, do
     return c0;
 }
 
-// block sums of NV values (one partial per thread and value): in-wave sums, then the 4 wave partials through LDS in a fixed
-// order.  red: >= 4 * NV doubles.  Result valid in every thread.
+// block sums of NV values (one partial per thread and value): in-wave sums, then the 8 wave partials through LDS in a fixed
+// order.  red: >= 8 * NV doubles.  Result valid in every thread.
 template <int NV>
 __device__ __forceinline__ void ks_block_sums(double (&v)[NV], double *red)
 {
@@ -116,7 +119,8 @@ __device__ __forceinline__ void ks_block_sums(double (&v)[NV], double *red)
         for (int i = 0; i < NV; ++i) red[wv * NV + i] = v[i];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = (red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i]);
+    for (int i = 0; i < NV; ++i)
+        v[i] = ((red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i])) + ((red[4 * NV + i] + red[5 * NV + i]) + (red[6 * NV + i] + red[7 * NV + i]));
 }
 
 struct ks_lds {   // offsets in doubles
@@ -136,7 +140,7 @@ __host__ __device__ inline ks_lds ks_layout(int Q, int nlv)
     L.A = o; o += KS_KP * Q;
     L.H = o; o += KS_KP * Q;
     L.gv = o; o += KS_KP; L.uv = o; o += KS_KP; L.sv = o; o += KS_KP;
-    L.red = o; o += 4 * (Q * (Q + 1) / 2 + Q + 2) + 16;
+    L.red = o; o += 8 * (Q * (Q + 1) / 2 + Q + 2) + 16;
     L.ys = o; o += 4 * Q;
     L.vl = o; o += 16;
     L.eig = o; o += 5 * Q * (Q + 2) + 2 * (Q + 2) + 8;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
     int resd[KS_ND];                    // wave-dependent base row block (mod 4) of every tile class
 #pragma unroll
     for (int dlt = 0; dlt < KS_ND; ++dlt) resd[dlt] = ks_res(wv, dlt);
-    const int c8 = lane & 7, r8 = lane >> 3;   // stage-load role: column pair 2 c8 of row 8 wv + r8 (+ 32 per round)
+    const int c8 = lane & 7, r8 = lane >> 3;   // stage-load role: column pair 2 c8 of row 8 wv + r8 (+ 64 per round)
 
 #define KS_STAMP(i) do { if ((g.dbg & 2) && tid == 0 && blockIdx.x == 0 && qi == 0) sgl[i] = (double)wall_clock64(); } while (0)
     for (int qi = blockIdx.x; qi < g.m; qi += gridDim.x) {
@@ -235,20 +239,20 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
 #pragma unroll
                 for (int y = 0; y < Q; ++y) {
                     const double z = yrow[y] - ymean[y];
-                    Am[tid * Q + y] = (y < q && tid < k) ? dme * (g.scal ? z / ysd[y] : z) : 0.0;
+                    Am[y * KP + tid] = (y < q && tid < k) ? dme * (g.scal ? z / ysd[y] : z) : 0.0;
                 }
             if (tid < q && g.nlv_lo == 0) g.pred[((size_t)qi * le) * q + tid] = ymean[tid];   // nlv = 0: the intercept alone
         }
         __syncthreads();
 
-        // ---- gathered rows in 16-column stages: thread (wave, lane) owns column pair 2 c8 of rows 32 rr + 8 wv + r8
+        // ---- gathered rows in 16-column stages: thread (wave, lane) owns column pair 2 c8 of rows 64 rr + 8 wv + r8
         const int colst = 2 * c8;
         v2f64k xr[KS_NR], pv, sq = {1.0, 1.0};
         auto issue = [&](int cs) {
             const int col = min(KS_CS * cs + colst, ldr - 2);
 #pragma unroll
             for (int rr = 0; rr < KS_NR; ++rr) {
-                const int e = min(32 * rr + 8 * wv + r8, k - 1);
+                const int e = min(64 * rr + 8 * wv + r8, k - 1);
                 xr[rr] = *reinterpret_cast<const v2f64k *>(g.Xrm + (size_t)idx[e] * ldr + col);
             }
             pv.x = g.Xq[(size_t)qi + (size_t)min(col, p - 1) * (size_t)g.ldxq];
@@ -266,12 +270,12 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 v2f64k s1 = {0.0, 0.0}, s2 = {0.0, 0.0};
 #pragma unroll
                 for (int rr = 0; rr < KS_NR; ++rr) {
-                    const int e = 32 * rr + 8 * wv + r8;
+                    const int e = 64 * rr + 8 * wv + r8;
                     const double d = e < k ? dl[e] : 0.0;
                     const double zx = xr[rr].x - pv.x, zy = xr[rr].y - pv.y;
                     s1.x += d * zx; s1.y += d * zy; s2.x += d * zx * zx; s2.y += d * zy * zy;
                 }
-                // 32 partials per column (4 waves x 8 row groups) through the (still unused) stage area
+                // 64 partials per column (8 waves x 8 row groups) through the (still unused) stage area
                 double *cp = stage + ((wv * 8 + r8) * KS_CS + colst) * 2;
                 cp[0] = s1.x; cp[1] = s2.x; cp[2] = s1.y; cp[3] = s2.y;
                 __syncthreads();
@@ -291,8 +295,8 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             const bool c0 = col < p, c1 = col + 1 < p;
 #pragma unroll
             for (int rr = 0; rr < KS_NR; ++rr) {
-                const int e = 32 * rr + 8 * wv + r8;
-                if (e < KP) {                                     // (the seventh round covers rows 192 .. 223)
+                const int e = 64 * rr + 8 * wv + r8;
+                if (e < KP) {                                     // (the fourth round covers rows 192 .. 255)
                     v2f64k z;
                     z.x = (e < k && c0) ? xr[rr].x - pv.x : 0.0;
                     z.y = (e < k && c1) ? xr[rr].y - pv.y : 0.0;
@@ -314,19 +318,25 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             // serves as A and as B; tile (I, I + delta) reads row blocks res + 4 i and res + 4 i + delta (cyclic extension)
             {
                 const double *bl = buf + kap + (l15 << 2);
+                // the seven tiles every wave has (i = 0 of every class): one basic block of 28 products
 #pragma unroll
                 for (int ks = 0; ks < KS_CS / 4; ++ks) {
 #pragma unroll
                     for (int dlt = 0; dlt < KS_ND; ++dlt) {
                         const double *bd = bl + ks * (RS * 4) + resd[dlt] * 64;
+                        const double aI = bd[0], aJ = dlt ? bd[dlt * 64] : aI;
+                        KS_MFMA(acc[KS_SPC * dlt], aI, aJ);
+                    }
+                }
+                // the second tile of a class (row block res + 8) exists for res <= 4: four or five classes per wave
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const double aI = bd[i * 256], aJ = dlt ? bd[i * 256 + dlt * 64] : aI;
-                            KS_MFMA(acc[4 * dlt + i], aI, aJ);
-                        }
-                        if (resd[dlt] == 0) {                      // wave-uniform: row block 12 exists in the class only for res = 0
-                            const double aI = bd[3 * 256], aJ = dlt ? bd[3 * 256 + dlt * 64] : aI;
-                            KS_MFMA(acc[4 * dlt + 3], aI, aJ);
+                for (int dlt = 0; dlt < KS_ND; ++dlt) {
+                    if (resd[dlt] <= KS_KB - 1 - KS_NW) {           // wave-uniform
+                        const double *bd = bl + resd[dlt] * 64 + KS_NW * 64;
+#pragma unroll
+                        for (int ks = 0; ks < KS_CS / 4; ++ks) {
+                            const double aI = bd[ks * (RS * 4)], aJ = dlt ? bd[ks * (RS * 4) + dlt * 64] : aI;
+                            KS_MFMA(acc[KS_SPC * dlt + 1], aI, aJ);
                         }
                     }
                 }
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             if (job == 0) x = dl;
             else if (job <= q) {
                 if (tid < KP) {
-                    const double v = Am[tid * Q + (job - 1)];
+                    const double v = Am[(job - 1) * KP + tid];
                     xv[tid] = v;
                     if (tid < KS_KPX - KP) xv[KP + tid] = v;
                 }
@@ -361,26 +371,18 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 double nrm;
                 if constexpr (Q > 1) {
                     constexpr int NE = Q * (Q + 1) / 2;
-                    double ge[NE];
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) ge[e] = 0.0;
-                    if (tid < KP) {
-                        double ar[Q], hr[Q];
-#pragma unroll
-                        for (int y = 0; y < Q; ++y) { ar[y] = Am[tid * Q + y]; hr[y] = Hm[tid * Q + y]; }
-                        int e = 0;
-#pragma unroll
-                        for (int y1 = 0; y1 < Q; ++y1)
-#pragma unroll
-                            for (int y2 = y1; y2 < Q; ++y2) ge[e++] = 0.5 * (ar[y1] * hr[y2] + ar[y2] * hr[y1]);   // M = A'H, symmetrised
-                    }
-                    ks_block_sums<NE>(ge, red);
                     for (int e = tid; e < 5 * Q * lda; e += KS_NT) G0m[e] = 0.0;
                     __syncthreads();
-                    if (tid == 0) {
-                        int e = 0;
-                        for (int y1 = 0; y1 < Q; ++y1)
-                            for (int y2 = y1; y2 < Q; ++y2) { G0m[y1 * lda + y2] = ge[e]; G0m[y2 * lda + y1] = ge[e]; ++e; }
+                    // M = A'H, symmetrised: one wave per entry (y1, y2 >= y1) of the triangle, columns of A and H are contiguous in
+                    // LDS — no per-thread arrays next to the accumulators, a fixed summation order
+                    for (int e = wv; e < NE; e += KS_NW) {
+                        int y1 = 0, r = e;
+                        while (r >= Q - y1) { r -= Q - y1; ++y1; }
+                        const int y2 = y1 + r;
+                        double b = 0.0;
+                        for (int i = lane; i < KP; i += 64) b += Am[y1 * KP + i] * Hm[y2 * KP + i] + Am[y2 * KP + i] * Hm[y1 * KP + i];
+                        b = 0.5 * ks_wave_sum(b);
+                        if (lane == 0) { G0m[y1 * lda + y2] = b; G0m[y2 * lda + y1] = b; }
                     }
                     __syncthreads();
                     if (wv == 0) {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                     if constexpr (Q == 1) { o = Am[tid]; sv_ = Hm[tid]; }
                     else {
 #pragma unroll
-                        for (int y = 0; y < Q; ++y) { o += Am[tid * Q + y] * vl[y]; sv_ += Hm[tid * Q + y] * vl[y]; }
+                        for (int y = 0; y < Q; ++y) { o += Am[y * KP + tid] * vl[y]; sv_ += Hm[y * KP + tid] * vl[y]; }
                     }
                     o /= nrm; sv_ /= nrm;
                     sv[tid] = sv_;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 double sc_[Q + 1];
                 sc_[Q] = dte * tme;
 #pragma unroll
-                for (int y = 0; y < Q; ++y) sc_[y] = tid < KP ? Am[tid * Q + y] * tme : 0.0;
+                for (int y = 0; y < Q; ++y) sc_[y] = tid < KP ? Am[y * KP + tid] * tme : 0.0;
                 ks_block_sums<Q + 1>(sc_, red);
                 const double tt = sc_[Q];
                 if (tid == 0) { tth[a] = tt; tauh[a] = tau; }
@@ -462,74 +464,63 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             for (int i = lane; i < KP; i += 64) { const double xi = x[i]; px += xi; pu += uv[i] * xi; }
             const double sx = ks_wave_sum(px), ux = ks_wave_sum(pu);
             // the wave's share, straight from the accumulator registers (D layout: lane (kap, l15), register reg holds
-            // G0[16 I + kap + 4 reg][16 J + l15]).  Rows of block I: the tiles (I, J) x_J of classes delta and delta + 4 share their I
-            // and are accumulated first, then ONE transposing 16-lane reduction per group (ypR[wave][group g = delta & 3, i]);
-            // rows of block J: the tile is also G0[J][I]' — four registers against x_I, then the four lane rows, four tiles per
-            // permlane reduction (ypC[wave][slot]).  Slots with i = 3 exist for res = 0 only: their registers stay zero otherwise.
+            // G0[16 I + kap + 4 reg][16 J + l15]).  Rows of block I from G0[I][J] x_J: ONE transposing 16-lane reduction for the four
+            // registers (ypR[wave][slot]); rows of block J from the tile's columns against x_I (it is also G0[J][I]'): four
+            // registers, then the four lane rows, four tiles per permlane reduction (ypC[wave][slot]).
             {
                 double *pR = ypR + wv * (KS_TPW * 16), *pC = ypC + wv * (KS_TPW * 16);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {               // classes gq and gq + 4 have the same res, hence the same I
-                        if (i == 3 && resd[gq] != 0) continue;     // (wave-uniform) no such tile: its x entries would lie past the vector
-                        const double *xb = x + resd[gq] * 16 + 64 * i;
-                        double r[4];
-                        {
-                            const double xJ = xb[gq * 16 + l15];
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) r[reg] = acc[4 * gq + i][reg] * xJ;
-                        }
-                        if (gq + 4 < KS_ND) {
-                            const double xJ = xb[(gq + 4) * 16 + l15];
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) r[reg] += acc[4 * (gq + 4) + i][reg] * xJ;
-                        }
-                        const double t = ks_rowsum16x4(r, l15);
-                        if ((l15 & 3) == 0) pR[(4 * gq + i) * 16 + kap + 4 * (2 * ((l15 >> 2) & 1) + (l15 >> 3))] = t;
-                    }
-                }
                 double cp[KS_TPW];
 #pragma unroll
-                for (int dlt = 1; dlt < KS_ND; ++dlt)
+                for (int dlt = 0; dlt < KS_ND; ++dlt) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double *xb = x + resd[dlt] * 16 + 64 * i + kap;
-                        double c = 0.0;
-                        if (i < 3 || resd[dlt] == 0) {             // (wave-uniform)
+                    for (int i = 0; i < KS_SPC; ++i) {
+                        const int s_ = KS_SPC * dlt + i;
+                        cp[s_] = 0.0;
+                        if (i == 0 || resd[dlt] <= KS_KB - 1 - KS_NW) {     // (wave-uniform) the tile exists
+                            const double *xb = x + resd[dlt] * 16 + (KS_NW * 16) * i;
+                            const double xJ = xb[dlt * 16 + l15];
+                            double r[4];
 #pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) c += acc[4 * dlt + i][reg] * xb[4 * reg];
+                            for (int reg = 0; reg < 4; ++reg) r[reg] = acc[s_][reg] * xJ;
+                            const double t = ks_rowsum16x4(r, l15);
+                            if ((l15 & 3) == 0) pR[s_ * 16 + kap + 4 * (2 * ((l15 >> 2) & 1) + (l15 >> 3))] = t;
+                            if (dlt) {
+                                double c = 0.0;
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) c += acc[s_][reg] * xb[kap + 4 * reg];
+                                cp[s_] = c;
+                            }
                         }
-                        cp[4 * dlt + i] = c;
                     }
+                }
 #pragma unroll
-                for (int dlt = 1; dlt < KS_ND; ++dlt) {            // the class's four tiles in one reduction: rows hold i = 0, 2, 1, 3
-                    const double c = ks_colsum4(cp[4 * dlt], cp[4 * dlt + 1], cp[4 * dlt + 2], cp[4 * dlt + 3]);
-                    pC[(4 * dlt + ((kap & 1) * 2 + (kap >> 1))) * 16 + l15] = c;
+                for (int dlt = 1; dlt < KS_ND; dlt += 2) {         // classes dlt, dlt + 1: four tiles per reduction; rows hold c0, c2, c1, c3
+                    const double c = ks_colsum4(cp[KS_SPC * dlt], cp[KS_SPC * dlt + 1], cp[KS_SPC * (dlt + 1)], cp[KS_SPC * (dlt + 1) + 1]);
+                    pC[(KS_SPC * (dlt + (kap & 1)) + (kap >> 1)) * 16 + l15] = c;
                 }
             }
             __syncthreads();
             if (tid < KP) {
-                // entry 16 I + ml of G0 x: the seven tiles (I, I + delta) of its row block (four partials: classes delta and delta + 4
-                // were combined by their owner) and the six tiles (I - delta, I) that reach it transposed — 10 terms, fixed order
+                // entry 16 I + ml of G0 x: the seven tiles (I, I + delta) of its row block and the six tiles (I - delta, I) that reach
+                // it transposed, each from its owner wave (I + delta) mod 8 — 13 terms in a fixed order (deterministic)
                 const int I = tid >> 4, ml = tid & 15;
                 double v = 0.0;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) v += ypR[(((I + gq) & 3) * KS_TPW + 4 * gq + (I >> 2)) * 16 + ml];   // owner of (I, delta): wave (I + delta) mod 4
+                for (int dlt = 0; dlt < KS_ND; ++dlt) v += ypR[(((I + dlt) & (KS_NW - 1)) * KS_TPW + KS_SPC * dlt + (I >> 3)) * 16 + ml];
 #pragma unroll
                 for (int dlt = 1; dlt < KS_ND; ++dlt) {
                     const int Ip = I - dlt + (I < dlt ? KS_KB : 0);
-                    v += ypC[(((Ip + dlt) & 3) * KS_TPW + 4 * dlt + (Ip >> 2)) * 16 + ml];
+                    v += ypC[(((Ip + dlt) & (KS_NW - 1)) * KS_TPW + KS_SPC * dlt + (Ip >> 3)) * 16 + ml];
                 }
                 if (job > 0) v = v - uv[tid] * sx - (ux - mm * sx);                       // G x = G0 x - u (1'x) - 1 (u'x - mm 1'x)
                 v = tid < k ? v : 0.0;
                 if (job == 0) uv[tid] = v;
-                else if (job <= q) Hm[tid * Q + (job - 1)] = v;
+                else if (job <= q) Hm[(job - 1) * KP + tid] = v;
                 else {
 #pragma unroll
                     for (int y = 0; y < Q; ++y) {      // deflation: A <- A - (D t) c', H <- H - (G D t) c'
-                        Am[tid * Q + y] -= dte * cvec[y];
-                        Hm[tid * Q + y] -= v * cvec[y];
+                        Am[y * KP + tid] -= dte * cvec[y];
+                        Hm[y * KP + tid] -= v * cvec[y];
                     }
                 }
             }
@@ -540,7 +531,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 mm = t1[0];
                 if (tid < KP) gv[tid] = tid < k ? mm - uv[tid] : 0.0;
 #pragma unroll 1
-                for (int y = q; y < Q; ++y) if (tid < KP) Hm[tid * Q + y] = 0.0;
+                for (int y = q; y < Q; ++y) if (tid < KP) Hm[y * KP + tid] = 0.0;
             }
             __syncthreads();
         }
