@@ -38,14 +38,14 @@
                          // cycles, the matrix pipe takes one per 32 (tools/mfma_f64_rate.hip: 73 vs 157 TFLOP/s chip-wide), and the
                          // second wave's products also cover the first one's LDS waits, stage stores and barriers
 #define KS_NW 8
-#define KS_SPC 2         // accumulator slots per tile class and wave: I = res + 8 i, i = 0, 1
 #define KS_KB 13         // 16-row blocks of the Gram matrix: k <= 208 (smaller k is zero-padded)
 #define KS_KP (16 * KS_KB)
 #define KS_ND 7          // tile classes delta = J - I (mod 13) = 0 .. 6: every unordered pair of row blocks exactly once
 #define KS_EXT (KS_KB + KS_ND - 1)   // row blocks of the cyclic extension (blocks 13 .. 18 repeat blocks 0 .. 5)
 #define KS_KPX (16 * KS_EXT)
 #define KS_RS (KS_KPX + 1)   // rows of an LDS stage block (odd: the 32-B lane pairs of a row store spread over all banks)
-#define KS_TPW (KS_SPC * KS_ND)   // accumulator slots per wave: slot 2 delta + i <-> tile (I = res_delta + 8 i, J = I + delta)
+#define KS_TPW 12        // accumulator slots per wave: its 11 or 12 tiles in the order of their row blocks
+#define KS_AD 4          // operand pairs in flight ahead of their product
 #define KS_CS 16         // columns per LDS stage
 #define KS_NR 4          // load rounds per stage: 8 waves x 8 rows per round
 #define KS_MAXNLV 48
@@ -57,12 +57,48 @@
 typedef double v2f64k __attribute__((ext_vector_type(2)));
 typedef double v4f64k __attribute__((ext_vector_type(4)));
 
-// Tile ownership.  The 91 tiles of the upper triangle are the pairs (I, (I + delta) mod 13), I = 0 .. 12, delta = 0 .. 6.  Class
-// delta is dealt to the waves by I: wave w owns the I with I mod 8 == (w - delta) mod 8, i.e. I = res + 8 i (i = 1 only for
-// res <= 4) — 11 or 12 tiles per wave, and (the point of the construction) tile coordinates that are the SAME compile-time offsets
-// in every wave on top of seven wave-dependent bases: one instruction stream for the eight waves, every LDS address an
-// immediate.  J = I + delta is taken in the cyclic extension (blocks 13 .. 18 = blocks 0 .. 5): no modulo in an address.
-__device__ __forceinline__ int ks_res(int wv, int delta) { return (wv - delta) & (KS_NW - 1); }
+// Tile ownership.  The 91 tiles of the upper triangle are the pairs (I, J = I + delta), I = 0 .. 12, delta = 0 .. 6, J taken in the
+// cyclic extension (blocks 13 .. 18 = blocks 0 .. 5).  Wave w owns the COLUMN blocks J = w, w + 8, w + 16: among the seven J of a
+// row block I at most one is congruent to w mod 8, so wave w has the tile (I, I + (w - I) mod 8) of every row block I except
+// I = e1 = (w + 1) mod 8 and I = e1 + 8 (where (w - I) mod 8 = 7): 11 tiles (e1 <= 4) or 12, 23 / 23 / 23 / 22 per SIMD (waves
+// w and w + 4).  Slot r of a wave is its r-th tile in the order of I; the LDS addresses of a slot's two operands are per-wave
+// values kept in registers, so ONE instruction stream serves the eight waves and nothing but the operand reads sits between
+// the products.  That matters on this chip: v_mfma_f64_16x16x4 occupies the SIMD for 64 cycles (78 TFLOP/s chip-wide, the
+// vector f64 rate: tools/mfma_f64_rate2.hip) and vector instructions do NOT run beside it — a 64-bit select per product costs
+// 17 cycles, a v_add_f64 12, an LDS read 2 .. 7 — whatever sits between the products is paid in full.
+__device__ __forceinline__ int ks_e1(int w) { return (w + 1) & (KS_NW - 1); }
+__device__ __forceinline__ int ks_ntiles(int w) { return ks_e1(w) + 8 < KS_KB ? KS_TPW - 1 : KS_TPW; }
+__device__ __forceinline__ int ks_slot_I(int w, int r) { const int e1 = ks_e1(w); int I = r; if (I >= e1) ++I; if (I >= e1 + 8) ++I; return I; }
+__device__ __forceinline__ int ks_slot_J(int w, int I) { return I + ((w - I) & (KS_NW - 1)); }
+__device__ __forceinline__ int ks_rank(int w, int I) { const int e1 = ks_e1(w); return I - (I > e1 ? 1 : 0) - (I > e1 + 8 ? 1 : 0); }   // slot of row block I in wave w
+
+typedef double v4f64k_ __attribute__((ext_vector_type(4)));
+// NKS k-steps (4 columns each) of one LDS stage: G0 tile (I, J) += Z[rows of I][cols] Z[rows of J][cols]'.  pa[r] / pb[r]: the LDS
+// address of slot r's row blocks I / J in this stage buffer + the lane part (kap + 4 l15: operand lane (m = l15 -> row, kap ->
+// column)); the same array serves as A and as B (SYRK).  The 11 slots every wave has run as one software-pipelined stream with
+// KS_AD operand pairs in flight; the twelfth (waves 4 .. 6) follows under a wave-uniform branch.
+template <int NKS>
+__device__ __forceinline__ void ks_gram(v4f64k_ (&acc)[KS_TPW], const double *const (&pa)[KS_TPW], const double *const (&pb)[KS_TPW], bool has12, int koff)
+{
+    constexpr int NM = KS_TPW - 1, NP = NKS * NM, KST = KS_RS * 4;
+    double aq[KS_AD], bq[KS_AD];
+#pragma unroll
+    for (int n = 0; n < KS_AD && n < NP; ++n) { aq[n] = pa[n % NM][koff + (n / NM) * KST]; bq[n] = pb[n % NM][koff + (n / NM) * KST]; }
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const double a = aq[n % KS_AD], b = bq[n % KS_AD];
+        if (n + KS_AD < NP) {
+            aq[n % KS_AD] = pa[(n + KS_AD) % NM][koff + ((n + KS_AD) / NM) * KST];
+            bq[n % KS_AD] = pb[(n + KS_AD) % NM][koff + ((n + KS_AD) / NM) * KST];
+        }
+        acc[n % NM] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[n % NM], 0, 0, 0);
+    }
+    if (has12) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            acc[NM] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[NM][koff + ks * KST], pb[NM][koff + ks * KST], acc[NM], 0, 0, 0);
+    }
+}
 
 __device__ __forceinline__ double ks_rowsum16(double v)   // sum over the 16 lanes of a DPP row, result in every lane
 {
@@ -103,6 +139,37 @@ __device__ __forceinline__ double ks_colsum4(double c0, double c1, double c2, do
     jch_fold32(c2, c3);
     jch_fold16(c0, c2);
     return c0;
+}
+
+// The wave's share of y = G0 x, straight from the accumulator registers (D layout: lane (kap, l15), register reg of the slot of
+// tile (I, J) holds G0[16 I + kap + 4 reg][16 J + l15]).  Rows of block I from G0[I][J] x_J: ONE transposing 16-lane reduction for
+// the four registers (pR[slot]); rows of block J from the tile's columns against x_I (it is also G0[J][I]'): four registers, then
+// the four lane rows, four tiles per permlane reduction (pC[slot]).  x carries the cyclic extension.
+__device__ __forceinline__ void ks_matvec(const v4f64k_ (&acc)[KS_TPW], const double *x, double *pR, double *pC, int wv, int kap, int l15)
+{
+    const int nt = ks_ntiles(wv);
+    const int rrow = kap + 4 * (2 * ((l15 >> 2) & 1) + (l15 >> 3));   // the row whose total ks_rowsum16x4 leaves in this lane
+    double cp[KS_TPW];
+#pragma unroll
+    for (int r = 0; r < KS_TPW; ++r) {
+        const bool valid = r < nt;                                  // (wave-uniform; an unused slot holds zeros)
+        const int I = valid ? ks_slot_I(wv, r) : 0, J = valid ? ks_slot_J(wv, I) : 0;
+        const double xJ = x[J * 16 + l15];
+        double q4[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) q4[reg] = acc[r][reg] * xJ;
+        const double t = ks_rowsum16x4(q4, l15);
+        if ((l15 & 3) == 0) pR[r * 16 + rrow] = t;
+        double c = 0.0;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) c += acc[r][reg] * x[I * 16 + kap + 4 * reg];
+        cp[r] = J == I ? 0.0 : c;                                   // (a diagonal tile is its own transpose)
+    }
+#pragma unroll
+    for (int gq = 0; gq < KS_TPW / 4; ++gq) {                       // four tiles per reduction; lane rows hold c0, c2, c1, c3
+        const double c = ks_colsum4(cp[4 * gq], cp[4 * gq + 1], cp[4 * gq + 2], cp[4 * gq + 3]);
+        pC[(4 * gq + (((kap & 1) << 1) | (kap >> 1))) * 16 + l15] = c;
+    }
 }
 
 // block sums of NV values (one partial per thread and value): in-wave sums, then the 8 wave partials through LDS in a fixed
@@ -172,10 +239,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
     const int nlvloc = min(min(k, p), g.nlv_hi);
     const int nstage = (ldr + KS_CS - 1) / KS_CS;
     double *sgl = g.scratch + (size_t)blockIdx.x * g.slab;   // [ldr] local column stds (scal only)
-    v4f64k acc[KS_TPW];
-    int resd[KS_ND];                    // wave-dependent base row block (mod 4) of every tile class
-#pragma unroll
-    for (int dlt = 0; dlt < KS_ND; ++dlt) resd[dlt] = ks_res(wv, dlt);
+    v4f64k_ acc[KS_TPW];
     const int c8 = lane & 7, r8 = lane >> 3;   // stage-load role: column pair 2 c8 of row 8 wv + r8 (+ 64 per round)
 
 #define KS_STAMP(i) do { if ((g.dbg & 2) && tid == 0 && blockIdx.x == 0 && qi == 0) sgl[i] = (double)wall_clock64(); } while (0)
@@ -248,13 +312,13 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
         // ---- gathered rows in 16-column stages: thread (wave, lane) owns column pair 2 c8 of rows 64 rr + 8 wv + r8
         const int colst = 2 * c8;
         v2f64k xr[KS_NR], pv, sq = {1.0, 1.0};
+        const double *rowp[KS_NR];             // the thread's four rows (rows beyond k: the last one again — they meet zero weights only)
+#pragma unroll
+        for (int rr = 0; rr < KS_NR; ++rr) rowp[rr] = g.Xrm + (size_t)idx[min(64 * rr + 8 * wv + r8, k - 1)] * ldr;
         auto issue = [&](int cs) {
             const int col = min(KS_CS * cs + colst, ldr - 2);
 #pragma unroll
-            for (int rr = 0; rr < KS_NR; ++rr) {
-                const int e = min(64 * rr + 8 * wv + r8, k - 1);
-                xr[rr] = *reinterpret_cast<const v2f64k *>(g.Xrm + (size_t)idx[e] * ldr + col);
-            }
+            for (int rr = 0; rr < KS_NR; ++rr) xr[rr] = *reinterpret_cast<const v2f64k *>(rowp[rr] + col);
             pv.x = g.Xq[(size_t)qi + (size_t)min(col, p - 1) * (size_t)g.ldxq];
             pv.y = g.Xq[(size_t)qi + (size_t)min(col + 1, p - 1) * (size_t)g.ldxq];
             if (g.scal) {   // written by other waves of this workgroup a moment ago: agent-scope loads (not through this CU's L1)
@@ -289,8 +353,11 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             }
         }
 #pragma unroll
-        for (int s = 0; s < KS_TPW; ++s) acc[s] = v4f64k{0.0, 0.0, 0.0, 0.0};
-        auto put = [&](int cs, double *buf) {   // registers -> LDS stage [column quad][row][4], rows about the pivot (and scaled)
+        for (int s = 0; s < KS_TPW; ++s) acc[s] = v4f64k_{0.0, 0.0, 0.0, 0.0};
+        // registers -> LDS stage [column quad][row][4], rows about the pivot (and scaled).  Columns >= p (last stage only) are
+        // zeroed; rows >= k are NOT (copies of row k - 1): every vector they meet is zero there, and so is every output
+        auto put = [&](int cs, double *buf, auto last_) {
+            constexpr bool last = decltype(last_)::value;
             const int col = KS_CS * cs + colst;
             const bool c0 = col < p, c1 = col + 1 < p;
 #pragma unroll
@@ -298,8 +365,9 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 const int e = 64 * rr + 8 * wv + r8;
                 if (e < KP) {                                     // (the fourth round covers rows 192 .. 255)
                     v2f64k z;
-                    z.x = (e < k && c0) ? xr[rr].x - pv.x : 0.0;
-                    z.y = (e < k && c1) ? xr[rr].y - pv.y : 0.0;
+                    z.x = xr[rr].x - pv.x;
+                    z.y = xr[rr].y - pv.y;
+                    if (last) { z.x = c0 ? z.x : 0.0; z.y = c1 ? z.y : 0.0; }
                     if (g.scal) { z.x /= sq.x; z.y /= sq.y; }     // (uniform branch: no divisions on the scal = false path)
                     double *dst = buf + (((c8 >> 1) * RS + e) << 2) + 2 * (c8 & 1);
                     *reinterpret_cast<v2f64k *>(dst) = z;
@@ -308,51 +376,47 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             }
         };
         KS_STAMP(1);
-        issue(0);
-        put(0, stage);
-        if (nstage > 1) issue(1);
-        __syncthreads();
-        for (int cs = 0; cs < nstage; ++cs) {
-            const double *buf = stage + (cs & 1) * ((KS_CS / 4) * RS * 4);
-            // G0 += Z_stage Z_stage': 4 k-steps of 4 columns; operand lane (m = l15 -> row, kap -> column), the same LDS array
-            // serves as A and as B; tile (I, I + delta) reads row blocks res + 4 i and res + 4 i + delta (cyclic extension)
-            {
-                const double *bl = buf + kap + (l15 << 2);
-                // the seven tiles every wave has (i = 0 of every class): one basic block of 28 products
+        {
+            const bool has12 = ks_ntiles(wv) == KS_TPW;
+            const double *pa[KS_TPW], *pb[KS_TPW];                 // operand addresses of the slots in the current stage buffer
 #pragma unroll
-                for (int ks = 0; ks < KS_CS / 4; ++ks) {
-#pragma unroll
-                    for (int dlt = 0; dlt < KS_ND; ++dlt) {
-                        const double *bd = bl + ks * (RS * 4) + resd[dlt] * 64;
-                        const double aI = bd[0], aJ = dlt ? bd[dlt * 64] : aI;
-                        KS_MFMA(acc[KS_SPC * dlt], aI, aJ);
-                    }
-                }
-                // the second tile of a class (row block res + 8) exists for res <= 4: four or five classes per wave
-#pragma unroll
-                for (int dlt = 0; dlt < KS_ND; ++dlt) {
-                    if (resd[dlt] <= KS_KB - 1 - KS_NW) {           // wave-uniform
-                        const double *bd = bl + resd[dlt] * 64 + KS_NW * 64;
-#pragma unroll
-                        for (int ks = 0; ks < KS_CS / 4; ++ks) {
-                            const double aI = bd[ks * (RS * 4)], aJ = dlt ? bd[ks * (RS * 4) + dlt * 64] : aI;
-                            KS_MFMA(acc[KS_SPC * dlt + 1], aI, aJ);
-                        }
-                    }
-                }
+            for (int r = 0; r < KS_TPW; ++r) {
+                const int I = r < ks_ntiles(wv) ? ks_slot_I(wv, r) : 0, J = r < ks_ntiles(wv) ? ks_slot_J(wv, I) : 0;
+                pa[r] = stage + kap + (l15 << 2) + I * 64;
+                pb[r] = stage + kap + (l15 << 2) + J * 64;
             }
-            if (cs + 1 < nstage) {
-                put(cs + 1, stage + ((cs + 1) & 1) * ((KS_CS / 4) * RS * 4));   // (its loads were issued a stage ago)
-                if (cs + 2 < nstage) issue(cs + 2);
+            constexpr int STG = (KS_CS / 4) * RS * 4;              // doubles per stage buffer
+            issue(0);
+            if (nstage > 1) put(0, stage, std::false_type{}); else put(0, stage, std::true_type{});
+            if (nstage > 1) issue(1);
+            __syncthreads();
+            for (int cs = 0; cs + 1 < nstage; ++cs) {
+                ks_gram<KS_CS / 4>(acc, pa, pb, has12, 0);          // G0 += Z_stage Z_stage': 4 k-steps of 4 columns
+                double *nb = stage + ((cs + 1) & 1) * STG;
+                if (cs + 2 < nstage) { put(cs + 1, nb, std::false_type{}); issue(cs + 2); }   // (its loads were issued a stage ago)
+                else put(cs + 1, nb, std::true_type{});
+                const int d = (cs & 1) ? -STG : STG;
+#pragma unroll
+                for (int r = 0; r < KS_TPW; ++r) { pa[r] += d; pb[r] += d; }
+                __syncthreads();
+            }
+            {                                                       // the last stage: only the k-steps that hold columns < p
+                const int nks = (ldr - KS_CS * (nstage - 1) + 3) >> 2;
+#pragma unroll 1
+                for (int ks = 0; ks < nks; ++ks) ks_gram<1>(acc, pa, pb, has12, ks * (RS * 4));
             }
             __syncthreads();
         }
 
-        // ---- everything else runs on G0 in the registers.  ONE product site, driven by a job counter:
-        //   job 0: u = G0 d (raw), then mm = d'u, g = mm - u;  jobs 1 .. q: H[:, y] = G A[:, y];  job q + 1 + a: LV a — scores,
-        //   loadings, prediction, then z = G (D t) for the deflation of H
+        // (The thread index is laundered through an empty asm here: every address of the latent-variable phase derives from it,
+        // and the compiler otherwise computes them all ONCE before the query loop — some 80 registers held through the Gram
+        // phase, which then spilled its stage loads.)
+        int tid_lv = threadIdx.x;
+        asm volatile("" : "+v"(tid_lv));
         double mm = 0.0, tme = 0.0, dte = 0.0;
         KS_STAMP(2);
+        {
+        const int tid = tid_lv, lane = tid & 63, kap = lane >> 4, l15 = lane & 15;
         for (int job = 0;; ++job) {
             if (job == q + 1) KS_STAMP(3);
             if (job == q + 2) KS_STAMP(4);
@@ -463,54 +527,23 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             double px = 0.0, pu = 0.0;
             for (int i = lane; i < KP; i += 64) { const double xi = x[i]; px += xi; pu += uv[i] * xi; }
             const double sx = ks_wave_sum(px), ux = ks_wave_sum(pu);
-            // the wave's share, straight from the accumulator registers (D layout: lane (kap, l15), register reg holds
-            // G0[16 I + kap + 4 reg][16 J + l15]).  Rows of block I from G0[I][J] x_J: ONE transposing 16-lane reduction for the four
-            // registers (ypR[wave][slot]); rows of block J from the tile's columns against x_I (it is also G0[J][I]'): four
-            // registers, then the four lane rows, four tiles per permlane reduction (ypC[wave][slot]).
             {
                 double *pR = ypR + wv * (KS_TPW * 16), *pC = ypC + wv * (KS_TPW * 16);
-                double cp[KS_TPW];
-#pragma unroll
-                for (int dlt = 0; dlt < KS_ND; ++dlt) {
-#pragma unroll
-                    for (int i = 0; i < KS_SPC; ++i) {
-                        const int s_ = KS_SPC * dlt + i;
-                        cp[s_] = 0.0;
-                        if (i == 0 || resd[dlt] <= KS_KB - 1 - KS_NW) {     // (wave-uniform) the tile exists
-                            const double *xb = x + resd[dlt] * 16 + (KS_NW * 16) * i;
-                            const double xJ = xb[dlt * 16 + l15];
-                            double r[4];
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) r[reg] = acc[s_][reg] * xJ;
-                            const double t = ks_rowsum16x4(r, l15);
-                            if ((l15 & 3) == 0) pR[s_ * 16 + kap + 4 * (2 * ((l15 >> 2) & 1) + (l15 >> 3))] = t;
-                            if (dlt) {
-                                double c = 0.0;
-#pragma unroll
-                                for (int reg = 0; reg < 4; ++reg) c += acc[s_][reg] * xb[kap + 4 * reg];
-                                cp[s_] = c;
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int dlt = 1; dlt < KS_ND; dlt += 2) {         // classes dlt, dlt + 1: four tiles per reduction; rows hold c0, c2, c1, c3
-                    const double c = ks_colsum4(cp[KS_SPC * dlt], cp[KS_SPC * dlt + 1], cp[KS_SPC * (dlt + 1)], cp[KS_SPC * (dlt + 1) + 1]);
-                    pC[(KS_SPC * (dlt + (kap & 1)) + (kap >> 1)) * 16 + l15] = c;
-                }
+                ks_matvec(acc, x, pR, pC, wv, kap, l15);
             }
             __syncthreads();
             if (tid < KP) {
                 // entry 16 I + ml of G0 x: the seven tiles (I, I + delta) of its row block and the six tiles (I - delta, I) that reach
-                // it transposed, each from its owner wave (I + delta) mod 8 — 13 terms in a fixed order (deterministic)
+                // it transposed, each from its owner wave (column block mod 8) and its slot there — 13 terms in a fixed order
                 const int I = tid >> 4, ml = tid & 15;
                 double v = 0.0;
 #pragma unroll
-                for (int dlt = 0; dlt < KS_ND; ++dlt) v += ypR[(((I + dlt) & (KS_NW - 1)) * KS_TPW + KS_SPC * dlt + (I >> 3)) * 16 + ml];
+                for (int dlt = 0; dlt < KS_ND; ++dlt) { const int ow = (I + dlt) & (KS_NW - 1); v += ypR[(ow * KS_TPW + ks_rank(ow, I)) * 16 + ml]; }
 #pragma unroll
                 for (int dlt = 1; dlt < KS_ND; ++dlt) {
                     const int Ip = I - dlt + (I < dlt ? KS_KB : 0);
-                    v += ypC[(((Ip + dlt) & (KS_NW - 1)) * KS_TPW + KS_SPC * dlt + (Ip >> 3)) * 16 + ml];
+                    const int ow = (Ip + dlt) & (KS_NW - 1);
+                    v += ypC[(ow * KS_TPW + ks_rank(ow, Ip)) * 16 + ml];
                 }
                 if (job > 0) v = v - uv[tid] * sx - (ux - mm * sx);                       // G x = G0 x - u (1'x) - 1 (u'x - mm 1'x)
                 v = tid < k ? v : 0.0;
@@ -534,6 +567,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 for (int y = q; y < Q; ++y) if (tid < KP) Hm[y * KP + tid] = 0.0;
             }
             __syncthreads();
+        }
         }
         // requested nlv beyond what the local model has: predict clamps to the model's nlv (src/plskern.jl:228-229)
         __syncthreads();
