@@ -41,9 +41,7 @@
 #define KS_KB 13         // 16-row blocks of the Gram matrix: k <= 208 (smaller k is zero-padded)
 #define KS_KP (16 * KS_KB)
 #define KS_ND 7          // tile classes delta = J - I (mod 13) = 0 .. 6: every unordered pair of row blocks exactly once
-#define KS_EXT (KS_KB + KS_ND - 1)   // row blocks of the cyclic extension (blocks 13 .. 18 repeat blocks 0 .. 5)
-#define KS_KPX (16 * KS_EXT)
-#define KS_RS (KS_KPX + 1)   // rows of an LDS stage block (odd: the 32-B lane pairs of a row store spread over all banks)
+#define KS_RS (KS_KP + 1)   // rows of an LDS stage block (odd: the 32-B lane pairs of a row store spread over all banks)
 #define KS_TPW 12        // accumulator slots per wave: its 11 or 12 tiles in the order of their row blocks
 #define KS_AD 4          // operand pairs in flight ahead of their product
 #define KS_CS 16         // columns per LDS stage
@@ -57,8 +55,8 @@
 typedef double v2f64k __attribute__((ext_vector_type(2)));
 typedef double v4f64k __attribute__((ext_vector_type(4)));
 
-// Tile ownership.  The 91 tiles of the upper triangle are the pairs (I, J = I + delta), I = 0 .. 12, delta = 0 .. 6, J taken in the
-// cyclic extension (blocks 13 .. 18 = blocks 0 .. 5).  Wave w owns the COLUMN blocks J = w, w + 8, w + 16: among the seven J of a
+// Tile ownership.  The 91 tiles of the upper triangle are the pairs (I, J = I + delta), I = 0 .. 12, delta = 0 .. 6 (J >= 13 is row
+// block J - 13: every unordered pair of row blocks exactly once).  Wave w owns the COLUMN blocks J = w, w + 8, w + 16: among the seven J of a
 // row block I at most one is congruent to w mod 8, so wave w has the tile (I, I + (w - I) mod 8) of every row block I except
 // I = e1 = (w + 1) mod 8 and I = e1 + 8 (where (w - I) mod 8 = 7): 11 tiles (e1 <= 4) or 12, 23 / 23 / 23 / 22 per SIMD (waves
 // w and w + 4).  Slot r of a wave is its r-th tile in the order of I; the LDS addresses of a slot's two operands are per-wave
@@ -69,7 +67,7 @@ typedef double v4f64k __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int ks_e1(int w) { return (w + 1) & (KS_NW - 1); }
 __device__ __forceinline__ int ks_ntiles(int w) { return ks_e1(w) + 8 < KS_KB ? KS_TPW - 1 : KS_TPW; }
 __device__ __forceinline__ int ks_slot_I(int w, int r) { const int e1 = ks_e1(w); int I = r; if (I >= e1) ++I; if (I >= e1 + 8) ++I; return I; }
-__device__ __forceinline__ int ks_slot_J(int w, int I) { return I + ((w - I) & (KS_NW - 1)); }
+__device__ __forceinline__ int ks_slot_J(int w, int I) { const int J = I + ((w - I) & (KS_NW - 1)); return J >= KS_KB ? J - KS_KB : J; }   // its column block, as a row block
 __device__ __forceinline__ int ks_rank(int w, int I) { const int e1 = ks_e1(w); return I - (I > e1 ? 1 : 0) - (I > e1 + 8 ? 1 : 0); }   // slot of row block I in wave w
 
 typedef double v4f64k_ __attribute__((ext_vector_type(4)));
@@ -144,7 +142,7 @@ __device__ __forceinline__ double ks_colsum4(double c0, double c1, double c2, do
 // The wave's share of y = G0 x, straight from the accumulator registers (D layout: lane (kap, l15), register reg of the slot of
 // tile (I, J) holds G0[16 I + kap + 4 reg][16 J + l15]).  Rows of block I from G0[I][J] x_J: ONE transposing 16-lane reduction for
 // the four registers (pR[slot]); rows of block J from the tile's columns against x_I (it is also G0[J][I]'): four registers, then
-// the four lane rows, four tiles per permlane reduction (pC[slot]).  x carries the cyclic extension.
+// the four lane rows, four tiles per permlane reduction (pC[slot]).
 __device__ __forceinline__ void ks_matvec(const v4f64k_ (&acc)[KS_TPW], const double *x, double *pR, double *pC, int wv, int kap, int l15)
 {
     const int nt = ks_ntiles(wv);
@@ -202,8 +200,8 @@ __host__ __device__ inline ks_lds ks_layout(int Q, int nlv)
     int need = 2 * (KS_CS / 4) * KS_RS * 4;                // two stage buffers [4 column quads][KS_RS rows][4]
     if (nlv * KS_KP + 2 * KS_NW * KS_TPW * 16 > need) need = nlv * KS_KP + 2 * KS_NW * KS_TPW * 16;
     o += need;
-    L.dl = o; o += KS_KPX;                                 // (x vectors of the products carry the cyclic extension)
-    L.xv = o; o += KS_KPX;
+    L.dl = o; o += KS_KP;
+    L.xv = o; o += KS_KP;
     L.A = o; o += KS_KP * Q;
     L.H = o; o += KS_KP * Q;
     L.gv = o; o += KS_KP; L.uv = o; o += KS_KP; L.sv = o; o += KS_KP;
@@ -266,7 +264,6 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 const int e = tid;
                 dme = e < k ? g.w[(size_t)qi * k + e] / sw : 0.0;
                 dl[e] = dme;
-                if (e < KS_KPX - KP) dl[KP + e] = dme;      // cyclic extension (blocks 13 .. 18 = blocks 0 .. 5)
                 if (e < k) {
 #pragma unroll
                     for (int y = 0; y < Q; ++y) {
@@ -371,7 +368,6 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                     if (g.scal) { z.x /= sq.x; z.y /= sq.y; }     // (uniform branch: no divisions on the scal = false path)
                     double *dst = buf + (((c8 >> 1) * RS + e) << 2) + 2 * (c8 & 1);
                     *reinterpret_cast<v2f64k *>(dst) = z;
-                    if (e < KS_KPX - KP) *reinterpret_cast<v2f64k *>(dst + 4 * KP) = z;   // cyclic copy of row blocks 0 .. 5
                 }
             }
         };
@@ -390,20 +386,23 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             if (nstage > 1) put(0, stage, std::false_type{}); else put(0, stage, std::true_type{});
             if (nstage > 1) issue(1);
             __syncthreads();
-            for (int cs = 0; cs + 1 < nstage; ++cs) {
-                ks_gram<KS_CS / 4>(acc, pa, pb, has12, 0);          // G0 += Z_stage Z_stage': 4 k-steps of 4 columns
-                double *nb = stage + ((cs + 1) & 1) * STG;
+            // two stages per trip: the buffer parity is a compile-time LDS offset then, and the operand addresses never change
+            auto stage_step = [&](int cs, auto par_) {
+                constexpr int PAR = decltype(par_)::value;
+                ks_gram<KS_CS / 4>(acc, pa, pb, has12, PAR * STG);  // G0 += Z_stage Z_stage': 4 k-steps of 4 columns
+                double *nb = stage + (1 - PAR) * STG;
                 if (cs + 2 < nstage) { put(cs + 1, nb, std::false_type{}); issue(cs + 2); }   // (its loads were issued a stage ago)
                 else put(cs + 1, nb, std::true_type{});
-                const int d = (cs & 1) ? -STG : STG;
-#pragma unroll
-                for (int r = 0; r < KS_TPW; ++r) { pa[r] += d; pb[r] += d; }
                 __syncthreads();
+            };
+            for (int cs = 0; cs + 1 < nstage; cs += 2) {
+                stage_step(cs, std::integral_constant<int, 0>{});
+                if (cs + 2 < nstage) stage_step(cs + 1, std::integral_constant<int, 1>{});
             }
             {                                                       // the last stage: only the k-steps that hold columns < p
-                const int nks = (ldr - KS_CS * (nstage - 1) + 3) >> 2;
+                const int nks = (ldr - KS_CS * (nstage - 1) + 3) >> 2, lo = ((nstage - 1) & 1) * STG;
 #pragma unroll 1
-                for (int ks = 0; ks < nks; ++ks) ks_gram<1>(acc, pa, pb, has12, ks * (RS * 4));
+                for (int ks = 0; ks < nks; ++ks) ks_gram<1>(acc, pa, pb, has12, lo + ks * (RS * 4));
             }
             __syncthreads();
         }
@@ -427,7 +426,6 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 if (tid < KP) {
                     const double v = Am[(job - 1) * KP + tid];
                     xv[tid] = v;
-                    if (tid < KS_KPX - KP) xv[KP + tid] = v;
                 }
             }
             else {
@@ -501,7 +499,6 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                     Th[a * KP + tid] = tme;
                     dte = dl[tid] * tme;
                     xv[tid] = dte;
-                    if (tid < KS_KPX - KP) xv[KP + tid] = dte;
                 }
                 double tau = gom;
                 for (int j = 0; j < a; ++j) tau -= beta[j] * tauh[j];
