@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <new>
 #include <vector>
 
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void k_to_rowmajor(const double *__restrict__ 
 // ---------------------------------------------------------------- K9: kNN + weights
 #define KNN_QB 4       // queries per workgroup (each loaded training value serves KNN_QB queries; 8 measured slower)
 #define KNN_CAP 1024   // candidate buffer per query (LDS); k <= KNN_CAP - 256
+#define KNN_FCAP 2048  // candidates per query that k_knn_finish merges (segments x k)
 #define KNN_RB 4        // 256-row chunks of the training scores in flight per trip
 #define KNN_CB 8        // score columns loaded together
 
@@ -76,6 +78,94 @@ __device__ static void bitonic_sort_n(double *key, int *idx, int cap)
     }
     __syncthreads();
 }
+// The same network run by ONE wave (no workgroup barrier between the passes: a wave's LDS operations complete in order): the four
+// waves of a scan workgroup sort the four queries' buffers side by side — 7 us per 1024 entries against 14 us x 4 queries with
+// the workgroup-wide sort, which was half of the scan's time (JCH_KNN_DBG=1 measures the scan without any candidate kept).
+template <int PP>   // PP = pairs per lane and pass = cap / 128 (1 for cap <= 128): all of a pass's loads go out together
+__device__ __forceinline__ void bitonic_sort_wave_pp(double *key, int *idx, int cap)
+{
+    const int lane = threadIdx.x & 63;
+    for (int size = 2; size <= cap; size <<= 1) {
+        for (int stride = size >> 1, ls = 31 - __builtin_clz(size >> 1); stride > 0; stride >>= 1, --ls) {
+            wavesync();
+            double a[PP], b[PP];
+            int ia[PP], ib[PP], lo[PP];
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const int t = lane + 64 * u;
+                lo[u] = ((t >> ls) << (ls + 1)) | (t & (stride - 1));
+                const int l = t < cap / 2 ? lo[u] : 0;
+                a[u] = key[l]; b[u] = key[l + stride]; ia[u] = idx[l]; ib[u] = idx[l + stride];
+            }
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const bool up = ((lo[u] & size) == 0);
+                const bool gt = (a[u] > b[u]) || (a[u] == b[u] && ia[u] > ib[u]) || (a[u] != a[u] && b[u] == b[u]);   // NaN sorts last
+                if (lane + 64 * u < cap / 2 && gt == up) { key[lo[u]] = b[u]; key[lo[u] + stride] = a[u]; idx[lo[u]] = ib[u]; idx[lo[u] + stride] = ia[u]; }
+            }
+        }
+    }
+    wavesync();
+}
+__device__ static void bitonic_sort_wave(double *key, int *idx, int cap)
+{
+    if (cap <= 128) bitonic_sort_wave_pp<1>(key, idx, cap);
+    else if (cap == 256) bitonic_sort_wave_pp<2>(key, idx, cap);
+    else if (cap == 512) bitonic_sort_wave_pp<4>(key, idx, cap);
+    else bitonic_sort_wave_pp<8>(key, idx, cap);
+}
+// Compaction WITHOUT a sort (one wave, a query's candidate buffer of c0 <= KNN_CAP unordered entries): any bar tau' that leaves
+// at least k entries <= tau' is a valid bar, so the wave sorts 64 SAMPLES of the keys across its lanes (21 shuffle passes),
+// bisects for the smallest sample with >= k keys at or below it (6 counting steps: 16 compares + ballots per lane), and moves
+// the survivors to the front (k .. k + ~30 of them).  ~700 instructions against ~13000 for the bitonic sort of 1024 entries,
+// which was half of the scan's time.  Returns the number of survivors, or -1 if even the largest sample has fewer than k keys
+// below it (the caller sorts then).  Keys are never NaN here (a NaN distance fails every test against the bar).
+__device__ static int knn_wave_compact(double *key, int *idx, int c0, int k, double *tau_out)
+{
+    constexpr int E = KNN_CAP / 64;
+    const int lane = threadIdx.x & 63;
+    double kr[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) { const int e = lane + 64 * j; kr[j] = e < c0 ? key[e] : __builtin_inf(); }
+    double sv = kr[0];                                   // (c0 >= 64: entries 0 .. 63 exist)
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const double pv = __shfl_xor(sv, stride, 64);
+            const bool keepmin = ((lane & stride) == 0) == ((lane & size) == 0);
+            sv = keepmin ? (pv < sv ? pv : sv) : (pv > sv ? pv : sv);
+        }
+    auto count = [&](double pv) {
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) n += __popcll(__ballot((lane + 64 * j < c0) && kr[j] <= pv));
+        return n;
+    };
+    int lo = 0, hi = 63;
+    if (count(__shfl(sv, 63, 64)) < k) return -1;
+    while (lo < hi) {                                    // (wave-uniform)
+        const int mid = (lo + hi) >> 1;
+        if (count(__shfl(sv, mid, 64)) >= k) hi = mid; else lo = mid + 1;
+    }
+    const double pivot = __shfl(sv, hi, 64);
+    int ir[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) { const int e = lane + 64 * j; ir[j] = e < c0 ? idx[e] : 0x7fffffff; }
+    wavesync();
+    int base = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const bool keep = (lane + 64 * j < c0) && kr[j] <= pivot;
+        const unsigned long long m = __ballot(keep);
+        if (keep) { const int pos = base + __popcll(m & below); key[pos] = kr[j]; idx[pos] = ir[j]; }
+        base += __popcll(m);
+    }
+    wavesync();
+    *tau_out = pivot;
+    return base;
+}
 __device__ __forceinline__ int knn_pow2_at_least(int v) { int c = 64; while (c < v) c <<= 1; return c; }
 
 struct knn_args {
@@ -86,9 +176,10 @@ struct knn_args {
     int *ind;      // [m][k]
     double *dist;  // [m][k]
     double *w;     // [m][k]
-    int nseg;      // the training rows are scanned in nseg segments by different workgroups (blockIdx.y)
+    int nseg;      // the training rows are scanned in nseg segments by different workgroups (block b: segment b % nseg, query group b / nseg)
     double *ckey;  // [m][nseg][k] squared distances of every segment's k best (ascending; +inf beyond the segment's rows)
     int *cidx;     // [m][nseg][k]
+    int dbg;       // measurement switch (JCH_KNN_DBG; results then wrong by design): 1 = the bar starts at -inf (no candidate is ever kept: the bare scan)
 };
 
 // NT threads per workgroup, QB queries per workgroup (every loaded training value serves QB queries).  <256, 4>: two workgroups
@@ -104,14 +195,19 @@ __global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
     double *zq = reinterpret_cast<double *>(bidx + QB * KNN_CAP);  // [QB][dd]
     double *tau = zq + QB * g.dd;                              // [QB]
     int *cnt = reinterpret_cast<int *>(tau + QB);              // [QB]
-    const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * QB;
+    static_assert(QB == NT / 64, "one wave per query in the compactions");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // segment = block mod nseg (with 8 segments every XCD would only read ONE segment of the score matrix, workgroups being dealt
+    // round-robin over the XCDs — measured: no gain, the scan is not bound by where its 4 GB of L2 / Infinity Cache reads come
+    // from but by its waves' dependent steps)
+    const int seg = blockIdx.x % g.nseg;
+    const int q0 = (blockIdx.x / g.nseg) * QB;
     const int nq = min(QB, g.m - q0);
     for (int e = tid; e < QB * g.dd; e += NT) {
         const int qq = e / g.dd, c = e - qq * g.dd;
         zq[e] = qq < nq ? g.Zq[(size_t)(q0 + qq) + (size_t)c * (size_t)g.ldzq] : 0.0;
     }
-    if (tid < QB) { tau[tid] = __builtin_inf(); cnt[tid] = 0; }
+    if (tid < QB) { tau[tid] = (g.dbg & 1) ? -__builtin_inf() : __builtin_inf(); cnt[tid] = 0; }
     __syncthreads();
     const int k = g.k;
     // KNN_RB chunks of NT training rows per trip: all their loads go out together (the kernel is bound by the latency of the
@@ -119,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
     // other, exactly as if they had been read one at a time (round 2: 4.1 -> 1.3 ms per 1000 queries at cfg5)
     // this block's segment of the training rows (multiples of NT rows; the last one takes the rest)
     const int64_t seg_rows = ((g.n + g.nseg - 1) / g.nseg + NT - 1) / NT * NT;
-    const int64_t row_lo = (int64_t)blockIdx.y * seg_rows, row_hi = min(g.n, row_lo + seg_rows);
+    const int64_t row_lo = min(g.n, (int64_t)seg * seg_rows), row_hi = min(g.n, row_lo + seg_rows);
     for (int64_t base = row_lo; base < row_hi; base += NT * KNN_RB) {
         double d2[KNN_RB][QB];
 #pragma unroll
@@ -171,37 +267,53 @@ __global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
             // every wave must have taken its snapshot before any wave's next chunk bumps the counters: the compaction
             // below contains barriers, so the decision has to be the same in all four waves
             __syncthreads();
+            bool need = false;
 #pragma unroll
-            for (int qq = 0; qq < QB; ++qq) {
-                if (qq < nq && cq[qq] > KNN_CAP - NT) {   // compact: keep the k best, raise the bar (block-uniform decision)
-                    const int c0 = cq[qq];
-                    for (int e = c0 + tid; e < KNN_CAP; e += NT) { bkey[qq * KNN_CAP + e] = __builtin_inf(); bidx[qq * KNN_CAP + e] = 0x7fffffff; }
-                    bitonic_sort_n<NT>(bkey + qq * KNN_CAP, bidx + qq * KNN_CAP, KNN_CAP);
-                    if (tid == 0) { cnt[qq] = k; tau[qq] = bkey[qq * KNN_CAP + k - 1]; }
-                    __syncthreads();
+            for (int qq = 0; qq < QB; ++qq) need = need || (qq < nq && cq[qq] > KNN_CAP - NT);
+            if (need) {   // compact: keep the k best, raise the bar (block-uniform decision); wave w sorts query w's buffer
+                const int c0 = cnt[wv];                   // (stable: the next appends come after the barrier below)
+                if (wv < nq && c0 > KNN_CAP - NT) {
+                    double *key = bkey + wv * KNN_CAP;
+                    int *idx = bidx + wv * KNN_CAP;
+                    double bar = 0.0;
+                    const int c1 = knn_wave_compact(key, idx, c0, k, &bar);
+                    if (c1 >= k && c1 <= KNN_CAP - 2 * NT) { if (lane == 0) { cnt[wv] = c1; tau[wv] = bar; } }
+                    else {                                // (no sample bar, or ties left too many entries: the exact k best)
+                        const int c2 = c1 < 0 ? c0 : c1;
+                        for (int e = c2 + lane; e < KNN_CAP; e += 64) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
+                        bitonic_sort_wave(key, idx, KNN_CAP);
+                        if (lane == 0) { cnt[wv] = k; tau[wv] = key[k - 1]; }
+                    }
                 }
+                __syncthreads();
             }
         }
     }
-    // the segment's k best of every query, in (distance, index) order
-    for (int qq = 0; qq < nq; ++qq) {
-        const int c0 = cnt[qq];
+    // the segment's k best of every query, in (distance, index) order: wave w takes query w
+    __syncthreads();
+    if (wv < nq) {
+        int c0 = cnt[wv];
+        double *key = bkey + wv * KNN_CAP;
+        int *idx = bidx + wv * KNN_CAP;
+        if (c0 > 256 && c0 > k) {                         // shrink to k .. k + ~30 entries first: the sort below is over those only
+            double bar;
+            const int c1 = knn_wave_compact(key, idx, c0, k, &bar);
+            if (c1 >= k) c0 = c1;
+        }
         const int cap = knn_pow2_at_least(c0);
-        double *key = bkey + qq * KNN_CAP;
-        int *idx = bidx + qq * KNN_CAP;
-        for (int e = c0 + tid; e < cap; e += NT) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
-        bitonic_sort_n<NT>(key, idx, cap);
-        double *ok = g.ckey + ((size_t)(q0 + qq) * g.nseg + blockIdx.y) * k;
-        int *oi = g.cidx + ((size_t)(q0 + qq) * g.nseg + blockIdx.y) * k;
-        for (int e = tid; e < k; e += NT) { ok[e] = e < c0 ? key[e] : __builtin_inf(); oi[e] = e < c0 ? idx[e] : 0x7fffffff; }
+        for (int e = c0 + lane; e < cap; e += 64) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
+        bitonic_sort_wave(key, idx, cap);
+        double *ok = g.ckey + ((size_t)(q0 + wv) * g.nseg + seg) * k;
+        int *oi = g.cidx + ((size_t)(q0 + wv) * g.nseg + seg) * k;
+        for (int e = lane; e < k; e += 64) { ok[e] = e < c0 ? key[e] : __builtin_inf(); oi[e] = e < c0 ? idx[e] : 0x7fffffff; }
     }
 }
 
 // K9b: one workgroup per query merges the segments' candidates, orders the k nearest and turns the distances into weights
 __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
 {
-    __shared__ double key[KNN_CAP];
-    __shared__ int idx[KNN_CAP];
+    __shared__ double key[KNN_FCAP];
+    __shared__ int idx[KNN_FCAP];
     __shared__ double sred[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qi = blockIdx.x, k = g.k;
@@ -739,6 +851,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         knn_args a;
         a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
         a.h = h; a.cri = 4.0; a.tol = tol; a.ind = dind; a.dist = ddist; a.w = dw;
+        { const char *e = getenv("JCH_KNN_DBG"); a.dbg = e ? atoi(e) : 0; }
         // JCH_KNN_WIDE=1 (measurement knob, round 3): eight queries per 512-thread workgroup — half the L2 traffic, the same waves per
         // CU.  Measured at cfg5: 1.62 ms with 3 row segments, 1.05 with 2, against 0.87 for four queries per 256-thread workgroup:
         // the scan is not bound by the L2 bytes but by its dependent steps (threshold tests, LDS appends, barriers, sorts), which
@@ -751,8 +864,9 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         // row segments: as many as keep every segment at >= 4 trips and the merged candidate lists inside one sort (nseg * k <= KNN_CAP)
         // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
         // its own compaction sorts)
-        int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_CAP / k), n / (4 * nt * KNN_RB)));
-        if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_CAP / k));
+        // (round 3, with the sort-free compactions: 2 segments 0.60 ms, 3: 0.51, 4: 0.59, 5: 0.57, 6: 0.56, 8: 0.59)
+        int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_FCAP / k), n / (4 * nt * KNN_RB)));
+        if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_FCAP / k));
         a.nseg = nseg;
         JCH_TRY(jch_reserve(ctx, ctx->gemm_b, (sizeof(double) + sizeof(int)) * (size_t)m * nseg * k + 256));
         a.ckey = (double *)ctx->gemm_b.ptr; a.cidx = (int *)(a.ckey + (size_t)m * nseg * k);
@@ -762,8 +876,8 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
             JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr.mark(ctx->device);
         }
-        if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8), nseg), dim3(512), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB), nseg), dim3(256), lds, ctx->stream, a);
+        if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8) * nseg), dim3(512), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB) * nseg), dim3(256), lds, ctx->stream, a);
         hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
     }
     ev2 = jch_ev(ctx);

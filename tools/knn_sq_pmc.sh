@@ -1,0 +1,22 @@
+#!/bin/bash
+# SQ counters of the kNN scan (cfg5): where its waves' cycles go.  tools/knn_sq_pmc.sh -> gpurun_out/knn_sq/summary.txt
+export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/knn_sq; mkdir -p $O; cd /tmp
+i=0
+for g in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT"; do
+  timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $O/g$i -- python $R/tools/bench_lwplsr.py > $O/g$i.log 2>&1 || exit 1
+  i=$((i+1))
+done
+cd $R
+python - <<'PY' > gpurun_out/knn_sq/summary.txt
+import csv,glob,collections
+for d in sorted(glob.glob('gpurun_out/knn_sq/g*/')):
+    for f in glob.glob(d+'**/*counter_collection.csv',recursive=True):
+        acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
+        for r in csv.DictReader(open(f)):
+            k=r['Kernel_Name'].split('(')[0]
+            if 'knn_scan' in k or 'locw_kspace' in k:
+                acc[k][r['Counter_Name']]+=float(r['Counter_Value']); n[(k,r['Counter_Name'])]+=1
+        for k in acc:
+            for c,v in acc[k].items(): print(f"{k[:40]:40s} {c:24s} per launch {v/n[(k,c)]:16.0f}")
+PY
+cat gpurun_out/knn_sq/summary.txt
