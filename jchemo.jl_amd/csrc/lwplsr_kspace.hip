@@ -227,12 +227,12 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
     const ks_lds L = ks_layout(Q, g.nlv_hi);
     double *stage = lds + L.stage, *Th = lds + L.T, *ypR = lds + L.ypR, *ypC = lds + L.ypC;
     double *dl = lds + L.dl, *Am = lds + L.A, *Hm = lds + L.H, *gv = lds + L.gv, *uv = lds + L.uv, *xv = lds + L.xv;
-    double *sv = lds + L.sv, *red = lds + L.red, *ys = lds + L.ys, *vl = lds + L.vl;
+    double *red = lds + L.red, *ys = lds + L.ys, *vl = lds + L.vl;
     double *beta = lds + L.beta, *tauh = lds + L.tauh, *tth = lds + L.tth;
     int *idx = reinterpret_cast<int *>(lds + L.idx);
     constexpr int lda = Q + 2;
     double *G0m = lds + L.eig, *E0 = G0m + Q * lda, *E1 = E0 + Q * lda, *V0 = E1 + Q * lda, *V1 = V0 + Q * lda, *csl = V1 + Q * lda;
-    double *ymean = ys, *ysd = ys + Q, *prun = ys + 2 * Q, *cvec = ys + 3 * Q;
+    double *ymean = ys, *ysd = ys + Q, *prun = ys + 2 * Q;
     const int le = g.nlv_hi - g.nlv_lo + 1;
     const int nlvloc = min(min(k, p), g.nlv_hi);
     const int nstage = (ldr + KS_CS - 1) / KS_CS;
@@ -412,7 +412,9 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
         // phase, which then spilled its stage loads.)
         int tid_lv = threadIdx.x;
         asm volatile("" : "+v"(tid_lv));
-        double mm = 0.0, tme = 0.0, dte = 0.0;
+        double mm = 0.0, tme = 0.0, dte = 0.0, cv[Q];
+#pragma unroll
+        for (int y = 0; y < Q; ++y) cv[y] = 0.0;
         KS_STAMP(2);
         {
         const int tid = tid_lv, lane = tid & 63, kap = lane >> 4, l15 = lane & 15;
@@ -427,10 +429,10 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                     const double v = Am[(job - 1) * KP + tid];
                     xv[tid] = v;
                 }
+                __syncthreads();                      // x published
             }
             else {
                 // ---------------- LV a (src/plskern.jl:149-175 in neighbour space, see the header)
-                double nrm;
                 if constexpr (Q > 1) {
                     constexpr int NE = Q * (Q + 1) / 2;
                     for (int e = tid; e < 5 * Q * lda; e += KS_NT) G0m[e] = 0.0;
@@ -455,46 +457,48 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                         }
                     }
                     __syncthreads();
-                    double vmv = 0.0;
-#pragma unroll
-                    for (int y1 = 0; y1 < Q; ++y1)
-#pragma unroll
-                        for (int y2 = 0; y2 < Q; ++y2) vmv += vl[y1] * G0m[y1 * lda + y2] * vl[y2];
-                    nrm = sqrt(vmv);
-                } else {
-                    double t1[1] = {tid < KP ? Am[tid] * Hm[tid] : 0.0};
-                    ks_block_sums<1>(t1, red);
-                    nrm = sqrt(t1[0]);
                 }
-                // om = A v / nrm, s = H v / nrm; g'om
-                double gom = 0.0;
-                if (tid < KP) {
-                    double o = 0.0, sv_ = 0.0;
-                    if constexpr (Q == 1) { o = Am[tid]; sv_ = Hm[tid]; }
+                if (a == 3) KS_STAMP(6);
+                // ---- per WAVE, no workgroup sums (each costs two barriers; the 208-long sums are 4 LDS trips for a wave): |K v|^2 =
+                // (A v)'(H v), g'(A v), and beta_j = t_j'D s / tt_j for the wave's share of the finished LVs
+                double p1 = 0.0, p2 = 0.0;
+                for (int i = lane; i < KP; i += 64) {
+                    double av = 0.0, hv = 0.0;
+                    if constexpr (Q == 1) { av = Am[i]; hv = Hm[i]; }
                     else {
 #pragma unroll
-                        for (int y = 0; y < Q; ++y) { o += Am[y * KP + tid] * vl[y]; sv_ += Hm[y * KP + tid] * vl[y]; }
+                        for (int y = 0; y < Q; ++y) { av += Am[y * KP + i] * vl[y]; hv += Hm[y * KP + i] * vl[y]; }
                     }
-                    o /= nrm; sv_ /= nrm;
-                    sv[tid] = sv_;
-                    gom = gv[tid] * o;
+                    p1 += av * hv; p2 += gv[i] * av;
                 }
-                {
-                    double t1[1] = {gom};
-                    ks_block_sums<1>(t1, red);       // (its barriers publish sv)
-                    gom = t1[0];
-                }
-                // beta_j = t_j'D s / tt_j (wave per finished LV)
+                const double nrm = sqrt(ks_wave_sum(p1));
+                const double gom = ks_wave_sum(p2) / nrm;           // g'om, om = A v / nrm
                 for (int j = wv; j < a; j += KS_NW) {
-                    double b = 0.0;
-                    for (int i = lane; i < KP; i += 64) b += Th[j * KP + i] * dl[i] * sv[i];
-                    b = ks_wave_sum(b);
-                    if (lane == 0) beta[j] = b / tth[j];
+                    double bsum = 0.0;
+                    for (int i = lane; i < KP; i += 64) {
+                        double hv = 0.0;
+                        if constexpr (Q == 1) hv = Hm[i];
+                        else {
+#pragma unroll
+                            for (int y = 0; y < Q; ++y) hv += Hm[y * KP + i] * vl[y];
+                        }
+                        bsum += Th[j * KP + i] * dl[i] * hv;
+                    }
+                    bsum = ks_wave_sum(bsum);
+                    if (lane == 0) beta[j] = bsum / (nrm * tth[j]);
                 }
-                __syncthreads();
+                __syncthreads();                                    // beta published
+                if (a == 3) KS_STAMP(7);
+                // scores t = s - sum_j beta_j t_j, s = H v / nrm = Xc w;  x = D t for the deflation product
                 tme = 0.0; dte = 0.0;
                 if (tid < KP) {
-                    tme = sv[tid];
+                    double hv = 0.0;
+                    if constexpr (Q == 1) hv = Hm[tid];
+                    else {
+#pragma unroll
+                        for (int y = 0; y < Q; ++y) hv += Hm[y * KP + tid] * vl[y];
+                    }
+                    tme = hv / nrm;
                     for (int j = 0; j < a; ++j) tme -= beta[j] * Th[j * KP + tid];
                     Th[a * KP + tid] = tme;
                     dte = dl[tid] * tme;
@@ -502,33 +506,45 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 }
                 double tau = gom;
                 for (int j = 0; j < a; ++j) tau -= beta[j] * tauh[j];
-                double sc_[Q + 1];
-                sc_[Q] = dte * tme;
+                __syncthreads();                                    // t_a and x published
+                if (a == 3) KS_STAMP(8);
+                // tt = t'D t and c = A't / tt, again per wave
+                double pt = 0.0, pc[Q];
 #pragma unroll
-                for (int y = 0; y < Q; ++y) sc_[y] = tid < KP ? Am[y * KP + tid] * tme : 0.0;
-                ks_block_sums<Q + 1>(sc_, red);
-                const double tt = sc_[Q];
+                for (int y = 0; y < Q; ++y) pc[y] = 0.0;
+                for (int i = lane; i < KP; i += 64) {
+                    const double ti = Th[a * KP + i];
+                    pt += xv[i] * ti;
+#pragma unroll
+                    for (int y = 0; y < Q; ++y) pc[y] += Am[y * KP + i] * ti;
+                }
+                const double tt = ks_wave_sum(pt);
+#pragma unroll
+                for (int y = 0; y < Q; ++y) cv[y] = ks_wave_sum(pc[y]) / tt;
                 if (tid == 0) { tth[a] = tt; tauh[a] = tau; }
                 const int kk = a + 1;
                 if (tid < Q) {
-                    const double c = sc_[tid] / tt;
-                    cvec[tid] = c;
+                    double c = cv[0];
+#pragma unroll
+                    for (int y = 1; y < Q; ++y) c = tid == y ? cv[y] : c;
                     const double pr = prun[tid] + tau * c * ysd[tid];
                     prun[tid] = pr;
                     if (tid < q && kk >= g.nlv_lo && kk <= g.nlv_hi) g.pred[((size_t)qi * le + (kk - g.nlv_lo)) * q + tid] = pr;
                 }
+                if (a == 3) KS_STAMP(9);
                 if (kk >= nlvloc) break;              // (uniform) the last LV needs no deflation
             }
-            __syncthreads();                          // x (and cvec) published
             // ---------------- y = G0 x from the accumulator registers, then the centring and the fixed-order combination
             double px = 0.0, pu = 0.0;
             for (int i = lane; i < KP; i += 64) { const double xi = x[i]; px += xi; pu += uv[i] * xi; }
             const double sx = ks_wave_sum(px), ux = ks_wave_sum(pu);
+            if (job == q + 4) KS_STAMP(10);
             {
                 double *pR = ypR + wv * (KS_TPW * 16), *pC = ypC + wv * (KS_TPW * 16);
                 ks_matvec(acc, x, pR, pC, wv, kap, l15);
             }
             __syncthreads();
+            if (job == q + 4) KS_STAMP(11);
             if (tid < KP) {
                 // entry 16 I + ml of G0 x: the seven tiles (I, I + delta) of its row block and the six tiles (I - delta, I) that reach
                 // it transposed, each from its owner wave (column block mod 8) and its slot there — 13 terms in a fixed order
@@ -549,8 +565,8 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 else {
 #pragma unroll
                     for (int y = 0; y < Q; ++y) {      // deflation: A <- A - (D t) c', H <- H - (G D t) c'
-                        Am[y * KP + tid] -= dte * cvec[y];
-                        Hm[y * KP + tid] -= v * cvec[y];
+                        Am[y * KP + tid] -= dte * cv[y];
+                        Hm[y * KP + tid] -= v * cv[y];
                     }
                 }
             }
@@ -563,6 +579,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
 #pragma unroll 1
                 for (int y = q; y < Q; ++y) if (tid < KP) Hm[y * KP + tid] = 0.0;
             }
+            if (job == q + 4) KS_STAMP(12);
             __syncthreads();
         }
         }
@@ -618,11 +635,13 @@ static int32_t launch_ks(jch_ctx *ctx, locw_args &g)
         fprintf(stderr, "\n");
     }
     if (g.dbg & 2) {   // phase stamps of block 0's first query (wall_clock64: 100 MHz)
-        double st[6] = {};
+        double st[13] = {};
         JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         JCH_HIP(ctx, hipMemcpy(st, g.scratch, sizeof st, hipMemcpyDeviceToHost));
         fprintf(stderr, "[jch] k_locw_kspace phases (us): setup %.1f  gram %.1f  u+H %.1f  first LV %.1f  remaining LVs %.1f  (nlv %d)\n", (st[1] - st[0]) * 0.01,
                 (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01, g.nlv_hi);
+        fprintf(stderr, "[jch]   LV 4 (us): sums+beta %.2f  scores %.2f  tt,c %.2f  (to product %.2f)  product %.2f  combine+deflate %.2f\n", (st[7] - st[6]) * 0.01,
+                (st[8] - st[7]) * 0.01, (st[9] - st[8]) * 0.01, (st[10] - st[9]) * 0.01, (st[11] - st[10]) * 0.01, (st[12] - st[11]) * 0.01);
     }
     return JCH_OK;
 }
