@@ -222,18 +222,23 @@ __global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
         for (int r = 0; r < KNN_RB; ++r)
 #pragma unroll
             for (int qq = 0; qq < QB; ++qq) d2[r][qq] = 0.0;
+        unsigned bo[KNN_RB];
+#pragma unroll
+        for (int r = 0; r < KNN_RB; ++r) {
+            const int64_t i = base + NT * r + tid;
+            bo[r] = (unsigned)(i < row_hi ? i : g.n - 1) * 8u;
+        }
         // KNN_CB score columns x KNN_RB row chunks = 32 loads per thread go out before the first is used (written as a plain
         // loop the compiler waited for each column's 4 loads before it issued the next: 20 round trips per trip instead of 3)
         for (int c0 = 0; c0 < g.dd; c0 += KNN_CB) {
             double x[KNN_CB][KNN_RB];
 #pragma unroll
             for (int cc = 0; cc < KNN_CB; ++cc) {
-                const size_t coff = (size_t)min(c0 + cc, g.dd - 1) * (size_t)g.ldzt;
+                // a uniform column base + a 32-bit byte offset of the row (n < 2^29, checked by the launcher): no 64-bit vector
+                // arithmetic per load
+                const char *cp = reinterpret_cast<const char *>(g.Zt + (size_t)min(c0 + cc, g.dd - 1) * (size_t)g.ldzt);
 #pragma unroll
-                for (int r = 0; r < KNN_RB; ++r) {
-                    const int64_t i = base + NT * r + tid;
-                    x[cc][r] = g.Zt[(size_t)(i < row_hi ? i : g.n - 1) + coff];
-                }
+                for (int r = 0; r < KNN_RB; ++r) x[cc][r] = *reinterpret_cast<const double *>(cp + bo[r]);
             }
 #pragma unroll
             for (int cc = 0; cc < KNN_CB; ++cc)
@@ -865,6 +870,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
         // its own compaction sorts)
         // (round 3, with the sort-free compactions: 2 segments 0.60 ms, 3: 0.51, 4: 0.59, 5: 0.57, 6: 0.56, 8: 0.59)
+        if (n >= ((int64_t)1 << 29)) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: 2^29 training rows or more");
         int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_FCAP / k), n / (4 * nt * KNN_RB)));
         if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_FCAP / k));
         a.nseg = nseg;
