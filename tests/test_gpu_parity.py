@@ -273,6 +273,35 @@ def test_lwplsr_constant_neighbourhood(J, ctx):
     assert np.allclose(pred, ref["pred"][:, 0, :], rtol=1e-8, atol=1e-10)
 
 
+def test_lwplsr_knn_ties_and_duplicates(J, ctx):
+    """Exact ties in the kNN scan (round 3: the candidate buffers are compacted by a SAMPLED bar, not sorted): 700 copies of one
+    training row, spread over both row segments, sit at the smallest distance of every query, k = 100 cuts through them — the
+    sampled bar then keeps > 512 entries and the compaction must fall back to the exact sort; later copies tie with the bar and
+    must lose to the earlier ones (ties are broken by the row index, oracle/plsr_oracle.py getknn).  Groups of 4 duplicates
+    among the other rows put ties at the k-th place of the ordinary queries as well.  Only the neighbours and distances are
+    compared: a neighbourhood of identical rows has no local model."""
+    n, p, m = 9000, 10, 6
+    X = CO.fill_uniform(11, n, p)
+    X[(np.arange(n) // 4) * 4 != np.arange(n)] = 0.0
+    X = X + np.repeat(X[::4], 4, axis=0)[:n] * (X == 0.0)       # rows 4 i .. 4 i + 3 identical
+    dup = np.arange(5, n, 12)[:700]
+    X[dup] = X[dup[0]]
+    y = X[:, :3] @ np.array([1.0, -2.0, 0.5]) + 0.05 * CO.fill_uniform(13, n, 1)[:, 0]
+    Xq = np.vstack([X[dup[0]][None, :] + 1e-3 * (CO.fill_uniform(12, 3, p) - 0.5), CO.fill_uniform(14, 3, p)])
+    kw = dict(nlvdis=3, metric="mahal", h=1.0, k=100, nlv=2)
+    with np.errstate(all="ignore"):
+        ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, 3))
+    fm = J.lwplsr(X, y, ctx=ctx, **kw)
+    res = J.predict(fm, Xq, nlv=range(0, 3), ctx=ctx)
+    assert np.array_equal(res.listnn, ref["listnn"])
+    copies = np.union1d(dup, [4, 5, 6, 7])                     # (row 5 was one of a group of 4 identical rows already)
+    assert np.all(np.isin(res.listnn[:3], copies)) and np.array_equal(res.listnn[0], copies[:100])   # the first 100 copies, in index order
+    assert O.rel_fro(ref["listd"], res.listd) < 1e-9
+    assert O.rel_fro(ref["listw"][3:], res.listw[3:]) < 1e-7
+    pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)
+    assert O.rel_fro(ref["pred"][3:, 0, :], pred[3:]) < 1e-6
+
+
 def test_lwplsr_nan_query_row(J, ctx):
     """A missing value in ONE query row: its scores, hence all its distances, are NaN and no training row ever beats the
     bar.  The reference's arithmetic gives that query NaN predictions (predict on a NaN row) and leaves the others alone;
