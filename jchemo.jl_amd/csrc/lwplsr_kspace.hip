@@ -16,13 +16,17 @@
 //     u = G0 d,  mm = d'u,   G x = G0 x - u (1'x) - 1 (u'x - mm 1'x),   g = -u + mm 1        (xq - pivot = 0)
 // (numpy prototype against the oracle at cfg5-like data: predictions equal to 4e-13 at 15 LVs, q = 1 and 3, scal on / off.)
 //
-// Layout: one 512-thread workgroup per query (eight waves, two per SIMD, 256 registers each).  G0 is built on the matrix cores (v_mfma_f64_16x16x4, the SAME LDS operand
-// array serves as A and as B: G0 is a SYRK) from 32-column stages of the gathered rows that are staged through LDS once and
-// shared by the four waves; its 16 x 16 tiles (upper triangle: 91 for 13 row blocks) never leave the accumulator registers —
-// every wave owns three or four whole block rows, 21 ... 24 tiles — and every later product G0 x is taken straight from
-// them (a row's tiles are accumulated first, then ONE DPP row sum per register; the transposed use of a tile goes through a
-// cross-row butterfly; five fixed-order partials per entry -> deterministic).  HBM traffic per query: the k gathered rows,
-// once (0.8 MB at cfg5; the p-space kernel streamed them 15 + 3 times: profiles/r02_pmc_lwplsr_cfg5.txt).
+// Layout: one 512-thread workgroup per query (eight waves, two per SIMD, 256 registers each).  G0 is built on the matrix cores
+// (v_mfma_f64_16x16x4; the SAME LDS operand array serves as A and as B: G0 is a SYRK) from 16-column stages of the gathered rows
+// that are staged through LDS once (two buffers) and shared by the eight waves; its 16 x 16 tiles (upper triangle: 91 for 13 row
+// blocks) never leave the accumulator registers — wave w owns the tiles whose column block is congruent to w mod 8, 11 or 12 of
+// them (see "Tile ownership" below) — and every later product G0 x is taken straight from them (one transposing DPP row sum per
+// tile, the transposed use of a tile through a cross-row butterfly, 13 fixed-order partials per entry -> deterministic).  The
+// latent-variable phase needs four workgroup barriers per LV: every 208-long sum (norm, g'om, beta, tt, c) is taken per wave.
+// HBM traffic per query: the k gathered rows, once (0.8 MB at cfg5; the p-space kernel streamed them 15 + 3 times:
+// profiles/r02_pmc_lwplsr_cfg5.txt).  Phase times of one query at cfg5 (JCH_LOCW_DBG=2, us): setup 8, Gram 115 (the matrix pipe
+// alone: 23 tiles per SIMD x 125 k-steps x 64 cycles = 77), u and H 8, 15 LVs 84 (per LV: sums + beta 0.9, scores 0.5, tt / c
+// 0.6, product 2.9, combine + deflate 0.5).
 #include <stdlib.h>
 
 #include <algorithm>
@@ -34,9 +38,10 @@
 #include "rowsum_dev.h"
 #include "lwplsr_dev.h"
 
-#define KS_NT 512        // threads per workgroup: 8 waves, TWO per SIMD — a single wave can issue one v_mfma_f64_16x16x4 per 64
-                         // cycles, the matrix pipe takes one per 32 (tools/mfma_f64_rate.hip: 73 vs 157 TFLOP/s chip-wide), and the
-                         // second wave's products also cover the first one's LDS waits, stage stores and barriers
+#define KS_NT 512        // threads per workgroup: 8 waves, TWO per SIMD.  (Not for the matrix pipe — ONE wave saturates it: a
+                         // v_mfma_f64_16x16x4 holds the SIMD for 64 cycles whoever issues it, 78 TFLOP/s chip-wide with one wave or
+                         // two, tools/mfma_f64_rate2.hip — but the second wave's products run while the first one waits for its
+                         // stage loads, LDS reads and barriers, and the vector-bound latent-variable phase interleaves two waves)
 #define KS_NW 8
 #define KS_KB 13         // 16-row blocks of the Gram matrix: k <= 208 (smaller k is zero-padded)
 #define KS_KP (16 * KS_KB)
