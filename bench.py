@@ -216,6 +216,13 @@ def secondary_lwplsr(J, lib, ctx, dev, calls):
                              note="algorithmic bytes = the gathered neighbour rows m k p 8 (SURVEY §8d: the path is latency / occupancy bound, "
                                   "the HBM fraction is reported for completeness; profiles/ holds the counted traffic)"),
            "device_ms_per_step": {k_: v / calls for k_, v in dev_ms.items()}}
+    # the local fits are a matrix-pipe + vector kernel since round 3 (k_locw_kspace: the k x k Gram matrix of the gathered rows on
+    # v_mfma_f64_16x16x4, then the LVs on it): its second bound, against the 78.6 TFLOP/s of the f64 matrix pipe
+    lf_s = dev_ms["local_fits"] / calls * 1e-3
+    syrk = float(m) * k * (k + 1) * p                       # algorithmic flop of the Gram matrices (one triangle)
+    out["roofline_matrix"] = {"bound": "mfma", "kernel": "k_locw_kspace (whole kernel: Gram pass + latent variables)", "achieved": syrk / lf_s / 1e12,
+                              "peak": 78.6, "unit": "TFLOP/s", "frac": syrk / lf_s / 1e12 / 78.6, "flop_per_launch": syrk,
+                              "note": "Gram pass alone (JCH_LOCW_DBG=2 stamps, profiles/README.md): about half of the kernel's time"}
     del X, Xq, y, noise, fm
     torch.cuda.empty_cache()
     return out

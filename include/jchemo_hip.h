@@ -228,6 +228,8 @@ JCH_API int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int6
  * and predictions up to rounding) —, otherwise one workgroup per query sweeps the k x p slab once per LV (that kernel
  * fails with JCH_EINVAL when k, p and q together exceed the 150 KB of LDS the workgroup may use);
  * the constant-y shortcut of src/locwlv.jl:25-28 applies to q == 1 only, as in the reference.
+ * n < 2^29 (the kNN scan addresses a training row by a 32-bit byte offset; JCH_EINVAL beyond), k <= 768.
+ * Neighbours at equal distance are ordered by their row index.
  */
 JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
                                    const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt,

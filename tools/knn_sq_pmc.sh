@@ -1,8 +1,8 @@
 #!/bin/bash
-# SQ counters of the kNN scan (cfg5): where its waves' cycles go.  tools/knn_sq_pmc.sh -> gpurun_out/knn_sq/summary.txt
+# SQ counters of the cfg5 kernels (kNN scan, neighbour-space local fits): where their waves' cycles go, matrix-pipe busy cycles.  tools/knn_sq_pmc.sh -> gpurun_out/knn_sq/summary.txt
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/knn_sq; mkdir -p $O; cd /tmp
 i=0
-for g in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT"; do
+for g in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $O/g$i -- python $R/tools/bench_lwplsr.py > $O/g$i.log 2>&1 || exit 1
   i=$((i+1))
 done
