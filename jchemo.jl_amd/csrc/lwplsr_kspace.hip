@@ -53,12 +53,10 @@
 #define KS_NR 4          // load rounds per stage: 8 waves x 8 rows per round
 #define KS_MAXNLV 48
 
-// (The builtin, not inline asm: an asm statement hides the instruction from the compiler's hazard recognizer, and back-to-back
+// (The products are issued through __builtin_amdgcn_mfma_f64_16x16x4f64, not inline asm: an asm statement hides the instruction from the compiler's hazard recognizer, and back-to-back
 // dependent f64 products on ONE accumulator — the four k-steps of a guarded tile — then lose part of the sum: measured, rows
 // 12 .. 15 of those tiles.  Pinning the tiles to AccVGPRs through an asm constraint bought no time anyway.)
-#define KS_MFMA(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc_, 0, 0, 0)
 typedef double v2f64k __attribute__((ext_vector_type(2)));
-typedef double v4f64k __attribute__((ext_vector_type(4)));
 
 // Tile ownership.  The 91 tiles of the upper triangle are the pairs (I, J = I + delta), I = 0 .. 12, delta = 0 .. 6 (J >= 13 is row
 // block J - 13: every unordered pair of row blocks exactly once).  Wave w owns the COLUMN blocks J = w, w + 8, w + 16: among the seven J of a
@@ -362,6 +360,10 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             constexpr bool last = decltype(last_)::value;
             const int col = KS_CS * cs + colst;
             const bool c0 = col < p, c1 = col + 1 < p;
+            // scal: ONE reciprocal per column and stage, then products — a division per element is ~25 vector instructions, and
+            // every one of them is time the matrix pipe stands still (the quotient differs from x / s by at most one ulp)
+            v2f64k rq = {1.0, 1.0};
+            if (g.scal) { rq.x = 1.0 / sq.x; rq.y = 1.0 / sq.y; }
 #pragma unroll
             for (int rr = 0; rr < KS_NR; ++rr) {
                 const int e = 64 * rr + 8 * wv + r8;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                     z.x = xr[rr].x - pv.x;
                     z.y = xr[rr].y - pv.y;
                     if (last) { z.x = c0 ? z.x : 0.0; z.y = c1 ? z.y : 0.0; }
-                    if (g.scal) { z.x /= sq.x; z.y /= sq.y; }     // (uniform branch: no divisions on the scal = false path)
+                    if (g.scal) { z.x *= rq.x; z.y *= rq.y; }     // (uniform branch)
                     double *dst = buf + (((c8 >> 1) * RS + e) << 2) + 2 * (c8 & 1);
                     *reinterpret_cast<v2f64k *>(dst) = z;
                 }
