@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 102 /* 0.1.2: + collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release */
+#define JCH_VERSION 103 /* 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
@@ -252,6 +252,15 @@ JCH_API int32_t jch_lwplsr_predict_prepared(jch_ctx *ctx, const jch_lwplsr_model
                                             int32_t nlv_lo, int32_t nlv_hi, double *pred, int32_t *ind_out, double *dist_out,
                                             double *w_out);
 JCH_API int32_t jch_lwplsr_release(jch_ctx *ctx, jch_lwplsr_model *model);
+/* The map that takes a query block to the neighbour-search space — the reference's `transform(object.fm, X)`
+ * (src/lwplsr.jl:139-151) followed by getknn's whitening (src/getknn.jl:37-49) — as a chain of affine stages
+ * Z <- ((Z - shift) ./ scale) B + bias (the arithmetic of jch_affine_gemm; shift, scale, bias may be NULL; B is p_in x k_out,
+ * column-major, all on the HOST), kept on the device with the model.  Stage 1 takes the model's p columns, every later stage
+ * the previous one's k_out, the last one must deliver dd columns; at most 4 stages.  With a map in place
+ * jch_lwplsr_predict_prepared accepts Zq = NULL and computes the query scores itself: same numbers as two jch_affine_gemm
+ * calls, without their uploads and synchronisations. */
+JCH_API int32_t jch_lwplsr_add_query_map(jch_ctx *ctx, jch_lwplsr_model *model, const double *shift, const double *scale,
+                                         const double *B, int64_t p_in, int64_t k_out, const double *bias);
 
 /* jch_weighted_cov — S = (A - 1 mu')' D (A - 1 mu') (d x d, d <= 64), D = diag(weights / sum); weights NULL = ones:
  * `Statistics.cov(Xtrain, corrected = false)` of getknn's Mahalanobis branch (src/getknn.jl:38).  A n x d [loc];

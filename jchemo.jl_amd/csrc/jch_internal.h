@@ -60,7 +60,7 @@ struct jch_ctx {
     // workspace (grow-only)
     void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
     size_t hstage_bytes = 0;
-    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets;
+    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz;
     // profiling
     bool profiling = false;
     jch_profile prof{};
@@ -74,6 +74,9 @@ struct jch_ctx {
     size_t cev_used = 0;             // events handed out (2 per pair)
     int coll_phase = 0;
     int coll_transport = 0;          // JCH_TRANSPORT_* of the last LV-loop all-reduce
+    // second stream + event (created on first use): result copies that may run beside the last kernel of a call (lwplsr.hip)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_event = nullptr;
     // tuning knobs (env JCH_SWEEP_BLOCKS_PER_CU etc.)
     int sweep_blocks_per_cu = 0;
     // diagnostics

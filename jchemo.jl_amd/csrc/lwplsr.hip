@@ -831,6 +831,10 @@ struct jch_lwplsr_model {
     double *Xrm = nullptr;   // [n][ldr]
     double *Y = nullptr;     // n x q, column-major, ld n
     double *Zt = nullptr;    // n x dd, column-major, ld n
+    // optional: the map that takes a query block to the neighbour-search space, as a chain of affine maps (the reference's
+    // transform(fm, X) followed by the whitening of getknn: two stages) kept on the device — jch_lwplsr_add_query_map
+    struct qmap { int p_in = 0, k_out = 0, kpad = 0; double *dB = nullptr; };   // dB: [p_in][kpad] folded B, then kpad folded biases
+    std::vector<qmap> qmaps;
 };
 
 static void lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t n, int p, double *Xrm, int ldr)
@@ -887,6 +891,17 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
     }
     ev2 = jch_ev(ctx);
+    // neighbours, distances and weights are final here: their copies to the host (3.2 MB at cfg5, into pages of the caller's
+    // fresh arrays that have never been touched) run on a second stream BESIDE the local fits instead of after them
+    bool side_copies = (ind_out || dist_out || w_out) && !getenv("JCH_LW_SIDE_COPY_OFF");
+    if (side_copies) {
+        if (!ctx->aux_stream && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) { ctx->aux_stream = nullptr; side_copies = false; }
+        if (side_copies && !ctx->aux_event && hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming) != hipSuccess) { ctx->aux_event = nullptr; side_copies = false; }
+        if (side_copies) {
+            JCH_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream));
+            JCH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
+        }
+    }
     {
         locw_args g;
         g.Xrm = Xrm; g.ldr = ldr; g.p = (int)p; g.Y = dY; g.ldy = ldyd; g.q = (int)q; g.Xq = dXq; g.ldxq = ldxqd; g.m = (int)m;
@@ -905,10 +920,15 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     }
     JCH_HIP(ctx, hipGetLastError());
     ev3 = jch_ev(ctx);
+    // (the local fits are in the queue: whatever the host does from here on runs beside them)
+    hipStream_t cs = side_copies ? ctx->aux_stream : ctx->stream;
+    hipError_t ce = hipSuccess;
+    if (ind_out && ce == hipSuccess) ce = hipMemcpyAsync(ind_out, dind, sizeof(int) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
+    if (dist_out && ce == hipSuccess) ce = hipMemcpyAsync(dist_out, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
+    if (w_out && ce == hipSuccess) ce = hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
+    if (side_copies) { const hipError_t se = hipStreamSynchronize(cs); if (ce == hipSuccess) ce = se; }   // (before any return: the buffers are the caller's)
+    if (ce != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_predict: copy of the neighbour lists failed: %s", hipGetErrorString(ce)); }
     JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
-    if (ind_out) JCH_HIP(ctx, hipMemcpyAsync(ind_out, dind, sizeof(int) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
-    if (dist_out) JCH_HIP(ctx, hipMemcpyAsync(dist_out, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
-    if (w_out) JCH_HIP(ctx, hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
     JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->profiling && ev0 && ev1 && ev2 && ev3) {
         // jch_profile of a prediction call: fit_ms = device time of the three stages, prologue_ms = row-major copy + kNN +
@@ -1022,7 +1042,43 @@ extern "C" int32_t jch_lwplsr_release(jch_ctx *ctx, jch_lwplsr_model *model)
         (void)hipStreamSynchronize(ctx->stream);
     }
     (void)hipFree(model->Xrm); (void)hipFree(model->Y); (void)hipFree(model->Zt);
+    for (auto &qm : model->qmaps) (void)hipFree(qm.dB);
     delete model;
+    return JCH_OK;
+}
+
+// Appends one affine stage Z <- ((Z - shift) ./ scale) B + bias (the arithmetic of jch_affine_gemm, folded the same way) to the
+// model's query map.  With a map in place jch_lwplsr_predict_prepared may be called with Zq = NULL: the query scores are then
+// computed from Xq on the device, on the ctx stream, with no upload and no host synchronisation per stage (the two
+// jch_affine_gemm calls per predict they replace cost 0.15 ms of a 1.9 ms call at cfg5).  Stage 1 takes p columns (the
+// model's), every later stage the previous one's k; the last stage must deliver the model's dd columns.
+extern "C" int32_t jch_lwplsr_add_query_map(jch_ctx *ctx, jch_lwplsr_model *model, const double *shift, const double *scale, const double *B,
+                                            int64_t p_in, int64_t k_out, const double *bias)
+{
+    if (!ctx) return JCH_EINVAL;
+    if (!model || !B || p_in < 1 || k_out < 1) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_add_query_map: bad arguments");
+    if (model->device != ctx->device) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_add_query_map: the model lives on device %d, the ctx on %d", model->device, ctx->device);
+    const int64_t expect = model->qmaps.empty() ? model->p : model->qmaps.back().k_out;
+    if (p_in != expect) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_add_query_map: this stage takes %lld columns, the previous one delivers %lld", (long long)p_in, (long long)expect);
+    if (model->qmaps.size() >= 4) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_add_query_map: at most 4 stages");
+    JCH_HIP(ctx, hipSetDevice(ctx->device));
+    const int kpad = (int)((k_out + 15) / 16 * 16);
+    std::vector<double> hb((size_t)p_in * kpad + kpad, 0.0);      // the fold of jch_affine_gemm: Bs = diag(1 / scale) B, bias' = bias - shift' Bs
+    double *Bs = hb.data(), *b2 = hb.data() + (size_t)p_in * kpad;
+    for (int64_t c = 0; c < k_out; ++c) {
+        double acc = bias ? bias[c] : 0.0;
+        for (int64_t j = 0; j < p_in; ++j) {
+            const double v = B[j + c * p_in] / (scale ? scale[j] : 1.0);
+            Bs[j * kpad + c] = v;
+            if (shift) acc -= shift[j] * v;
+        }
+        b2[c] = acc;
+    }
+    jch_lwplsr_model::qmap qm;
+    qm.p_in = (int)p_in; qm.k_out = (int)k_out; qm.kpad = kpad;
+    if (hipMalloc((void **)&qm.dB, sizeof(double) * hb.size()) != hipSuccess) return jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_add_query_map: device allocation failed");
+    if (hipMemcpy(qm.dB, hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(qm.dB); return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_add_query_map: upload failed"); }
+    model->qmaps.push_back(qm);
     return JCH_OK;
 }
 
@@ -1031,7 +1087,9 @@ extern "C" int32_t jch_lwplsr_predict_prepared(jch_ctx *ctx, const jch_lwplsr_mo
                                                int32_t nlv_lo, int32_t nlv_hi, double *pred, int32_t *ind_out, double *dist_out, double *w_out)
 {
     if (!ctx) return JCH_EINVAL;
-    if (!model || !Zq || !Xq || !pred || ldzq < m || ldxq < m) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: bad arguments");
+    if (!model || !Xq || !pred || ldxq < m || (Zq && ldzq < m)) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: bad arguments");
+    if (!Zq && (model->qmaps.empty() || model->qmaps.back().k_out != model->dd))
+        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: Zq is NULL and the model has no query map ending in %lld columns (jch_lwplsr_add_query_map)", (long long)model->dd);
     if (model->device != ctx->device) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: the model lives on device %d, the ctx on %d", model->device, ctx->device);
     JCH_TRY(lw_check(ctx, "jch_lwplsr_predict_prepared", model->n, model->p, model->q, model->dd, m, k, nlv_lo, nlv_hi));
     if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict_prepared: bad loc");
@@ -1042,13 +1100,27 @@ extern "C" int32_t jch_lwplsr_predict_prepared(jch_ctx *ctx, const jch_lwplsr_mo
     if (loc == JCH_LOC_HOST) {
         JCH_TRY(jch_reserve(ctx, ctx->xq, sizeof(double) * ((size_t)m * dd + (size_t)m * p)));
         double *b = (double *)ctx->xq.ptr;
-        JCH_HIP(ctx, hipMemcpy2DAsync(b, sizeof(double) * m, Zq, sizeof(double) * ldzq, sizeof(double) * m, dd, hipMemcpyHostToDevice, ctx->stream));
+        if (Zq) JCH_HIP(ctx, hipMemcpy2DAsync(b, sizeof(double) * m, Zq, sizeof(double) * ldzq, sizeof(double) * m, dd, hipMemcpyHostToDevice, ctx->stream));
         JCH_HIP(ctx, hipMemcpy2DAsync(b + (size_t)m * dd, sizeof(double) * m, Xq, sizeof(double) * ldxq, sizeof(double) * m, p, hipMemcpyHostToDevice, ctx->stream));
-        dZq = b; ldzqd = m; dXq = b + (size_t)m * dd; ldxqd = m;
+        dZq = Zq ? b : nullptr; ldzqd = m; dXq = b + (size_t)m * dd; ldxqd = m;
     }
     ctx->ev_used = 0;
     ctx->prof = jch_profile{};
     hipEvent_t ev0 = jch_ev(ctx);
+    if (!Zq) {   // the model's query map: Xq -> the neighbour-search space, stage by stage in two alternating device buffers
+        size_t wmax = 0;
+        for (const auto &qm : model->qmaps) wmax = std::max(wmax, (size_t)qm.k_out);
+        JCH_TRY(jch_reserve(ctx, ctx->qz, sizeof(double) * 2 * (size_t)m * wmax));
+        double *zb[2] = {(double *)ctx->qz.ptr, (double *)ctx->qz.ptr + (size_t)m * wmax};
+        const double *src = dXq;
+        int64_t lds_ = ldxqd;
+        int w = 0;
+        for (const auto &qm : model->qmaps) {
+            JCH_TRY(jch_launch_affine_gemm(ctx, src, m, qm.p_in, lds_, qm.dB, qm.k_out, qm.kpad, qm.dB + (size_t)qm.p_in * qm.kpad, zb[w], m));
+            src = zb[w]; lds_ = m; w ^= 1;
+        }
+        dZq = src; ldzqd = m;
+    }
     return lw_run(ctx, model->Xrm, model->ldr, model->n, p, model->Y, model->q, model->n, model->Zt, model->n, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol,
                   scal, nlv_lo, nlv_hi, pred, ind_out, dist_out, w_out, ev0);
 }

@@ -27,7 +27,7 @@ SYMBOLS = (
     "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
     "jch_predict", "jch_loopback_group_create", "jch_loopback_group_destroy", "jch_ctx_comm_init_loopback",
     "jch_ctx_p2p_export", "jch_ctx_p2p_import", "jch_ctx_p2p_enable", "jch_plskern_fit_scaled", "jch_col_stats",
-    "jch_ctx_get_counter", "jch_ctx_allreduce_probe", "jch_lwplsr_prepare", "jch_lwplsr_predict_prepared", "jch_lwplsr_release",
+    "jch_ctx_get_counter", "jch_ctx_allreduce_probe", "jch_lwplsr_prepare", "jch_lwplsr_predict_prepared", "jch_lwplsr_release", "jch_lwplsr_add_query_map",
 )
 
 
@@ -96,6 +96,7 @@ def load():
     L.jch_lwplsr_prepare.argtypes = [vp, i32, dp, i64, i64, i64, dp, i64, i64, dp, i64, i64, C.POINTER(vp)]
     L.jch_lwplsr_predict_prepared.argtypes = [vp, vp, i32, dp, i64, dp, i64, i64, i32, C.c_double, C.c_double, i32, i32, i32, dp, dp, dp, dp]
     L.jch_lwplsr_release.argtypes = [vp, vp]
+    L.jch_lwplsr_add_query_map.argtypes = [vp, vp, dp, dp, dp, i64, i64, dp]
     L.jch_weighted_cov.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp]
     L.jch_score_sums.argtypes = [vp, i32, dp, i64, i64, i64, dp, i64, i64, dp, dp]
     L.jch_fill_uniform.argtypes = [vp, dp, i64, i64, i64, i64, i64, C.c_uint64]

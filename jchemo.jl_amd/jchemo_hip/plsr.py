@@ -13,6 +13,7 @@ stride(0) == 1 — use `colmajor_empty`).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Union
 
@@ -552,7 +553,9 @@ def _cov_uncorrected(A, ctx):
 def _knn_train_space(obj: Lwplsr, ctx):
     """The space neighbours are searched in (src/lwplsr.jl:139-151 + the whitening of src/getknn.jl:37-49): returns the training
     coordinates Zt (n x dd) and the map that takes a query block to the same coordinates.  Model-constant: computed once per
-    `Lwplsr` object and cached with the device handle (`_lwplsr_prepared`)."""
+    `Lwplsr` object and cached with the device handle (`_lwplsr_prepared`).  Third value: the same map as a list of affine
+    stages (shift, scale, B) for jch_lwplsr_add_query_map — [] when the queries are searched in their own coordinates."""
+    stages = []
     if obj.fm is None:
         Zt = obj.X
         try:
@@ -564,10 +567,12 @@ def _knn_train_space(obj: Lwplsr, ctx):
             xs = plskern(obj.X, obj.Y, nlv=1, scal=True, ctx=ctx).xscales
             D = np.diag(1.0 / xs)
             Zt = _affine(Zt, None, None, D, None, ctx)
+            stages.append((None, None, D))
         qmap = (lambda Xq: Xq) if D is None else (lambda Xq: _affine(Xq, None, None, D, None, ctx))
     else:
         Zt = obj.fm.T
         qmap = lambda Xq: transform(obj.fm, Xq, ctx=ctx)
+        stages.append((_model_vec(obj.fm.xmeans), _model_vec(obj.fm.xscales), np.asfortranarray(obj.fm.R[:, :_nlv_arg(obj.fm, None)], dtype=np.float64)))
     if obj.metric == "mahal":
         d = Zt.shape[1]
         if d > 64:
@@ -583,12 +588,13 @@ def _knn_train_space(obj: Lwplsr, ctx):
         Zt = _affine(Zt, None, None, Uinv, None, ctx)
         inner = qmap
         qmap = lambda Xq: _affine(inner(Xq), None, None, Uinv, None, ctx)
-    return Zt, qmap
+        stages.append((None, None, Uinv))
+    return Zt, qmap, stages
 
 
 def _knn_space(obj: Lwplsr, Xq, ctx):
     """(training coordinates, query coordinates) — see _knn_train_space."""
-    Zt, qmap = _knn_train_space(obj, ctx)
+    Zt, qmap, _ = _knn_train_space(obj, ctx)
     return Zt, qmap(Xq)
 
 
@@ -615,7 +621,7 @@ def _lwplsr_prepared(obj: Lwplsr, ctx, dev: bool, qk: int):
         _addr_ld(Xt); _addr_ld(Yt)
     except (ValueError, TypeError):
         Xt, Yt = _as_colmajor_copy(Xt), _as_colmajor_copy(Yt)
-    Zt, qmap = _knn_train_space(obj, ctx)
+    Zt, qmap, stages = _knn_train_space(obj, ctx)
     n, p = Xt.shape
     xa, ldx = _addr_ld(Xt); ya, ldy = _addr_ld(Yt); za, ldz = _addr_ld(Zt)
     if dev:
@@ -623,7 +629,16 @@ def _lwplsr_prepared(obj: Lwplsr, ctx, dev: bool, qk: int):
     h = C.c_void_p()
     ctx.check(_lib.load().jch_lwplsr_prepare(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, ya, qk, ldy, za, ldz,
                                              Zt.shape[1], C.byref(h)))
-    st = {"key": key, "handle": h, "qmap": qmap, "dd": Zt.shape[1], "fin": weakref.finalize(obj, _release_lwplsr_handle, h)}
+    st = {"key": key, "handle": h, "qmap": qmap, "dd": Zt.shape[1], "fin": weakref.finalize(obj, _release_lwplsr_handle, h), "device_map": False}
+    # the query map travels with the handle: the library then takes Xq alone (two jch_affine_gemm calls per predict, each with
+    # an upload of its matrix and a stream synchronisation, become two launches on the ctx stream)
+    if stages and os.environ.get("JCH_LW_DEVICE_QMAP", "1") != "0":
+        for shift, scale, B in stages:
+            B = np.asfortranarray(B, dtype=np.float64)
+            sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
+            sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+            ctx.check(_lib.load().jch_lwplsr_add_query_map(ctx._h, h, _np(sh), _np(sc), B.ctypes.data, B.shape[0], B.shape[1], None))
+        st["device_map"] = True
     obj.__dict__["_prep"] = st
     return st
 
@@ -703,10 +718,14 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, r
     # model-constant device data (row-major Xtrain, Ytrain, whitened training scores): prepared once per object
     # (q > 16: the kernel is still used — on the first y column — for neighbours + weights)
     st = _lwplsr_prepared(obj, ctx, dev, q if batched else 1)
-    Zq = st["qmap"](X)
     pred = np.empty((m, le, q if batched else 1))
     ind = np.empty((m, k), dtype=np.int32); dist = np.empty((m, k)); w = np.empty((m, k))
-    qa, ldq = _addr_ld(Zq); xqa, ldxq = _addr_ld(X)
+    if st["device_map"]:
+        qa, ldq = None, 0                                          # the handle maps the queries itself
+    else:
+        Zq = st["qmap"](X)
+        qa, ldq = _addr_ld(Zq)
+    xqa, ldxq = _addr_ld(X)
     if dev:
         torch.cuda.current_stream(X.device).synchronize()
     ctx.check(_lib.load().jch_lwplsr_predict_prepared(ctx._h, st["handle"], _lib.LOC_DEVICE if dev else _lib.LOC_HOST, qa, ldq, xqa, m, ldxq, k,

@@ -344,20 +344,33 @@ mutable struct LwplsrPrepared
     qmap                         # query block -> coordinates of the neighbour search
     dd::Int
     ctx::JchCtx
+    device_map::Bool             # the handle maps the queries itself (jch_lwplsr_add_query_map): predict passes Zq = C_NULL
 end
 
 "`prepare(object::Lwplsr; ctx)`: device handle of the model-constant data; release with `release!` (or let the GC do it)."
 function prepare(object; ctx = default_ctx())
     Xt = _in(object.X); Yt = _colocate_mat(_in(object.Y), Xt)
     n, p = size(Xt); q = size(Yt, 2)
-    Zt, qmap = _knn_train_space(object, Xt, ctx)
+    Zt, qmap, stages = _knn_train_space(object, Xt, ctx)
     Zt = _colocate_mat(Zt, Xt)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve Xt Yt Zt check(ctx, ccall((:jch_lwplsr_prepare, LIB), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int64, Ref{Ptr{Cvoid}}),
         ctx.h, _loc(Xt), pointer(Xt), n, p, stride(Xt, 2), pointer(Yt), q, max(stride(Yt, 2), n), pointer(Zt), stride(Zt, 2), size(Zt, 2), r))
-    pm = LwplsrPrepared(object, r[], qmap, size(Zt, 2), ctx)
+    pm = LwplsrPrepared(object, r[], qmap, size(Zt, 2), ctx, false)
     finalizer(release!, pm)
+    # the query map travels with the handle: two jch_affine_gemm calls per predict (each with an upload of its matrix and a
+    # stream synchronisation) become two launches inside jch_lwplsr_predict_prepared
+    for (shift, scale, B) in stages
+        Bm = Matrix{Float64}(B)
+        sh = shift === nothing ? Float64[] : Vector{Float64}(vec(shift))
+        sc = scale === nothing ? Float64[] : Vector{Float64}(vec(scale))
+        GC.@preserve Bm sh sc check(ctx, ccall((:jch_lwplsr_add_query_map, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}),
+            ctx.h, pm.h, shift === nothing ? Ptr{Float64}(C_NULL) : pointer(sh), scale === nothing ? Ptr{Float64}(C_NULL) : pointer(sc),
+            pointer(Bm), size(Bm, 1), size(Bm, 2), Ptr{Float64}(C_NULL)))
+    end
+    pm.device_map = !isempty(stages)
     pm
 end
 function release!(pm::LwplsrPrepared)
@@ -369,12 +382,14 @@ end
 
 # the space the neighbours are searched in (src/lwplsr.jl:139-150, src/getknn.jl:37-49): training coordinates + query map
 function _knn_train_space(object, Xt, ctx)
+    stages = Any[]                            # the query map as affine stages (shift, scale, B) for jch_lwplsr_add_query_map
     if object.fm === nothing
         if object.scal                        # :141-145  scale(object.X, colstd(object.X)) on both sides
             xs = col_stats(Xt; ctx = ctx).stds
             Dinv = Matrix(Diagonal(1 ./ xs))
             Zt = _affine(Xt, nothing, nothing, Dinv, nothing, ctx)
             qmap = Xq -> _affine(Xq, nothing, nothing, Dinv, nothing, ctx)
+            push!(stages, (nothing, nothing, Dinv))
         else
             Zt = Xt
             qmap = Xq -> Xq
@@ -383,6 +398,7 @@ function _knn_train_space(object, Xt, ctx)
         fmg = object.fm
         Zt = _colocate_mat(fmg.T, Xt)
         qmap = Xq -> transform(fmg, Xq; ctx = ctx)
+        push!(stages, (fmg.xmeans, fmg.xscales, fmg.R))
     end
     if object.metric == "mahal"               # src/getknn.jl:37-49
         S = _cov(Zt, ctx); d = size(S, 1)
@@ -390,8 +406,9 @@ function _knn_train_space(object, Xt, ctx)
         Zt = _affine(Zt, nothing, nothing, Uinv, nothing, ctx)
         inner = qmap
         qmap = Xq -> _affine(inner(Xq), nothing, nothing, Uinv, nothing, ctx)
+        push!(stages, (nothing, nothing, Uinv))
     end
-    Zt, qmap
+    Zt, qmap, stages
 end
 
 "`predict(pm::LwplsrPrepared, X; nlv)` — src/lwplsr.jl:134-166 on the prepared handle."
@@ -400,14 +417,14 @@ function predict(pm::LwplsrPrepared, X; nlv = nothing)
     X = _in(X); m = size(X, 1); n, p = size(object.X); q = size(object.Y, 2)
     a = object.nlv
     rng = nlv === nothing ? (a:a) : (max(minimum(nlv), 0):min(maximum(nlv), a, p))
-    Zq = _colocate_mat(pm.qmap(X), X)
+    Zq = pm.device_map ? X : _colocate_mat(pm.qmap(X), X)    # (device_map: Zq is not read, C_NULL goes down)
     k = min(object.k, n); le = length(rng)
     pred = zeros(q, le, m); ind = zeros(Int32, k, m); dist = zeros(k, m); w = zeros(k, m)   # C layout [m][le][q] == Julia (q, le, m)
     GC.@preserve Zq X check(ctx, ccall((:jch_lwplsr_predict_prepared, LIB), Int32,
         (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Int64, Int32, Float64, Float64, Int32, Int32, Int32,
          Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
-        ctx.h, pm.h, _loc(X), pointer(Zq), stride(Zq, 2), pointer(X), m, stride(X, 2), k, object.h, object.tol, object.scal ? 1 : 0,
-        first(rng), last(rng), pred, ind, dist, w))
+        ctx.h, pm.h, _loc(X), pm.device_map ? Ptr{Float64}(C_NULL) : pointer(Zq), stride(Zq, 2), pointer(X), m, stride(X, 2), k, object.h,
+        object.tol, object.scal ? 1 : 0, first(rng), last(rng), pred, ind, dist, w))
     preds = [permutedims(pred[:, i, :]) for i in 1:le]
     (pred = le == 1 ? preds[1] : preds, listnn = [Int.(ind[:, i]) .+ 1 for i in 1:m], listd = [dist[:, i] for i in 1:m],
      listw = [w[:, i] for i in 1:m])
@@ -419,7 +436,7 @@ function _predict_lwplsr(object, X, nlv, ctx)
     a = object.nlv
     rng = nlv === nothing ? (a:a) : (max(minimum(nlv), 0):min(maximum(nlv), a, p))
     Xt = _colocate_mat(_in(object.X), X)
-    Zt, qmap = _knn_train_space(object, Xt, ctx)
+    Zt, qmap, _ = _knn_train_space(object, Xt, ctx)
     Zt = _colocate_mat(Zt, X); Zq = _colocate_mat(qmap(X), X)
     k = min(object.k, n); le = length(rng)
     q <= 16 || error("predict(::Lwplsr): the batched kernel handles q <= 16 responses")

@@ -302,6 +302,36 @@ def test_lwplsr_knn_ties_and_duplicates(J, ctx):
     assert O.rel_fro(ref["pred"][3:, 0, :], pred[3:]) < 1e-6
 
 
+@pytest.mark.parametrize("kw", [dict(nlvdis=6, metric="mahal", scal=False), dict(nlvdis=4, metric="eucl", scal=True), dict(nlvdis=0, metric="mahal", scal=True),
+                                dict(nlvdis=0, metric="eucl", scal=False)])
+def test_lwplsr_device_query_map_is_the_same_arithmetic(kw, J, ctx, monkeypatch):
+    """jch_lwplsr_add_query_map (round 3): the prepared handle maps the queries to the neighbour-search space itself (transform,
+    then the whitening: the stages of `_knn_train_space`).  Same kernels on the same operands as the two jch_affine_gemm calls
+    it replaces, so neighbours, distances, weights and predictions must be IDENTICAL to the last bit; without a map (nlvdis = 0,
+    eucl, no scaling: the queries are searched in their own coordinates) the call still takes Zq."""
+    n, p, m = 2500, 30, 17
+    X = CO.fill_uniform(31, n, p); Xq = CO.fill_uniform(32, m, p)
+    y = X[:, :4] @ np.array([1.0, -2.0, 0.5, 3.0]) + 0.05 * CO.fill_uniform(33, n, 1)[:, 0]
+    full = dict(h=1.5, k=40, nlv=3, **kw)
+    fm = J.lwplsr(X, y, ctx=ctx, **full)
+    res = J.predict(fm, Xq, nlv=range(0, 4), ctx=ctx)
+    assert fm.__dict__["_prep"]["device_map"] == (kw["nlvdis"] > 0 or kw["scal"] or kw["metric"] == "mahal")
+    monkeypatch.setenv("JCH_LW_DEVICE_QMAP", "0")
+    fm2 = J.lwplsr(X, y, ctx=ctx, **full)
+    ref = J.predict(fm2, Xq, nlv=range(0, 4), ctx=ctx)
+    assert not fm2.__dict__["_prep"]["device_map"]
+    assert np.array_equal(res.listnn, ref.listnn) and np.array_equal(res.listd, ref.listd) and np.array_equal(res.listw, ref.listw)
+    for a in range(4):
+        assert np.array_equal(res.pred[a], ref.pred[a])
+    # Zq = NULL without a map that ends in the model's dd columns is refused
+    if not fm2.__dict__["_prep"]["device_map"]:
+        from jchemo_hip import _lib
+        h = fm2.__dict__["_prep"]["handle"]
+        out = np.empty((m, 1, 1)); Xf = np.asfortranarray(Xq)
+        st = _lib.load().jch_lwplsr_predict_prepared(ctx._h, h, _lib.LOC_HOST, None, 0, Xf.ctypes.data, m, m, 40, 1.5, fm2.tol, 0, 1, 1, out.ctypes.data, None, None, None)
+        assert st != 0 and b"query map" in _lib.load().jch_last_error(ctx._h)
+
+
 def test_lwplsr_nan_query_row(J, ctx):
     """A missing value in ONE query row: its scores, hence all its distances, are NaN and no training row ever beats the
     bar.  The reference's arithmetic gives that query NaN predictions (predict on a NaN row) and leaves the others alone;
