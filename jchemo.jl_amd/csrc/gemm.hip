@@ -149,6 +149,74 @@ __global__ __launch_bounds__(256) void k_affine_gemm32(const double *__restrict_
     }
 }
 
+// Short inputs (round 3: the query block of a kNN-LWPLSR predict, m = 1000 at cfg5): with 128 rows per workgroup the tiled kernel
+// above runs 8 workgroups on a 256-CU chip and every wave issues all p / 4 k-steps of its 32 rows — 56 us at cfg5.  Here a
+// workgroup takes 32 rows and its four waves split the COLUMNS of X (split-K inside the workgroup: p / 16 k-steps per wave), B
+// comes straight from L2 (no staging, no barrier in the product loop), and the four partial tiles are summed through LDS in a
+// fixed order.  Same products, a different association of the sum over k than the tiled kernel.
+__global__ __launch_bounds__(256) void k_affine_gemm32s(const double *__restrict__ Xc, int64_t m, int p, int64_t ldx,
+                                                         const double *__restrict__ Bs, int kpad, const double *__restrict__ bias,
+                                                         int k, double *__restrict__ out, int64_t ldo)
+{
+    __shared__ double part[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * 32;
+    const int64_t irow = i0 + 2 * (lane & 15);        // this lane's row pair
+    const bool two = irow + 1 < m, one = irow < m;
+    const bool vec = two && (ldx % 2 == 0) && ((((uintptr_t)Xc) & 15) == 0);
+    const int ntiles = kpad / 16;   // 1 or 2
+    const int ksteps = (p + 3) / 4, per = (ksteps + 3) / 4;
+    const int s0 = wv * per, s1 = min(ksteps, s0 + per);
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+    auto loadx = [&](int j) -> v2f64 {
+        if (j >= p || !one) return v2f64{0.0, 0.0};
+        const double *src = Xc + (size_t)irow + (size_t)j * (size_t)ldx;
+        if (vec) return *reinterpret_cast<const v2f64 *>(src);
+        return v2f64{src[0], two ? src[1] : 0.0};
+    };
+    auto loadb = [&](int j, int t) -> double { return (j < p && 16 * t < kpad) ? Bs[(size_t)j * kpad + 16 * t + (lane & 15)] : 0.0; };
+    constexpr int U = 8;                              // k-steps of loads in flight
+    v2f64 xa[U]; double ba[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int j = 4 * (s0 + u) + (lane >> 4); const bool in = s0 + u < s1; xa[u] = in ? loadx(j) : v2f64{0.0, 0.0}; ba[u][0] = in ? loadb(j, 0) : 0.0; ba[u][1] = (in && ntiles > 1) ? loadb(j, 1) : 0.0; }
+    for (int sb = s0; sb < s1; sb += U) {
+        v2f64 xb[U]; double bb[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int st = sb + U + u, j = 4 * st + (lane >> 4); const bool in = st < s1; xb[u] = in ? loadx(j) : v2f64{0.0, 0.0}; bb[u][0] = in ? loadb(j, 0) : 0.0; bb[u][1] = (in && ntiles > 1) ? loadb(j, 1) : 0.0; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                 // (steps past s1 multiply zeros)
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].x, ba[u][0], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].y, ba[u][0], acc[1][0], 0, 0, 0);
+            if (ntiles > 1) {
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].x, ba[u][1], acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u].y, ba[u][1], acc[1][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { xa[u] = xb[u]; ba[u][0] = bb[u][0]; ba[u][1] = bb[u][1]; }
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) part[wv][(par * 2 + t) * 4 + reg][lane] = acc[par][t][reg];
+    __syncthreads();
+    // D[mrow = (lane >> 4) + 4 reg][col = lane & 15]; row-tile 0 = even rows, row-tile 1 = odd rows of the 32; thread (wave w, lane)
+    // finishes entries e = 4 w .. 4 w + 3 of its lane: the four waves' partials in wave order
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        const int e = 4 * wv + e4, par = e >> 3, t = (e >> 2) & 1, reg = e & 3;
+        const int col = 16 * t + (lane & 15);
+        const int64_t i = i0 + 2 * ((lane >> 4) + 4 * reg) + par;
+        if (t < ntiles && col < k && i < m) out[(size_t)i + (size_t)col * (size_t)ldo] = ((part[0][e][lane] + part[1][e][lane]) + (part[2][e][lane] + part[3][e][lane])) + bias[col];
+    }
+}
+
 // Persistent variant of the narrow-output kernel for long inputs (round 2): the WHOLE coefficient matrix is staged in LDS
 // once per workgroup (p x 33 doubles = 132 KB at cfg2), after which the four waves stream their 32-row tiles without a
 // single barrier, X loads PD k-steps ahead of the MFMAs in a rotating register window.  With f64 MFMA at the vector rate
@@ -253,6 +321,13 @@ int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p,
             if (kpad == 16) { if (nw == 4) JCH_G32P(1, 4); else JCH_G32P(1, 8); }
             else { if (nw == 4) JCH_G32P(2, 4); else JCH_G32P(2, 8); }
 #undef JCH_G32P
+            JCH_HIP(ctx, hipGetLastError());
+            return JCH_OK;
+        }
+        // short inputs: 32 rows per workgroup, the columns of X split over its waves (JCH_GEMM_SMALL=0: the tiled kernel)
+        const char *es = getenv("JCH_GEMM_SMALL");
+        if (!(es && atoi(es) == 0) && m <= 32 * (int64_t)ctx->cus && p >= 64) {
+            hipLaunchKernelGGL(k_affine_gemm32s, dim3((unsigned)((m + 31) / 32)), dim3(256), 0, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo);
             JCH_HIP(ctx, hipGetLastError());
             return JCH_OK;
         }
