@@ -319,16 +319,50 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
 {
     __shared__ double key[KNN_FCAP];
     __shared__ int idx[KNN_FCAP];
+    __shared__ double okey[KNN_CAP];
+    __shared__ int oidx[KNN_CAP];
     __shared__ double sred[8];
+    __shared__ double smed[2];
+    __shared__ int snn[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qi = blockIdx.x, k = g.k;
     const int ncand = g.nseg * k;
-    const int cap = knn_pow2_at_least(ncand);
     const double *ck = g.ckey + (size_t)qi * ncand;
     const int *ci = g.cidx + (size_t)qi * ncand;
-    for (int e = tid; e < cap; e += 256) { key[e] = e < ncand ? ck[e] : __builtin_inf(); idx[e] = e < ncand ? ci[e] : 0x7fffffff; }
-    bitonic_sort_n<256>(key, idx, cap);
     const int kk = (int)min<int64_t>(k, g.n);
+    for (int e = tid; e < ncand; e += 256) { key[e] = ck[e]; idx[e] = ci[e]; }
+    for (int e = tid; e < kk; e += 256) { okey[e] = __builtin_inf(); oidx[e] = 0x7fffffff; }
+    __syncthreads();
+    // MERGE BY RANK instead of a sort (round 3; was a bitonic sort of all candidates, 55 barriers): every segment's list is
+    // already in (distance, index) order, so an entry's place in the merged order is its place in its own list plus, for every
+    // other list, the number of entries there that come before it — a binary search each.  Sentinels (+inf, 0x7fffffff) compare
+    // equal and may land on the same place: the output is pre-filled with them.
+    {
+        int s_ = 0, i_ = tid;                                  // (list, position) of entry e, advanced without a division
+        while (i_ >= k) { i_ -= k; ++s_; }
+        for (int e = tid; e < ncand; e += 256) {
+            const double a = key[e];
+            const int ia = idx[e];
+            int rank = i_;
+            for (int s2 = 0; s2 < g.nseg; ++s2) {
+                if (s2 == s_) continue;
+                const double *kl = key + s2 * k;
+                const int *il = idx + s2 * k;
+                int lo = 0, hi = k;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const double bkey_ = kl[mid];
+                    const bool before = (bkey_ < a) || (bkey_ == a && il[mid] < ia);
+                    if (before) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            if (rank < kk) { okey[rank] = a; oidx[rank] = ia; }
+            i_ += 256;
+            while (i_ >= k) { i_ -= k; ++s_; }
+        }
+    }
+    __syncthreads();
     int *oi = g.ind + (size_t)qi * k;
     double *od = g.dist + (size_t)qi * k, *ow = g.w + (size_t)qi * k;
     // fewer than k candidates with a finite distance (NaN / Inf in the query's or the training scores: no comparison
@@ -336,31 +370,42 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
     // NaN distance — wdist then yields weights 1 for the query exactly as the reference's arithmetic does (every
     // comparison with NaN is false, 0 / 0 -> NaN -> 1, src/wdist.jl:64-75) and nothing downstream reads out of bounds.
     for (int e = tid; e < kk; e += 256) {
-        const bool hole = idx[e] < 0 || (int64_t)idx[e] >= g.n;
-        oi[e] = hole ? e : idx[e];
-        key[e] = hole ? __builtin_nan("") : sqrt(key[e]);
-        od[e] = key[e];
+        const bool hole = oidx[e] < 0 || (int64_t)oidx[e] >= g.n;
+        oi[e] = hole ? e : oidx[e];
+        const double dv = hole ? __builtin_nan("") : sqrt(okey[e]);
+        okey[e] = dv;
+        od[e] = dv;
     }
     __syncthreads();
     // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
-    const double med = (kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]);
+    const double med = (kk & 1) ? okey[kk / 2] : 0.5 * (okey[kk / 2 - 1] + okey[kk / 2]);
+    // the median of |d - med| by RANK COUNTING (was a second sort): entry e's rank among the kk deviations in the order of the
+    // sort it replaces — by value, then by position, NaN last — is the number of entries that come before it
+    int nn = 0;
+    for (int e = tid; e < kk; e += 256) { const double v = fabs(okey[e] - med); key[e] = v; nn += v == v ? 1 : 0; }
+    for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
+    if (lane == 0) snn[wv] = nn;
+    if (tid < 2) smed[tid] = __builtin_nan("");                // (a target place among the NaNs stays NaN)
     __syncthreads();
-    // the distances are saved in the output array; |d - med| is sorted in place in the candidate buffer
-    const int cap2 = knn_pow2_at_least(kk);
-    for (int e = tid; e < cap2; e += 256) {
-        const double v = e < kk ? fabs(od[e] - med) : __builtin_inf();
-        key[e] = v;
-        idx[e] = e;
+    nn = snn[0] + snn[1] + snn[2] + snn[3];
+    const int t1 = kk / 2, t0 = (kk & 1) ? -1 : kk / 2 - 1;
+    for (int e = tid; e < kk; e += 256) {
+        const double v = key[e];
+        if (v != v) continue;
+        int r = 0;
+        for (int f = 0; f < kk; ++f) { const double u = key[f]; r += (u < v || (u == v && f < e)) ? 1 : 0; }
+        if (r == t1) smed[1] = v;
+        if (r == t0) smed[0] = v;
     }
-    bitonic_sort_n<256>(key, idx, cap2);
-    const double zmad = 1.4826 * ((kk & 1) ? key[kk / 2] : 0.5 * (key[kk / 2 - 1] + key[kk / 2]));
-    const double cutoff = med + g.cri * zmad;
     __syncthreads();
+    const double zmad = 1.4826 * ((kk & 1) ? smed[1] : 0.5 * (smed[0] + smed[1]));
+    const double cutoff = med + g.cri * zmad;
     // weights; max with NaN propagation (Julia's `maximum` returns NaN if any NaN is present)
     double wmax = -__builtin_inf();
     int anynan = 0;
+    __syncthreads();                                           // (key: the deviations are done with, the weights go there)
     for (int e = tid; e < kk; e += 256) {
-        const double dv = od[e];
+        const double dv = okey[e];
         const double wv_ = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
         key[e] = wv_;
         if (wv_ != wv_) anynan = 1;
