@@ -199,12 +199,12 @@ def secondary_lwplsr(J, lib, ctx, dev, calls):
     y = J.colmajor_empty(n, 1, dev); y.copy_((X @ beta + torch.sin(3 * X[:, 5])).reshape(-1, 1) + 0.05 * noise)
     fm = J.lwplsr(X, y, nlvdis=nlvdis, metric="mahal", h=1.0, k=k, nlv=nlv, ctx=ctx)
     J.predict(fm, Xq, nlv=range(0, nlv + 1), ctx=ctx)
-    dev_ms = {"copy": 0.0, "knn_and_weights": 0.0, "local_fits": 0.0}
+    dev_ms = {"query_scores_or_copies": 0.0, "knn_and_weights": 0.0, "local_fits": 0.0}
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(calls):
         res = J.predict(fm, Xq, nlv=range(0, nlv + 1), ctx=ctx)
         pr = ctx.profile()
-        dev_ms["copy"] += pr.smallstate_ms; dev_ms["knn_and_weights"] += pr.prologue_ms - pr.smallstate_ms; dev_ms["local_fits"] += pr.sweep_ms
+        dev_ms["query_scores_or_copies"] += pr.smallstate_ms; dev_ms["knn_and_weights"] += pr.prologue_ms - pr.smallstate_ms; dev_ms["local_fits"] += pr.sweep_ms
         gather_bytes = pr.sweep_bytes
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / calls
     pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)

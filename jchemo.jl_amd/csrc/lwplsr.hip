@@ -978,7 +978,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     if (ctx->profiling && ev0 && ev1 && ev2 && ev3) {
         // jch_profile of a prediction call: fit_ms = device time of the three stages, prologue_ms = row-major copy + kNN +
         // weights, sweep_ms = the batched local fits (ONE launch), sweep_bytes = the gathered neighbour rows m k ldr 8
-        // (algorithmic bytes per query = k p 8), smallstate_ms = the row-major copy alone (0 with a prepared model)
+        // (algorithmic bytes per query = k p 8), smallstate_ms = what precedes the kNN scan: the row-major copy (one-shot call) or the handle's query map (prepared model, Zq = NULL)
         float a = 0.f, b = 0.f, c = 0.f;
         (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2); (void)hipEventElapsedTime(&c, ev2, ev3);
         jch_profile &pr = ctx->prof;
