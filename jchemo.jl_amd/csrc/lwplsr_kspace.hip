@@ -46,7 +46,10 @@
 #define KS_KB 13         // 16-row blocks of the Gram matrix: k <= 208 (smaller k is zero-padded)
 #define KS_KP (16 * KS_KB)
 #define KS_ND 7          // tile classes delta = J - I (mod 13) = 0 .. 6: every unordered pair of row blocks exactly once
-#define KS_RS (KS_KP + 1)   // rows of an LDS stage block (odd: the 32-B lane pairs of a row store spread over all banks)
+#define KS_QS (4 * KS_KP + 8)   // doubles per column quad of an LDS stage: four columns of KS_KP rows each, column-major — an operand
+                         // read (lane (kap, l15): row 16 I + l15 of column kap) is then two 128-B runs 1664 B = 128 (mod 256) apart, i.e. all 64
+                         // banks once (with [row][4 columns] the 16 rows of a read were 32 B apart and met in pairs: SQ_LDS_BANK_CONFLICT was
+                         // 46 k cycles per query) — + 8 so that the four quads a stage store touches sit 64 B apart
 #define KS_TPW 12        // accumulator slots per wave: its 11 or 12 tiles in the order of their row blocks
 #define KS_AD 4          // operand pairs in flight ahead of their product
 #define KS_CS 16         // columns per LDS stage
@@ -81,7 +84,7 @@ typedef double v4f64k_ __attribute__((ext_vector_type(4)));
 template <int NKS>
 __device__ __forceinline__ void ks_gram(v4f64k_ (&acc)[KS_TPW], const double *const (&pa)[KS_TPW], const double *const (&pb)[KS_TPW], bool has12, int koff)
 {
-    constexpr int NM = KS_TPW - 1, NP = NKS * NM, KST = KS_RS * 4;
+    constexpr int NM = KS_TPW - 1, NP = NKS * NM, KST = KS_QS;
     double aq[KS_AD], bq[KS_AD];
 #pragma unroll
     for (int n = 0; n < KS_AD && n < NP; ++n) { aq[n] = pa[n % NM][koff + (n / NM) * KST]; bq[n] = pb[n % NM][koff + (n / NM) * KST]; }
@@ -200,7 +203,7 @@ __host__ __device__ inline ks_lds ks_layout(int Q, int nlv)
     int o = 0;
     // T history and the product partials alias the stage buffers (free after the Gram phase)
     L.stage = o; L.T = o; L.ypR = o + nlv * KS_KP; L.ypC = L.ypR + KS_NW * KS_TPW * 16;
-    int need = 2 * (KS_CS / 4) * KS_RS * 4;                // two stage buffers [4 column quads][KS_RS rows][4]
+    int need = 2 * (KS_CS / 4) * KS_QS;                    // two stage buffers [4 column quads][4 columns][KS_KP rows]
     if (nlv * KS_KP + 2 * KS_NW * KS_TPW * 16 > need) need = nlv * KS_KP + 2 * KS_NW * KS_TPW * 16;
     o += need;
     L.dl = o; o += KS_KP;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kap = lane >> 4, l15 = lane & 15;
     const int p = g.p, ldr = g.ldr, k = g.k, q = g.q;
-    constexpr int KP = KS_KP, RS = KS_RS;
+    constexpr int KP = KS_KP;
     const ks_lds L = ks_layout(Q, g.nlv_hi);
     double *stage = lds + L.stage, *Th = lds + L.T, *ypR = lds + L.ypR, *ypC = lds + L.ypC;
     double *dl = lds + L.dl, *Am = lds + L.A, *Hm = lds + L.H, *gv = lds + L.gv, *uv = lds + L.uv, *xv = lds + L.xv;
@@ -373,8 +376,9 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                     z.y = xr[rr].y - pv.y;
                     if (last) { z.x = c0 ? z.x : 0.0; z.y = c1 ? z.y : 0.0; }
                     if (g.scal) { z.x *= rq.x; z.y *= rq.y; }     // (uniform branch)
-                    double *dst = buf + (((c8 >> 1) * RS + e) << 2) + 2 * (c8 & 1);
-                    *reinterpret_cast<v2f64k *>(dst) = z;
+                    double *dst = buf + (c8 >> 1) * KS_QS + 2 * (c8 & 1) * KP + e;   // [quad][column][row]
+                    dst[0] = z.x;
+                    dst[KP] = z.y;
                 }
             }
         };
@@ -385,10 +389,10 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
 #pragma unroll
             for (int r = 0; r < KS_TPW; ++r) {
                 const int I = r < ks_ntiles(wv) ? ks_slot_I(wv, r) : 0, J = r < ks_ntiles(wv) ? ks_slot_J(wv, I) : 0;
-                pa[r] = stage + kap + (l15 << 2) + I * 64;
-                pb[r] = stage + kap + (l15 << 2) + J * 64;
+                pa[r] = stage + kap * KP + l15 + I * 16;
+                pb[r] = stage + kap * KP + l15 + J * 16;
             }
-            constexpr int STG = (KS_CS / 4) * RS * 4;              // doubles per stage buffer
+            constexpr int STG = (KS_CS / 4) * KS_QS;               // doubles per stage buffer
             issue(0);
             if (nstage > 1) put(0, stage, std::false_type{}); else put(0, stage, std::true_type{});
             if (nstage > 1) issue(1);
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             {                                                       // the last stage: only the k-steps that hold columns < p
                 const int nks = (ldr - KS_CS * (nstage - 1) + 3) >> 2, lo = ((nstage - 1) & 1) * STG;
 #pragma unroll 1
-                for (int ks = 0; ks < nks; ++ks) ks_gram<1>(acc, pa, pb, has12, lo + ks * (RS * 4));
+                for (int ks = 0; ks < nks; ++ks) ks_gram<1>(acc, pa, pb, has12, lo + ks * KS_QS);
             }
             __syncthreads();
         }
