@@ -332,6 +332,27 @@ def test_lwplsr_device_query_map_is_the_same_arithmetic(kw, J, ctx, monkeypatch)
         assert st != 0 and b"query map" in _lib.load().jch_last_error(ctx._h)
 
 
+@pytest.mark.parametrize("case", [dict(n=20000, k=50, levels=4), dict(n=20000, k=300, levels=3), dict(n=60000, k=200, levels=5), dict(n=3000, k=700, levels=2)])
+def test_lwplsr_knn_on_a_lattice(case, J, ctx):
+    """Neighbours on a LATTICE: integer coordinates in 6 dimensions, so squared distances are small integers and ties are the rule —
+    hundreds of training rows at exactly the k-th distance of every query.  The kNN scan's bar test (`==` admits a row only while
+    fewer than k are kept), its sampled-bar compactions (every sample equal; survivors beyond the buffer's mark -> the exact
+    sort) and the rank merge of the segments must still deliver the first k rows in (distance, index) order, as the oracle does."""
+    c = case
+    n, p, m = c["n"], 6, 12
+    rng = np.random.default_rng(1234 + c["k"])
+    X = rng.integers(0, c["levels"], size=(n, p)).astype(np.float64)
+    Xq = rng.integers(0, c["levels"], size=(m, p)).astype(np.float64)
+    y = X @ np.arange(1.0, p + 1.0) + rng.standard_normal(n)
+    kw = dict(nlvdis=0, metric="eucl", h=2.0, k=c["k"], nlv=2)
+    with np.errstate(all="ignore"):
+        ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, 2))
+    fm = J.lwplsr(X, y, ctx=ctx, **kw)
+    res = J.predict(fm, Xq, nlv=range(0, 2), ctx=ctx)
+    assert np.array_equal(res.listnn, ref["listnn"])
+    assert np.array_equal(res.listd, ref["listd"])                 # (square roots of the same small integers)
+
+
 def test_lwplsr_nan_query_row(J, ctx):
     """A missing value in ONE query row: its scores, hence all its distances, are NaN and no training row ever beats the
     bar.  The reference's arithmetic gives that query NaN predictions (predict on a NaN row) and leaves the others alone;
