@@ -434,6 +434,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
             if (job == q + 2) KS_STAMP(4);
             const int a = job - (q + 1);
             const double *x = xv;
+            double sx = 0.0, ux = 0.0;                 // 1'x and u'x of this job's product
             if (job == 0) x = dl;
             else if (job <= q) {
                 if (tid < KP) {
@@ -520,16 +521,19 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 __syncthreads();                                    // t_a and x published
                 if (a == 3) KS_STAMP(8);
                 // tt = t'D t and c = A't / tt, again per wave
-                double pt = 0.0, pc[Q];
+                // (and 1'x, u'x of the product below for x = D t: the same trip through LDS)
+                double pt = 0.0, pc[Q], px = 0.0, pu = 0.0;
 #pragma unroll
                 for (int y = 0; y < Q; ++y) pc[y] = 0.0;
                 for (int i = lane; i < KP; i += 64) {
-                    const double ti = Th[a * KP + i];
-                    pt += xv[i] * ti;
+                    const double ti = Th[a * KP + i], xi = xv[i];
+                    pt += xi * ti;
+                    px += xi; pu += uv[i] * xi;
 #pragma unroll
                     for (int y = 0; y < Q; ++y) pc[y] += Am[y * KP + i] * ti;
                 }
                 const double tt = ks_wave_sum(pt);
+                sx = ks_wave_sum(px); ux = ks_wave_sum(pu);
 #pragma unroll
                 for (int y = 0; y < Q; ++y) cv[y] = ks_wave_sum(pc[y]) / tt;
                 if (tid == 0) { tth[a] = tt; tauh[a] = tau; }
@@ -546,9 +550,11 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 if (kk >= nlvloc) break;              // (uniform) the last LV needs no deflation
             }
             // ---------------- y = G0 x from the accumulator registers, then the centring and the fixed-order combination
-            double px = 0.0, pu = 0.0;
-            for (int i = lane; i < KP; i += 64) { const double xi = x[i]; px += xi; pu += uv[i] * xi; }
-            const double sx = ks_wave_sum(px), ux = ks_wave_sum(pu);
+            if (job <= q) {
+                double px = 0.0, pu = 0.0;
+                for (int i = lane; i < KP; i += 64) { const double xi = x[i]; px += xi; pu += uv[i] * xi; }
+                sx = ks_wave_sum(px); ux = ks_wave_sum(pu);
+            }
             if (job == q + 4) KS_STAMP(10);
             {
                 double *pR = ypR + wv * (KS_TPW * 16), *pC = ypC + wv * (KS_TPW * 16);
