@@ -473,7 +473,9 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 if (a == 3) KS_STAMP(6);
                 // ---- per WAVE, no workgroup sums (each costs two barriers; the 208-long sums are 4 LDS trips for a wave): |K v|^2 =
                 // (A v)'(H v), g'(A v), and beta_j = t_j'D s / tt_j for the wave's share of the finished LVs
-                double p1 = 0.0, p2 = 0.0;
+                // (the wave's first beta — j = wave — rides along in the same trip through LDS; j = wave + 8, ... only from LV 9 on)
+                double p1 = 0.0, p2 = 0.0, pb = 0.0;
+                const int j0 = wv < a ? wv : 0;
                 for (int i = lane; i < KP; i += 64) {
                     double av = 0.0, hv = 0.0;
                     if constexpr (Q == 1) { av = Am[i]; hv = Hm[i]; }
@@ -482,10 +484,13 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                         for (int y = 0; y < Q; ++y) { av += Am[y * KP + i] * vl[y]; hv += Hm[y * KP + i] * vl[y]; }
                     }
                     p1 += av * hv; p2 += gv[i] * av;
+                    pb += Th[j0 * KP + i] * dl[i] * hv;
                 }
                 const double nrm = sqrt(ks_wave_sum(p1));
                 const double gom = ks_wave_sum(p2) / nrm;           // g'om, om = A v / nrm
-                for (int j = wv; j < a; j += KS_NW) {
+                pb = ks_wave_sum(pb);
+                if (wv < a && lane == 0) beta[wv] = pb / (nrm * tth[wv]);
+                for (int j = wv + KS_NW; j < a; j += KS_NW) {
                     double bsum = 0.0;
                     for (int i = lane; i < KP; i += 64) {
                         double hv = 0.0;
