@@ -79,6 +79,26 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             }
         }
     }
+    // (round 3) ... including the first trip of every small staging loop below: the sweep's slices, r, w, the raw-mode shift and
+    // the Z rows used to be loaded where they are consumed, each a round trip of its own BEHIND the wait for K — five dependent
+    // trips to L2, 15 k of the kernel's 48 k cycles.  Their first FT entries now go out here, with everything else.
+    const double *zsrc = g.bf_src ? g.bf_src : g.s.zt;
+    const int zld = g.bf_src ? g.bf_ld : g.ldz;
+    const int mz = g.bf_src ? g.bf_ldr + 2 : ldr + 1 + (g.algo == 1 ? 16 : (g.raw_mu ? 1 : 0));
+    const bool pre = !P2P && g.do_a;
+    double zpre[JCH_ZT_SLICES], rpre = 0.0, wpre = 0.0, mpre = 0.0, spre = 1.0, zlpre = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) zpre[sl] = 0.0;
+    if (pre && tid < mz) {
+        if (g.nslice == 1) zpre[0] = zsrc[tid];
+        else {
+#pragma unroll
+            for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) zpre[sl] = zsrc[(size_t)sl * zld + tid];
+        }
+    }
+    if (pre && tid < ldr) { rpre = g.s.r[tid]; wpre = g.s.w[tid]; }
+    if (pre && !g.bf_src && g.raw_mu && tid < p) { mpre = g.s.mshift[tid]; if (g.s.rs) spre = g.s.scl[tid]; }
+    if (rec && tid < a_old * QP) zlpre = g.s.Z[tid];
     if (needK) {   // K is [p][16] contiguous: flat coalesced loads, 16 in flight per thread, addresses clamped
         const int tot = p * 16;
         for (int base = 0; base < tot; base += FT * 16) {
@@ -95,13 +115,12 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     for (int e = tid; e < 5 * QP * lda; e += FT) G0[e] = 0.0;   // G0, A0, A1, V0, V1: zero padding
     if (tid < 32) cl[tid] = 0.0;                                 // cl, vl
     for (int e = tid; e < g.nlv; e += FT) ul[e] = 0.0;           // (prefetched R rows beyond a_old multiply zeros)
-    if (rec)
-        for (int e = tid; e < a_old * QP; e += FT) Zl[e] = g.s.Z[e];
+    if (rec) {
+        if (tid < a_old * QP) Zl[tid] = zlpre;
+        for (int e = tid + FT; e < a_old * QP; e += FT) Zl[e] = g.s.Z[e];
+    }
     // sweep output to reduce: f64 path: s.zt [nslice][ldz], first mz entries; bf16 storage mode (g.bf_src): the raw
     // [zp_raw (bf_ldr), tt, st] slices, turned into [zp, tt] below (zp_j = (zp_raw_j - m_j st) / s_j, bf16.hip header)
-    const double *zsrc = g.bf_src ? g.bf_src : g.s.zt;
-    const int zld = g.bf_src ? g.bf_ld : g.ldz;
-    const int mz = g.bf_src ? g.bf_ldr + 2 : ldr + 1 + (g.algo == 1 ? 16 : (g.raw_mu ? 1 : 0));
     if (P2P && g.do_a) {
         const int par = (int)(g.px.epoch & 1ull);
         char *mine = g.px.peer[g.px.rank];
@@ -139,7 +158,16 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         p2p_stat_end(g.px, tid, ts0);
         for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
     } else if (g.do_a) {
-        for (int c = tid; c < mz; c += FT) {
+        if (tid < mz) {   // (the first FT entries: loaded up front; same order of the slice sum)
+            double s = zpre[0];
+            if (g.nslice != 1) {
+                s = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < JCH_ZT_SLICES; ++sl) s += zpre[sl];
+            }
+            ztl[tid] = s;
+        }
+        for (int c = tid + FT; c < mz; c += FT) {
             double s;
             if (g.nslice == 1) {
                 s = zsrc[c];
@@ -153,7 +181,8 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             }
             ztl[c] = s;
         }
-        for (int j = tid; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
+        if (tid < ldr) { rl[tid] = rpre; wl[tid] = wpre; }
+        for (int j = tid + FT; j < ldr; j += FT) { rl[j] = g.s.r[j]; wl[j] = g.s.w[j]; }
     }
     if (g.do_a && g.bf_src) {   // (each thread rewrites only the entries it reads; slot ldr is outside every j < ldr)
         __syncthreads();
@@ -164,7 +193,11 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     } else if (g.do_a && g.raw_mu) {   // f64 raw mode (uncentred row copy): zp = zp_raw - mu * st, st = sum_i d_i t_i at [ldr + 1]
         __syncthreads();
         const double st_ = ztl[ldr + 1];
-        if (g.s.rs) { for (int j = tid; j < p; j += FT) ztl[j] = (ztl[j] - g.s.mshift[j] * st_) / g.s.scl[j]; }
+        if (pre) {   // (first FT entries from the registers loaded up front)
+            if (tid < p) ztl[tid] = g.s.rs ? (ztl[tid] - mpre * st_) / spre : ztl[tid] - mpre * st_;
+            if (g.s.rs) { for (int j = tid + FT; j < p; j += FT) ztl[j] = (ztl[j] - g.s.mshift[j] * st_) / g.s.scl[j]; }
+            else for (int j = tid + FT; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
+        } else if (g.s.rs) { for (int j = tid; j < p; j += FT) ztl[j] = (ztl[j] - g.s.mshift[j] * st_) / g.s.scl[j]; }
         else for (int j = tid; j < p; j += FT) ztl[j] -= g.s.mshift[j] * st_;
     }
     __syncthreads();
