@@ -451,6 +451,8 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     double ssq = 0.0;
 #pragma unroll
     for (int it = 0; it < JCH_SWEEP_MAXP / FT; ++it) {
+        wr[it] = 0.0;
+        if (it * FT >= p) continue;                    // (block-uniform: at p = 500 three of the four trips had nothing to do)
         const int j = min(tid + it * FT, p - 1);
         double wv_ = 0.0;
 #pragma unroll
