@@ -424,28 +424,40 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
     __syncthreads();
     JCH_STAMP(8);
     if (rec) {
-        if (tid < anext) {   // u = Z v
-            double u = 0.0;
-            if (defer && tid == a) {   // the new row arrives as DW partial rows (deferred work above): finish it here
-                const double tt = ztl[ldr];
-#pragma unroll
-                for (int k = 0; k < QP; ++k) {
+        if (defer) {
+            // the new row Z_a arrives as DW partial rows (deferred work above).  Sixteen lanes of wave 1 finish one entry each and
+            // sum z_k v_k among themselves (was: ONE lane of wave 0 doing the 16 entries, 16 divisions and 16 stores in turn while
+            // its wave waited — 5 k of the kernel's 45 k cycles)
+            if (wv == 1) {
+                double zv = 0.0;
+                if (lane < QP) {
+                    const double tt = ztl[ldr];
                     double z = 0.0;
 #pragma unroll
-                    for (int w = 0; w < DW; ++w) z += scratch[FT + w * 16 + k];
+                    for (int w = 0; w < DW; ++w) z += scratch[FT + w * 16 + lane];
                     z /= tt;
-                    Zl[a * QP + k] = z;
-                    g.s.Z[a * QP + k] = z;
-                    u += z * vl[k];
+                    Zl[a * QP + lane] = z;
+                    g.s.Z[a * QP + lane] = z;
+                    zv = z * vl[lane];
                 }
-            } else {
+                zv += __shfl_xor(zv, 8, 64); zv += __shfl_xor(zv, 4, 64); zv += __shfl_xor(zv, 2, 64); zv += __shfl_xor(zv, 1, 64);
+                if (lane == 0) ul[a] = zv;
+            }
+            if (tid < a) {   // u = Z v, finished rows
+                double u = 0.0;
 #pragma unroll
                 for (int k = 0; k < QP; ++k) u += Zl[tid * QP + k] * vl[k];
+                ul[tid] = u;
             }
+        } else if (tid < anext) {   // u = Z v
+            double u = 0.0;
+#pragma unroll
+            for (int k = 0; k < QP; ++k) u += Zl[tid * QP + k] * vl[k];
             ul[tid] = u;
         }
         for (int e = tid; e < (defer ? a : anext) * QP; e += FT) g.s.Z[e] = Zl[e];
     }
+    JCH_STAMP(12);
     // w_raw = K v ; ||w_raw||
     double wr[JCH_SWEEP_MAXP / FT];
     double ssq = 0.0;
@@ -461,7 +473,9 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         wr[it] = wv_;
         ssq += wv_ * wv_;
     }
+    JCH_STAMP(13);
     const double inv = 1.0 / sqrt(jch_block_sum<FT>(ssq, scratch));   // (its barriers also publish ul)
+    JCH_STAMP(14);
     // w = w_raw / ||.|| ;  r = (w_raw - R (Z v)) / ||.||   ==  w - sum_i (w . P_i) R_i
 #pragma unroll
     for (int it = 0; it < JCH_SWEEP_MAXP / FT; ++it) {
