@@ -3,6 +3,7 @@
 #pragma once
 #include "jch_internal.h"
 #include "p2p_dev.h"
+#include "rowsum_dev.h"
 
 #define FT 512   // threads of a single-workgroup small-state kernel
 
@@ -243,19 +244,27 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 __device__ static bool dominant_by_squaring_mfma16(int q, int lda, const double *G, double *vout, double *dbg, double *stamps = nullptr)
 {
     typedef double v4f64 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63;
-    double x[4];
+    const int lane = threadIdx.x & 63, kap = lane >> 4, l15 = lane & 15;
+    double x[4];      // D layout of the 16 x 16 iterate: x[j] = A[4 j + kap][l15]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = G[(4 * j + (lane >> 4)) * lda + (lane & 15)];
+    for (int j = 0; j < 4; ++j) x[j] = G[(4 * j + kap) * lda + l15];
+    // the lane's diagonal entry, if it holds one: A[m][m] sits in lane (kap, l15 = m) with m = 4 j + kap (round 3: the trace by a
+    // 16-lane DPP sum of these + four row totals instead of 16 readlanes per round; the column extraction below likewise works on
+    // the four lanes that hold the column instead of broadcasting its 16 entries)
+    const int jd = l15 - kap;
+    const bool hasd = jd >= 0 && (jd & 3) == 0;
+    const int jsel = jd >> 2;
+    auto diag_of = [&]() { double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d = (hasd && jsel == j) ? x[j] : d;
+        return d; };
+    auto rowsum16 = [](double v) { v += jch_dpp<0x128>(v); v += jch_dpp<0x124>(v); v += jch_dpp<0x122>(v); v += jch_dpp<0x121>(v); return v; };
     bool ok = false;
     int it = 0;
-    double dg[16];
     if (stamps && lane == 0) stamps[0] = (double)__builtin_readcyclecounter();
     for (; it < 10; ++it) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) dg[m] = readlane_f64(x[m >> 2], 16 * (m & 3) + m);
-        const double t = (((dg[0] + dg[1]) + (dg[2] + dg[3])) + ((dg[4] + dg[5]) + (dg[6] + dg[7]))) +
-                         (((dg[8] + dg[9]) + (dg[10] + dg[11])) + ((dg[12] + dg[13]) + (dg[14] + dg[15])));
+        const double rs = rowsum16(diag_of());
+        const double t = (readlane_f64(rs, 0) + readlane_f64(rs, 16)) + (readlane_f64(rs, 32) + readlane_f64(rs, 48));
         if (it > 0 && (1.0 - t) < 1e-2) { ok = true; break; }
         if (it == 9) break;
         double isc = __builtin_amdgcn_rcp(t);
@@ -274,29 +283,38 @@ __device__ static bool dominant_by_squaring_mfma16(int q, int lda, const double 
     if (lane == 0 && dbg) *dbg = ok ? 300 + 3 * it : -1;
     if (stamps && lane == 0) stamps[1] = (double)__builtin_readcyclecounter();
     if (!ok) return false;
-    // dominant eigenvector = the column of the largest diagonal entry (dg is wave-uniform), normalised, largest-|.| > 0
+    // dominant eigenvector = the column of the largest diagonal entry (first one among equals), normalised, largest-|.| > 0
+    double dg[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) dg[m] = readlane_f64(x[m >> 2], 16 * (m & 3) + m);
     int best = 0;
     double bd = dg[0];
 #pragma unroll
     for (int m = 1; m < 16; ++m)
         if (dg[m] > bd) { bd = dg[m]; best = m; }
     best = __builtin_amdgcn_readfirstlane(best);
-    double col[16], ss = 0.0, bigv = 0.0;
+    // column `best`: rows 4 j + kap are x[j] of lane (kap, best).  Sum of squares and the entry of largest magnitude (the first
+    // one in row order among equals, as before) over those four lanes
+    double pss = 0.0;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        col[m] = readlane_f64(x[m >> 2], 16 * (m & 3) + best);      // A[m][best]
-        ss += col[m] * col[m];
-        if (fabs(col[m]) > fabs(bigv)) bigv = col[m];
-    }
+    for (int j = 0; j < 4; ++j) pss += x[j] * x[j];
+    const double ss = (readlane_f64(pss, best) + readlane_f64(pss, 16 + best)) + (readlane_f64(pss, 32 + best) + readlane_f64(pss, 48 + best));
+    double bigv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {                 // row m = 4 j + kk, in order
+            const double c = readlane_f64(x[j], 16 * kk + best);
+            if (fabs(c) > fabs(bigv)) bigv = c;
+        }
     double y = __builtin_amdgcn_rsq(ss);            // 1 / sqrt(ss): hardware estimate + two Newton steps (full double)
     y = y * (1.5 - 0.5 * ss * y * y);
     y = y * (1.5 - 0.5 * ss * y * y);
     const double sc = bigv < 0.0 ? -y : y;
-    double mine = 0.0;
+    if (l15 == best) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m)
-        if (lane == m) mine = sc * col[m];
-    if (lane < 16) vout[lane] = lane < q ? mine : 0.0;
+        for (int j = 0; j < 4; ++j) vout[4 * j + kap] = 4 * j + kap < q ? sc * x[j] : 0.0;
+    }
     if (stamps && lane == 0) stamps[2] = (double)__builtin_readcyclecounter();
     return true;
 }
