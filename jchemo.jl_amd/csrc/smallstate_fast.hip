@@ -300,13 +300,25 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
         // Gram G = K'K on the matrix cores: v_mfma_f64_16x16x4 with A = B^T = a 4-row slab of K (the SAME register
         // is both operands: lane l holds K[j0 + (l>>4)][l&15]); each wave takes every 8th slab, partials combined in LDS.
         typedef double v4f64 __attribute__((ext_vector_type(4)));
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int j0 = 4 * wv; j0 < p; j0 += 4 * (FT / 64)) {
-            const int row = j0 + (lane >> 4);
-            const double x = Kl[min(row, p - 1) * ldk + (lane & 15)];
-            const double xz = row < p ? x : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xz, xz, acc, 0, 0, 0);
+        // (eight slabs' operands fetched together, two accumulators: one read + one DEPENDENT product per trip was 16 round trips
+        // of LDS latency + matrix-pipe latency per wave)
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int j0 = 4 * wv; j0 < p; j0 += 8 * 4 * (FT / 64)) {
+            double xs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = j0 + u * 4 * (FT / 64) + (lane >> 4);
+                const double x = Kl[min(row, p - 1) * ldk + (lane & 15)];
+                xs[u] = row < p ? x : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[u], xs[u], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[u + 1], xs[u + 1], acc1, 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[reg] += acc1[reg];
         double *gsc = csl + 2 * (QP + 2) + 8;   // [FT/64][256]
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) gsc[wv * 256 + reg * 64 + lane] = acc[reg];
