@@ -314,7 +314,9 @@ static hipEvent_t coll_event(jch_ctx *ctx)
 }
 void jch_coll_begin(jch_ctx *ctx)
 {
-    if (!ctx->profiling) return;
+    // pairs are recorded between the start of a fit and the collection of its profile only: the collectives of the other
+    // entry points (score sums, column statistics, covariances) would otherwise pile up in the pool, tagged as LV-loop
+    if (!ctx->profiling || !ctx->coll_in_fit || ctx->cev_used >= 8192) return;
     if (ctx->cev_used & 1) return;    // (unbalanced: a failed call left a begin behind — keep the pairing)
     if (coll_event(ctx)) ctx->cev_phase.push_back(ctx->coll_phase);
 }
@@ -328,6 +330,7 @@ void jch_coll_reset(jch_ctx *ctx)
     ctx->cev_used = 0;
     ctx->cev_phase.clear();
     ctx->coll_phase = 0;
+    ctx->coll_in_fit = true;
     ctx->coll_transport = JCH_TRANSPORT_NONE;
     if (ctx->profiling && ctx->p2p.stats) (void)hipMemsetAsync(ctx->p2p.stats, 0, 64, ctx->stream);
 }
@@ -336,6 +339,8 @@ void jch_coll_collect(jch_ctx *ctx, jch_profile &pr)
     pr.collective_ms = pr.prologue_collective_ms = pr.collective_wait_ms = 0.0;
     pr.collective_calls = 0;
     pr.collective_transport = ctx->coll_transport;
+    ctx->coll_in_fit = false;          // the fit is over: later collectives on this ctx are not its LV loop
+    ctx->coll_phase = 0;
     if (!ctx->profiling) return;
     for (size_t i = 0; 2 * i + 1 < ctx->cev_used && i < ctx->cev_phase.size(); ++i) {
         float ms = 0.f;
@@ -414,6 +419,7 @@ extern "C" int32_t jch_ctx_set_profiling(jch_ctx *ctx, int32_t enable)
 {
     if (!ctx) return JCH_EINVAL;
     ctx->profiling = enable != 0;
+    ctx->coll_in_fit = false;          // collective pairs are recorded from the next fit's start on
     return JCH_OK;
 }
 

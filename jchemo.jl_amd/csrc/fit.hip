@@ -102,9 +102,15 @@ public:
         if (hipStreamCreateWithFlags(&cs_, hipStreamNonBlocking) != hipSuccess) { cs_ = nullptr; return; }
         ev_.resize((size_t)ncols, nullptr);
         for (auto &e : ev_)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; release(); return; }
-        active_ = true;
-        th_ = std::thread([this] { run(); });
+            if (hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { e = nullptr; release(); return; }
+        // nothing may throw across the extern "C" entry points: a failed thread start (std::system_error at the process'
+        // thread limit) leaves the copier inactive and the fit takes the end-of-fit d2h path
+        try {
+            th_ = std::thread([this] { run(); });
+            active_ = true;
+        } catch (...) {
+            release();
+        }
     }
     ~t_column_copier() { finish(false); }
     bool active() const { return active_; }

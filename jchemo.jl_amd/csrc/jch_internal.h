@@ -73,6 +73,7 @@ struct jch_ctx {
     std::vector<int> cev_phase;      // one entry per PAIR
     size_t cev_used = 0;             // events handed out (2 per pair)
     int coll_phase = 0;
+    bool coll_in_fit = false;        // between jch_coll_reset (start of a fit) and jch_coll_collect
     int coll_transport = 0;          // JCH_TRANSPORT_* of the last LV-loop all-reduce
     // second stream + event (created on first use): result copies that may run beside the last kernel of a call (lwplsr.hip)
     hipStream_t aux_stream = nullptr;

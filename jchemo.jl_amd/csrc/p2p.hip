@@ -99,7 +99,7 @@ void jch_p2p_next(jch_ctx *ctx, p2p_dev *out)
     out->timeout_ticks = t.timeout_ticks;
     out->cap = t.cap;
     out->nranks = t.nranks; out->rank = t.rank;
-    out->stats = (ctx->profiling && t.stats) ? t.stats + 4 * (ctx->coll_phase ? 1 : 0) : nullptr;
+    out->stats = (ctx->profiling && ctx->coll_in_fit && t.stats) ? t.stats + 4 * (ctx->coll_phase ? 1 : 0) : nullptr;
 }
 
 static int32_t p2p_launch(jch_ctx *ctx, const double *src, int count, int nslice, int ldz, double *dst)

@@ -605,17 +605,34 @@ def _release_lwplsr_handle(handle):
         pass
 
 
+# Prepared device handles live OUTSIDE the `Lwplsr` instances (keyed by id(obj), dropped by a per-object finalizer): the
+# dataclass stays plain data, so copy / deepcopy / pickle of a predicted-from model work and a copy never shares — or outlives —
+# the original's handle.
+_LWPLSR_PREP = {}
+
+
+def _drop_lwplsr_prep(oid):
+    st = _LWPLSR_PREP.pop(oid, None)
+    if st is not None:
+        _release_lwplsr_handle(st["handle"])
+
+
 def _lwplsr_prepared(obj: Lwplsr, ctx, dev: bool, qk: int):
     """Device handle of the model-constant data of `obj` (include/jchemo_hip.h jch_lwplsr_prepare: row-major Xtrain, Ytrain, the
-    whitened training scores) + the query map, built on the first `predict` and kept with the object — the reference's `Lwplsr`
-    is fitted once and predicted from many times (src/lwplsr.jl:1-12).  qk: responses handed to the batched kernel."""
+    whitened training scores) + the query map, built on the first `predict` and kept for the object's lifetime — the reference's
+    `Lwplsr` is fitted once and predicted from many times (src/lwplsr.jl:1-12).  qk: responses handed to the batched kernel.
+    The cache key covers everything the handle was built from: re-assigning `obj.X`, `obj.Y`, `obj.fm`, `obj.metric` or
+    `obj.scal` after a predict rebuilds it (in-place edits of the arrays themselves are not detected)."""
     import weakref
-    key = (id(ctx), ctx._h.value, dev, qk)
-    st = obj.__dict__.get("_prep")
+    key = (id(ctx), ctx._h.value, dev, qk, id(obj.X), id(obj.Y), id(obj.fm), obj.metric, bool(obj.scal))
+    oid = id(obj)
+    st = _LWPLSR_PREP.get(oid)
     if st is not None and st["key"] == key:
         return st
     if st is not None:
-        st["fin"]()                                              # another ctx / residency: drop the old handle
+        _drop_lwplsr_prep(oid)                                   # another ctx / residency / model data: drop the old handle
+    else:
+        weakref.finalize(obj, _drop_lwplsr_prep, oid)
     Xt, Yt = obj.X, obj.Y
     try:
         _addr_ld(Xt); _addr_ld(Yt)
@@ -629,7 +646,8 @@ def _lwplsr_prepared(obj: Lwplsr, ctx, dev: bool, qk: int):
     h = C.c_void_p()
     ctx.check(_lib.load().jch_lwplsr_prepare(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, xa, n, p, ldx, ya, qk, ldy, za, ldz,
                                              Zt.shape[1], C.byref(h)))
-    st = {"key": key, "handle": h, "qmap": qmap, "dd": Zt.shape[1], "fin": weakref.finalize(obj, _release_lwplsr_handle, h), "device_map": False}
+    st = {"key": key, "handle": h, "qmap": qmap, "dd": Zt.shape[1], "device_map": False}
+    _LWPLSR_PREP[oid] = st
     # the query map travels with the handle: the library then takes Xq alone (two jch_affine_gemm calls per predict, each with
     # an upload of its matrix and a stream synchronisation, become two launches on the ctx stream)
     if stages and os.environ.get("JCH_LW_DEVICE_QMAP", "1") != "0":
@@ -639,7 +657,6 @@ def _lwplsr_prepared(obj: Lwplsr, ctx, dev: bool, qk: int):
             sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
             ctx.check(_lib.load().jch_lwplsr_add_query_map(ctx._h, h, _np(sh), _np(sc), B.ctypes.data, B.shape[0], B.shape[1], None))
         st["device_map"] = True
-    obj.__dict__["_prep"] = st
     return st
 
 

@@ -315,18 +315,18 @@ def test_lwplsr_device_query_map_is_the_same_arithmetic(kw, J, ctx, monkeypatch)
     full = dict(h=1.5, k=40, nlv=3, **kw)
     fm = J.lwplsr(X, y, ctx=ctx, **full)
     res = J.predict(fm, Xq, nlv=range(0, 4), ctx=ctx)
-    assert fm.__dict__["_prep"]["device_map"] == (kw["nlvdis"] > 0 or kw["scal"] or kw["metric"] == "mahal")
+    assert J.plsr._LWPLSR_PREP[id(fm)]["device_map"] == (kw["nlvdis"] > 0 or kw["scal"] or kw["metric"] == "mahal")
     monkeypatch.setenv("JCH_LW_DEVICE_QMAP", "0")
     fm2 = J.lwplsr(X, y, ctx=ctx, **full)
     ref = J.predict(fm2, Xq, nlv=range(0, 4), ctx=ctx)
-    assert not fm2.__dict__["_prep"]["device_map"]
+    assert not J.plsr._LWPLSR_PREP[id(fm2)]["device_map"]
     assert np.array_equal(res.listnn, ref.listnn) and np.array_equal(res.listd, ref.listd) and np.array_equal(res.listw, ref.listw)
     for a in range(4):
         assert np.array_equal(res.pred[a], ref.pred[a])
     # Zq = NULL without a map that ends in the model's dd columns is refused
-    if not fm2.__dict__["_prep"]["device_map"]:
+    if not J.plsr._LWPLSR_PREP[id(fm2)]["device_map"]:
         from jchemo_hip import _lib
-        h = fm2.__dict__["_prep"]["handle"]
+        h = J.plsr._LWPLSR_PREP[id(fm2)]["handle"]
         out = np.empty((m, 1, 1)); Xf = np.asfortranarray(Xq)
         st = _lib.load().jch_lwplsr_predict_prepared(ctx._h, h, _lib.LOC_HOST, None, 0, Xf.ctypes.data, m, m, 40, 1.5, fm2.tol, 0, 1, 1, out.ctypes.data, None, None, None)
         assert st != 0 and b"query map" in _lib.load().jch_last_error(ctx._h)
