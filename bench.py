@@ -209,9 +209,17 @@ def secondary_lwplsr(J, lib, ctx, dev, calls):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / calls
     pred = np.stack([p_[:, 0] for p_ in res.pred], axis=1)
     assert pred.shape == (m, nlv + 1) and np.all(np.isfinite(pred)), "lwplsr predictions are not finite"
+    # the same call WITHOUT the neighbour lists / distances / weights on the host (NULL outputs of the C ABI): predictions only
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(calls):
+        res_p = J.lwplsr_predict(fm, Xq, nlv=range(0, nlv + 1), ctx=ctx, lists=False)
+    torch.cuda.synchronize(); dt_p = (time.perf_counter() - t1) / calls
+    assert res_p.listnn is None and all(np.array_equal(a_, b_) for a_, b_ in zip(res.pred, res_p.pred))
     out = {"config": f"lwplsr predict n={n} p={p}, {m} queries x k={k} neighbours, nlvdis={nlvdis} mahal, nlv=0..{nlv} (BASELINE.json configs[4])",
            "metric": "queries/sec", "value": m / dt, "unit": "queries/s", "steps": calls, "warmup": 1, "ms_per_step": dt * 1e3, "dtype": "f64",
            "local_lv_per_s": m * nlv / dt,
+           "predictions_only": {"ms_per_step": dt_p * 1e3, "value": m / dt_p, "unit": "queries/s",
+                                "note": "the same call with NULL ind / dist / w outputs (no 3.2 MB D2H of the neighbour lists; not the reference's result shape)"},
            "roofline": _roof(gather_bytes, dev_ms["local_fits"], calls, "k_locw_* (batched local weighted plskern, one workgroup per query)",
                              note="algorithmic bytes = the gathered neighbour rows m k p 8 (SURVEY §8d: the path is latency / occupancy bound, "
                                   "the HBM fraction is reported for completeness; profiles/ holds the counted traffic)"),

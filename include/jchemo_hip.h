@@ -98,7 +98,7 @@ JCH_API int32_t jch_ctx_comm_init_loopback(jch_ctx *ctx, void *group, int32_t ra
 typedef struct jch_pls_desc {
     int64_t n;       /* rows held by THIS rank (all rows when single-GPU) */
     int64_t p;       /* columns of X */
-    int64_t q;       /* columns of Y (1..64) */
+    int64_t q;       /* columns of Y (>= 1; q <= 16 runs the LDS-resident small-state kernels, larger q a generic one) */
     int32_t nlv;     /* requested LVs; clamped to min(n_total, p, nlv) like plskern.jl:116 */
     int32_t scal;    /* 0/1: scale columns by their weighted uncorrected std (plskern.jl:123-126) */
     int32_t dtype;   /* JCH_F64 | JCH_BF16 */
@@ -167,7 +167,8 @@ JCH_API int32_t jch_col_stats(jch_ctx *ctx, int32_t loc, const double *X, int64_
  *   by sqrt(w) = 0 at :107 and returns NaN for them; desc->reserved |= JCH_WOLD_REF_ZERO_WEIGHT_NAN reproduces that).
  *   inplace = 1 hands back X, Y deflated AND carrying the row metric sqrt(w) (:57-58).
  * plssimp / plswold run their LDS-resident small-state kernels when q <= 16, p <= 2048 and the p x q state fits in LDS,
- * and a generic kernel (state in global memory, q <= 64, any p) otherwise; Float64 only. */
+ * and a generic kernel (state in global memory; any p, q and nlv — for q > 64 its q x q eigen-solver matrices live in
+ * global memory too) otherwise; Float64 only. */
 JCH_API int32_t jch_plssimp_fit(jch_ctx *ctx, const jch_pls_desc *desc, void *X, int64_t ldx, void *Y, int64_t ldy,
                         const double *weights, double *T, double *P, double *R, double *W, double *C,
                         double *TT, double *xmeans, double *xscales, double *ymeans, double *yscales,
@@ -223,12 +224,15 @@ JCH_API int32_t jch_weighted_ss(jch_ctx *ctx, int32_t loc, const double *X, int6
  *   k neighbours (clamped to n), h / tol: weight shape and floor; scal; nlv range nlv_lo..nlv_hi (contiguous)
  *   pred  m x le x q (le = nlv_hi - nlv_lo + 1), query-major: pred[(i*le + a)*q + y]              [HOST]
  *   ind_out (m x k, 0-based, row-major), dist_out, w_out (m x k): optional                       [HOST]
- * 1 <= q <= 16.  Two local-fit kernels: for k <= 208, q <= 8 and wide rows the fit runs in NEIGHBOUR space — the k x k Gram
- * matrix of the gathered rows, built on the matrix cores in one pass and held in registers (lwplsr_kspace.hip; same T, C
- * and predictions up to rounding) —, otherwise one workgroup per query sweeps the k x p slab once per LV (that kernel
- * fails with JCH_EINVAL when k, p and q together exceed the 150 KB of LDS the workgroup may use);
- * the constant-y shortcut of src/locwlv.jl:25-28 applies to q == 1 only, as in the reference.
- * n < 2^29 (the kNN scan addresses a training row by a 32-bit byte offset; JCH_EINVAL beyond), k <= 768.
+ * No shape limits (the reference has none: src/getknn.jl:29-57, src/locwlv.jl:9-48).  Inside the batched kernels' envelope —
+ * k <= 768 for the kNN scan; p <= 2048, q <= 16, nlv <= 48 and 150 KB of LDS for the local fits — one launch serves all m
+ * queries: for k <= 208, q <= 8 and wide rows the fit runs in NEIGHBOUR space (the k x k Gram matrix of the gathered rows, built
+ * on the matrix cores in one pass and held in registers: lwplsr_kspace.hip; same T, C and predictions up to rounding), otherwise
+ * one workgroup per query sweeps the k x p slab once per LV.  Outside it the generic paths of lwplsr_generic.hip run: an exact
+ * per-query selection of the k smallest distances (radix select + sort in global memory, the same distance expression: the
+ * same neighbours, order and distance bits), and one jch_plskern_fit + jch_predict per query on the gathered rows — the
+ * reference's own schedule (src/locwlv.jl:18-39); slower, never absent.
+ * The constant-y shortcut of src/locwlv.jl:25-28 applies to q == 1 only, as in the reference.
  * Neighbours at equal distance are ordered by their row index.
  */
 JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
@@ -242,7 +246,7 @@ JCH_API int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *Xtra
  * device data — the row-major copy of Xtrain the neighbour gathers read, Ytrain, the (whitened) training scores Ztrain — in
  * a handle; jch_lwplsr_predict_prepared is jch_lwplsr_predict without those three arguments and without their per-call
  * copies; jch_lwplsr_release frees the handle.  The handle belongs to the ctx's device; the inputs of prepare are not
- * referenced after it returns.  Same shape limits and errors as jch_lwplsr_predict. */
+ * referenced after it returns.  Same paths and errors as jch_lwplsr_predict. */
 typedef struct jch_lwplsr_model jch_lwplsr_model;
 JCH_API int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
                                    const double *Ytrain, int64_t q, int64_t ldy, const double *Ztrain, int64_t ldzt, int64_t dd,
@@ -262,9 +266,11 @@ JCH_API int32_t jch_lwplsr_release(jch_ctx *ctx, jch_lwplsr_model *model);
 JCH_API int32_t jch_lwplsr_add_query_map(jch_ctx *ctx, jch_lwplsr_model *model, const double *shift, const double *scale,
                                          const double *B, int64_t p_in, int64_t k_out, const double *bias);
 
-/* jch_weighted_cov — S = (A - 1 mu')' D (A - 1 mu') (d x d, d <= 64), D = diag(weights / sum); weights NULL = ones:
- * `Statistics.cov(Xtrain, corrected = false)` of getknn's Mahalanobis branch (src/getknn.jl:38).  A n x d [loc];
- * S (column-major d x d) and mu (d, may be NULL) HOST. */
+/* jch_weighted_cov — S = (A - 1 mu')' D (A - 1 mu') (d x d), D = diag(weights / sum); weights NULL = ones:
+ * `Statistics.cov(Xtrain, corrected = false)` of getknn's Mahalanobis branch (src/getknn.jl:38; with nlvdis = 0 the
+ * reference whitens the raw X, src/lwplsr.jl:21: d = p).  d <= 64: the X'DY kernels of the fit with Y = A; wider: the centred
+ * row-major copy + the tiled MFMA SYRK of the opt-in algorithm #2.  A n x d [loc]; S (column-major d x d) and mu (d, may be
+ * NULL) HOST. */
 JCH_API int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, int64_t n, int64_t d, int64_t lda,
                                  const double *weights, double *S, double *mu);
 

@@ -1140,6 +1140,9 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
             const bool fuse = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED") && (size_t)(ldr_b + 2) <= ctx->p2p.cap;
             if (!fuse) JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));
             else ctx->coll_transport = JCH_TRANSPORT_INBOX_FUSED;
+            if (s.kr)   // split small-state path (smallstate_split.hip): the slices are summed (and, with the inbox, exchanged) by its p-parallel kernel
+                JCH_TRY(jch_launch_lv_split(ctx, s, p, q, ldr_small, a, nlv, zt8, nslice, ldzb, ldr_b, ldr_b + 1, 2, a + 1 < nlv, fuse));
+            else
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, nslice, ldz, true, fuse, zt8, ldzb, ldr_b));
         } else {
             JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));

@@ -46,7 +46,7 @@ int32_t validate(jch_ctx *ctx, const fit_io &io, const char *who)
     if (!d) return jch_fail(ctx, JCH_EINVAL, "%s: desc is NULL", who);
     if (d->n < 1 || d->p < 1 || d->q < 1) return jch_fail(ctx, JCH_EINVAL, "%s: empty input (n=%lld p=%lld q=%lld)", who,
                                                          (long long)d->n, (long long)d->p, (long long)d->q);
-    if (d->q > JCH_MAXQ) return jch_fail(ctx, JCH_EINVAL, "%s: q=%lld > %d not supported", who, (long long)d->q, JCH_MAXQ);
+    if (d->q > (1 << 12)) return jch_fail(ctx, JCH_EINVAL, "%s: q=%lld too large", who, (long long)d->q);
     if (d->p > JCH_SWEEP_MAXP && d->dtype != JCH_F64)
         return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld > %d is supported for Float64 only", who, (long long)d->p, JCH_SWEEP_MAXP);
     if (d->p > (1 << 20)) return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld too large", who, (long long)d->p);
@@ -235,7 +235,8 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
 
     t_column_copier tcopy(ctx, (host && d.dtype == JCH_F64 && !(algo == ALGO_WOLD && (d.reserved & JCH_WOLD_REF_ZERO_WEIGHT_NAN))) ? io.T : nullptr, Tdev, n, nlv_cap);
     const size_t small_bytes = 256 * 21 + sizeof(double) * 16 * 2048 + sizeof(double) * (64 + (size_t)p + (size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
-                                                         (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128);
+                                                         (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128 +
+                                                         (p <= JCH_SWEEP_MAXP ? (size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv_cap) + 128 : 0));
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
@@ -256,6 +257,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     s.hdr = cv.take(8);
     s.variant = 0;
     s.niter = algo == ALGO_WOLD ? niter_dev : nullptr;
+    s.kr = nullptr; s.gpart = nullptr;
     // host copies of the small outputs: one pinned staging buffer, then plain memcpy into the caller's arrays
     auto fetch_small = [&](int k) -> int32_t {
         JCH_TRY(jch_reserve_host(ctx, out_bytes));
@@ -288,6 +290,13 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
         if (algo != ALGO_KERN) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
         const bool fastb = q <= 16 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
+        {   // split small-state path (see the f64 loop below); the fused inbox exchange keeps the one-kernel path
+            const char *e_sp = getenv("JCH_LV_SPLIT");
+            const bool fuse_b = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
+            if (fastb && (!fuse_b || jch_lv_split_p2p_ok(ctx, p)) && !(e_sp && atoi(e_sp) == 0) && jch_lv_solve_lds_bytes(p, q, ldr, nlv_cap) <= 150 * 1024) {
+                s.kr = cv.take(16); s.gpart = cv.take((size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv_cap));
+            }
+        }
         hipEvent_t evb = jch_ev(ctx);
         int nlvb = 0;
         JCH_TRY(jch_fit_plskern_bf16(ctx, d, io.X, io.ldx, io.Y, io.ldy, wdev, dn, Tdev, s, ldr, qpad, ldz, fastb, &nlvb));
@@ -334,7 +343,6 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     const int max_slices = all_fast ? JCH_ZT_SLICES : 1;
     const bool fuse_inbox = all_fast && ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED") &&
                             (size_t)(ldr + 1 + qpad) <= ctx->p2p.cap;   // the fused kernel writes one whole message into one inbox slot
-    if (sib && !all_fast && nlv > 256) return jch_fail(ctx, JCH_EINVAL, "%s: nlv > 256 outside the LDS-resident envelope is not supported", who);
     int nslice = 1;
     // ---- K1 means (+ two-pass std), K2 centre/scale + row-major copy + XtY
     const bool ext_scales = io.xscales_in != nullptr;
@@ -380,6 +388,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     // ---- LV loop
     const size_t sweep_ev0 = ctx->ev_used;
     const bool variant2 = (d.reserved & 1) != 0;
+    bool split = false;
     const bool wold_ref_nan = algo == ALGO_WOLD && (d.reserved & JCH_WOLD_REF_ZERO_WEIGHT_NAN) != 0;
     int x_reads = 0, x_writes = 0;   // plsnipals-shaped loops: whole passes over the working copy (profile: bytes actually moved)
     if (variant2) {   // OPT-IN kernel algorithm #2 (kern2.hip): Gram once, LV loop without X and without collectives
@@ -399,15 +408,37 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     else if (algo == ALGO_SIMP) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, 2, 1, ldz, false));
     else if (algo == ALGO_WOLD && all_fast) JCH_TRY(jch_launch_wold_b(ctx, s, p, q, ldr, 0, nlv, io.tol, io.maxit));
     else if (algo == ALGO_WOLD) JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, 0 | 0x20000000, nlv, 4, 1, ldz, false, false, nullptr, 0, 0, io.tol, io.maxit));
-    else JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, kern_like ? 0 : 1, 1, ldz, fast));
+    else {
+        // SPLIT small-state path (smallstate_split.hip; round 4): per LV a p-parallel kernel on (p + 15) / 16 CUs (slice sums, c,
+        // K update, P / W / R columns, partial Gram / Z sums) + a single-workgroup kernel that starts at the eigenvector.  plskern /
+        // plsrosa on the fast path; not with the inbox all-reduce fused into the one-kernel path.  JCH_LV_SPLIT=0: the one-kernel path.
+        const char *e_sp = getenv("JCH_LV_SPLIT");
+        split = (algo == ALGO_KERN || algo == ALGO_ROSA) && fast && !(e_sp && atoi(e_sp) == 0) &&
+                jch_lv_solve_lds_bytes(p, q, ldr, nlv) <= 150 * 1024 && (!fuse_inbox || jch_lv_split_p2p_ok(ctx, p));
+        if (split) { s.kr = cv.take(16); s.gpart = cv.take((size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv)); }
+        JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, kern_like ? 0 : 1, 1, ldz, fast));
+    }
     int npend = 0, pend_a0 = 0;   // postponed deflations: LVs pend_a0 .. pend_a0 + npend - 1
     if (pend_p) JCH_HIP(ctx, hipMemsetAsync(pend_p, 0, sizeof(double) * (size_t)defer_m * jch_nipals_lazy_pitch(ldr), ctx->stream));
     for (int a = 0; a < nlv; ++a) {
         double *tcol = Tdev + (size_t)a * (size_t)n;
         if (kern_like) {
-            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.rs ? s.rs : s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice, raw_mode ? s.mshift : nullptr));
+            jch_part_view pv;
+            const bool split_fused = split && fuse_inbox;   // the exchange happens inside k_lv_spread, on the rank's OWN partial rows
+            JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.rs ? s.rs : s.r, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice, raw_mode ? s.mshift : nullptr,
+                                     split && (ctx->nranks == 1 || split_fused) ? &pv : nullptr));
             tcopy.column_done(a);
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;   // rank-independent message size (a small shard may use 1 slice; the rest hold zeros)
+            if (split) {
+                // one GPU: k_lv_spread sums the sweep's block partials itself; several: the slices are all-reduced first
+                if (!pv.part) {   // (a sweep kernel that reduced into zt: the slices are the partial rows)
+                    if (!split_fused) JCH_TRY(jch_allreduce_slices(ctx, s.zt, ldr + 1 + (raw_mode ? 1 : 0), nslice, ldz, &nslice));
+                    pv.part = s.zt; pv.nb = nslice; pv.ldpart = ldz;
+                }
+                if (split_fused) ctx->coll_transport = JCH_TRANSPORT_INBOX_FUSED;
+                JCH_TRY(jch_launch_lv_split(ctx, s, p, q, ldr, a, nlv, pv.part, pv.nb, pv.ldpart, ldr, raw_mode ? ldr + 1 : -1, raw_mode ? 1 : 0, a + 1 < nlv, split_fused));
+                continue;
+            }
             // ONE collective per LV: [zp (p), tt].  With the inbox transport and the fast small-state kernel it happens
             // INSIDE that kernel (no launch of its own); otherwise here (RCCL / inbox kernel / loopback).
             if (fuse_inbox && algo != ALGO_SIMP) {
@@ -422,7 +453,10 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         } else {
             if (pend_p) JCH_TRY(jch_launch_sweep_lazy(ctx, Xr, n, ldr, dn, s.w, Yr, qpad, tcol, s.zt, ldz, max_slices, &nslice, pend_p, npend,
                                                       defer_m - 1, Tdev + (size_t)pend_a0 * (size_t)n, n));
-            else JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
+            else if (qpad > 64) {   // more responses than the NIPALS sweep has lanes for: t, tt, zp from the plskern-shaped sweep, c_raw = Y'Dt on its own
+                JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, 0, tcol, s.zt, ldz, max_slices, &nslice));
+                JCH_TRY(jch_launch_ytdt(ctx, Yr, n, qpad, dn, tcol, s.zt + ldr + 1));
+            } else JCH_TRY(jch_launch_sweep(ctx, Xr, n, p, ldr, dn, s.w, Yr, qpad, q, tcol, s.zt, ldz, max_slices, &nslice));
             tcopy.column_done(a);
             if (ctx->nranks > 1 && max_slices > 1) nslice = JCH_ZT_SLICES;
             ++x_reads;
@@ -513,7 +547,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         (void)hipMemcpy(st.data(), s.dbg + 512, sizeof(double) * st.size(), hipMemcpyDeviceToHost);
         for (int c : {0, 1, nlv / 2, nlv - 1}) {
             fprintf(stderr, "[jch] lv_update call %d stamps (cycles since kernel start):", c);
-            for (int k = 1; k < 16; ++k) if (st[16 * c + k] > 0) fprintf(stderr, " %d:%.0f", k, st[16 * c + k] - st[16 * c]);
+            for (int k = 1; k < 16; ++k) if (st[16 * c + k] > 0) fprintf(stderr, " %d:%.0f", k, st[16 * c + k] - st[16 * c]);   // (split path: 5-7 = k_lv_spread's block 0, before the solve kernel's origin)
             fprintf(stderr, "\n");
         }
     }

@@ -222,74 +222,89 @@ __global__ __launch_bounds__(256) void k_affine_gemm32s(const double *__restrict
 // single barrier, X loads PD k-steps ahead of the MFMAs in a rotating register window.  With f64 MFMA at the vector rate
 // (64 cycles per 16x16x4) the product itself is 0.41 ms at cfg2 / nlv = 25 against 0.50 ms of HBM time for X: the kernel
 // is co-bound, and what matters is that neither pipe waits for the other.
-template <int NT, int NW>   // NW waves per workgroup share the one LDS copy of the coefficients
+template <int NT, int NW, int RT>   // NW waves per workgroup share the one LDS copy of the coefficients; RT row tiles of 32 per wave-tile
 __global__ __launch_bounds__(64 * NW) void k_affine_gemm32p(const double *__restrict__ Xc, int64_t m, int p, int64_t ldx,
                                                          const double *__restrict__ Bs, int kpad, const double *__restrict__ bias,
                                                          int k, double *__restrict__ out, int64_t ldo)
 {
     extern __shared__ __attribute__((aligned(16))) double blp[];   // [nksp * 4][PB], zero rows beyond p
-    constexpr int PB = 16 * NT + 1, PD = 16;
+    // RT (round 4): a wave's tile is 32 RT rows — per column RT back-to-back 256-B pieces = one 256 RT-byte run of the column-major
+    // X instead of 256 B (the DRAM access granularity of this kernel); the prefetch window holds the same bytes (PD k-steps x RT)
+    constexpr int PB = 16 * NT + 1, PD = 16 / RT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nksp = ((p + 3) / 4 + PD - 1) / PD * PD;              // k-steps, padded to the prefetch window
+    const int nksp = ((p + 3) / 4 + 15) / 16 * 16;                  // k-steps, padded to the largest prefetch window
     for (int e = tid; e < nksp * 4 * 16 * NT; e += 64 * NW) {
         const int jj = e / (16 * NT), cc = e % (16 * NT);
         blp[jj * PB + cc] = jj < p ? Bs[(size_t)jj * kpad + cc] : 0.0;
     }
     __syncthreads();
     const int kq = lane >> 4, cl = lane & 15;
-    const int64_t ntile = (m + 31) / 32, tstep = (int64_t)gridDim.x * NW;
+    constexpr int TR = 32 * RT;
+    const int64_t ntile = (m + TR - 1) / TR, tstep = (int64_t)gridDim.x * NW;
     int64_t tile = (int64_t)blockIdx.x * NW + wv;
     if (tile >= ntile) return;
     // EVERY load is unconditional (m is even: row pairs past the end re-read the last pair, columns past p re-read column
     // p - 1 against zero coefficients): with a branch around a load the compiler loses track of the outstanding-load
     // count and waits for all of them (vmcnt(0)) before every MFMA group — measured 2.3x slower than the tiled kernel.
-    auto rowptr = [&](int64_t t) { int64_t ir = t * 32 + 2 * cl; if (ir > m - 2) ir = m - 2; return Xc + ir; };
-    auto ld = [&](const double *base, int ks) {
+    auto rowoff = [&](int64_t t, int rt) { int64_t ir = t * TR + 32 * rt + 2 * cl; if (ir > m - 2) ir = m - 2; return ir; };
+    auto ld = [&](int64_t ir, int ks) {
         const int j = min(4 * ks + kq, p - 1);
-        return __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(base + (size_t)j * (size_t)ldx));
+        return __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(Xc + ir + (size_t)j * (size_t)ldx));
     };
-    const double *cur = rowptr(tile), *nxt = rowptr(min(tile + tstep, ntile - 1));
-    v2f64 x[PD];
+    int64_t cur[RT], nxt[RT];
 #pragma unroll
-    for (int u = 0; u < PD; ++u) x[u] = ld(cur, u);
+    for (int rt = 0; rt < RT; ++rt) { cur[rt] = rowoff(tile, rt); nxt[rt] = rowoff(min(tile + tstep, ntile - 1), rt); }
+    v2f64 x[PD][RT];
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) x[u][rt] = ld(cur[rt], u);
     for (; tile < ntile; tile += tstep) {
-        v4f64 acc[2][NT];
+        v4f64 acc[RT][2][NT];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int b = 0; b < NT; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[rt][a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
         for (int ks0 = 0; ks0 < nksp; ks0 += PD) {
             const bool wrap = ks0 + PD >= nksp;           // the window runs on into the wave's next tile
-            const double *pb = wrap ? nxt : cur;
             const int kb = wrap ? ks0 + PD - nksp : ks0 + PD;
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
                 const double *bp = blp + (4 * (ks0 + u) + kq) * PB + cl;
+                double b[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const double b = bp[16 * t];
-                    acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, b, acc[0][t], 0, 0, 0);
-                    acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, b, acc[1][t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) b[t] = bp[16 * t];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc[rt][0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][rt].x, b[t], acc[rt][0][t], 0, 0, 0);
+                        acc[rt][1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][rt].y, b[t], acc[rt][1][t], 0, 0, 0);
+                    }
+                    x[u][rt] = ld(wrap ? nxt[rt] : cur[rt], kb + u);
                 }
-                x[u] = ld(pb, kb + u);
             }
         }
-        const int64_t i0 = tile * 32;
+        const int64_t i0 = tile * TR;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = 16 * t + cl;
             if (col >= k) continue;
             const double bv = bias[col];
 #pragma unroll
-            for (int par = 0; par < 2; ++par)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int64_t i = i0 + 2 * (kq + 4 * reg) + par;
-                    if (i < m) out[(size_t)i + (size_t)col * (size_t)ldo] = acc[par][t][reg] + bv;
-                }
+                for (int par = 0; par < 2; ++par)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int64_t i = i0 + 32 * rt + 2 * (kq + 4 * reg) + par;
+                        if (i < m) out[(size_t)i + (size_t)col * (size_t)ldo] = acc[rt][par][t][reg] + bv;
+                    }
         }
-        cur = nxt;
-        nxt = rowptr(min(tile + 2 * tstep, ntile - 1));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { cur[rt] = nxt[rt]; nxt[rt] = rowoff(min(tile + 2 * tstep, ntile - 1), rt); }
     }
 }
 
@@ -303,23 +318,21 @@ int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p,
         if (!(ep && atoi(ep) == 0) && ldsp <= 150 * 1024 && m >= 64 * 1024 && m % 2 == 0 && ldx % 2 == 0 && (((uintptr_t)Xc) & 15) == 0) {
             // two waves per SIMD, so that one wave's MFMAs cover the other's wait for its loads: two workgroups of 4 waves per CU
             // while two copies of the coefficients fit in LDS (kpad = 16 at cfg2), else ONE workgroup of 8 waves sharing one copy
-            static jch_per_device_once attr;
-            if (!attr.done(ctx->device)) {
-                JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr.mark(ctx->device);
-            }
             // (measured at cfg2, kernel time: nlv = 25 -> 32 columns: 4 waves 0.96 ms, 8 waves 0.87, 12 waves 0.87, tiled kernel 1.03;
             // 10 -> 16 columns: 2 x 4 waves 0.71 ms, 8 waves 0.73, 12 waves 0.75, tiled kernel 0.73.  JCH_GEMM_NW = 4 / 8 overrides.)
-            const char *enw = getenv("JCH_GEMM_NW");
+            const char *enw = getenv("JCH_GEMM_NW"), *ert = getenv("JCH_GEMM_RT");
             const int nw = enw ? (atoi(enw) == 4 ? 4 : 8) : (kpad == 16 ? 4 : 8);
+            const int rt = ert ? (atoi(ert) == 1 ? 1 : (atoi(ert) == 4 ? 4 : 2)) : 2;   // row tiles per wave-tile: 256 rt bytes per column piece
             const int bpc = std::max(1, std::min((int)((158 * 1024) / ldsp), 8 / nw));
-            const unsigned nb = (unsigned)std::min<int64_t>((m + 32 * nw - 1) / (32 * nw), (int64_t)ctx->cus * bpc);
-#define JCH_G32P(NT, NW) hipLaunchKernelGGL((k_affine_gemm32p<NT, NW>), dim3(nb), dim3(64 * NW), ldsp, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo)
-            if (kpad == 16) { if (nw == 4) JCH_G32P(1, 4); else JCH_G32P(1, 8); }
-            else { if (nw == 4) JCH_G32P(2, 4); else JCH_G32P(2, 8); }
+            const unsigned nb = (unsigned)std::min<int64_t>((m + 32 * rt * nw - 1) / (32 * rt * nw), (int64_t)ctx->cus * bpc);
+#define JCH_G32P(NT, NW, RT) do { \
+                static jch_per_device_once once_; \
+                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<NT, NW, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
+                hipLaunchKernelGGL((k_affine_gemm32p<NT, NW, RT>), dim3(nb), dim3(64 * NW), ldsp, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo); } while (0)
+#define JCH_G32P_RT(NT, NW) do { if (rt == 1) JCH_G32P(NT, NW, 1); else if (rt == 2) JCH_G32P(NT, NW, 2); else JCH_G32P(NT, NW, 4); } while (0)
+            if (kpad == 16) { if (nw == 4) JCH_G32P_RT(1, 4); else JCH_G32P_RT(1, 8); }
+            else { if (nw == 4) JCH_G32P_RT(2, 4); else JCH_G32P_RT(2, 8); }
+#undef JCH_G32P_RT
 #undef JCH_G32P
             JCH_HIP(ctx, hipGetLastError());
             return JCH_OK;

@@ -10,7 +10,7 @@
 
 #include "jchemo_hip.h"
 
-#define JCH_MAXQ 64       // Jacobi workspace bound (q x q in LDS)
+#define JCH_MAXQ 64       // largest q whose Jacobi workspace (q x q matrices) lives in LDS; beyond: global memory (smallstate.hip)
 #define JCH_ZT_SLICES 8      // max second-stage partial slices of the sweep reduction
 #define JCH_SWEEP_MAXP 2048  // widest row the register-resident fused sweep holds (16 column chunks of 128)
 
@@ -60,7 +60,7 @@ struct jch_ctx {
     // workspace (grow-only)
     void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
     size_t hstage_bytes = 0;
-    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz;
+    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz, lw_work, lw_xrm, lvws;
     // profiling
     bool profiling = false;
     jch_profile prof{};
@@ -128,6 +128,12 @@ void jch_coll_end(jch_ctx *ctx);
 void jch_coll_reset(jch_ctx *ctx);   // start of a fit: forget the pairs, zero the inbox tick counters
 void jch_coll_collect(jch_ctx *ctx, jch_profile &pr);   // after the fit's final sync: fill the collective fields
 
+// sweep output as the per-block partial rows (the launcher skipped its k_reduce_part): part [nb][ldpart]
+struct jch_part_view {
+    const double *part = nullptr;
+    int nb = 0, ldpart = 0;
+};
+
 // ---- kernel launchers (each enqueues on ctx->stream; no host sync) --------------------------------
 // prologue.hip
 int32_t jch_launch_weights(jch_ctx *ctx, const double *w_dev /*may be null*/, int64_t n, double *dnorm,
@@ -153,13 +159,15 @@ int32_t jch_launch_export_colmajor(jch_ctx *ctx, const double *Xr, int ldr, cons
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra /*0: plskern; q: also c_raw (plsnipals)*/,
                          double *tcol, double *zt /*[nslice][ldz] device, reduced over blocks*/, int ldz, int max_slices,
-                         int *nslice_out, const double *mu = nullptr /*raw mode: Xr is uncentred; t = x.r - mu.r, st at [ldr+1]*/);
+                         int *nslice_out, const double *mu = nullptr /*raw mode: Xr is uncentred; t = x.r - mu.r, st at [ldr+1]*/,
+                         jch_part_view *pv = nullptr /*non-null: the launcher MAY leave the block partials unreduced and describe them here (pv->part stays null when it reduced into zt as usual)*/);
 int32_t jch_launch_reduce_rows(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *out);
 int32_t jch_launch_raw_scales(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *mshift,
                               const double *Yr, int qpad, int q, double *tmp, double *scl, double *K);
 int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *zt, int ldz, int *nslice_out);
 int32_t jch_launch_sweep_wide(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
                               const double *Yr, int qpad, bool nipals, double *tcol, double *zt);
+int32_t jch_launch_ytdt(jch_ctx *ctx, const double *Yr, int64_t n, int qpad, const double *d, const double *tcol, double *out /*[qpad]*/);   // sweep_wide.hip
 // plsnipals with postponed write-back (sweep.hip, deflate.hip): the working copy holds the rows of `npend` LVs ago; pending
 // loadings pend_p[k][jch_nipals_lazy_pitch(ldr)] (pad columns zero), pending scores tpend + k * tstride, oldest first
 #define JCH_NIPALS_DEFER_DEFAULT 6   // rows rewritten every 6th LV (cfg4, ms per LV: eager 8.5-8.9; m = 2: 6.6, 4: 5.76, 5-7: 5.3-5.55, 8-9: 5.45-5.5 — up to 4 pending corrections hide behind the loads, each further one costs ~0.17 ms per pass in LDS reads)
@@ -195,7 +203,10 @@ struct jch_small {  // device-resident replicated small state of one fit
                         // 2: algorithm #1 in raw mode (uncentred row copy: zt holds [zp_raw, tt, st], zp = zp_raw - mom * st)
     double *dbg;        // [nlv + 1] diagnostics (JCH_LV_DEBUG): Jacobi sweeps per LV; may be null
     double *niter;      // [nlv] plswold: inner iterations per LV (src/plswold.jl:93); null otherwise
+    double *kr;         // [16] split small-state path (smallstate_split.hip): K' r of the current LV; null otherwise
+    double *gpart;      // [blocks][gld] split path: per-block partials of K_new'K_new, zp'K_new and P_i . zp; null otherwise
 };
+
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a /*-1: init*/,
                              int nlv, int algo /*0 plskern, 1 plsnipals*/, int nslice, int ldz, bool fast, bool fuse_p2p = false,
                              const double *bf_src = nullptr, int bf_ld = 0, int bf_ldr = 0, double tol = 0.0, int maxit = 0);
@@ -203,6 +214,14 @@ size_t jch_lv_fast_lds_bytes(int p, int q, int qpad, int ldr, int nlv);
 int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a, int nlv, int algo,
                                   int do_a, int do_b, int nslice, int ldz, bool fuse_p2p = false, const double *bf_src = nullptr,
                                   int bf_ld = 0, int bf_ldr = 0);
+// smallstate_split.hip: the per-LV step of the plskern-shaped loop as a p-parallel kernel + a single-workgroup kernel
+int jch_lv_split_blocks(int p);
+int jch_lv_split_gld(int nlv);
+size_t jch_lv_solve_lds_bytes(int p, int q, int ldr, int nlv);
+int32_t jch_launch_lv_split(jch_ctx *ctx, const jch_small &s, int p, int q, int ldr, int a, int nlv, const double *part, int nb,
+                            int ldpart, int itt, int ist /*< 0: none*/, int mode /*0 centred copy, 1 f64 raw mode, 2 bf16*/, bool solve,
+                            bool fuse_p2p = false /*the inbox all-reduce of the LOCAL partial rows inside the p-parallel kernel, block by block*/);
+bool jch_lv_split_p2p_ok(const jch_ctx *ctx, int p);
 struct p2p_dev;
 void jch_p2p_next(jch_ctx *ctx, p2p_dev *out);   // p2p.hip: device view of the inbox transport for the next epoch
 int32_t jch_launch_nipals_R(jch_ctx *ctx, const jch_small &s, int p, int nlv);

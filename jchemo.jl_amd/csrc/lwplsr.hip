@@ -168,19 +168,7 @@ __device__ static int knn_wave_compact(double *key, int *idx, int c0, int k, dou
 }
 __device__ __forceinline__ int knn_pow2_at_least(int v) { int c = 64; while (c < v) c <<= 1; return c; }
 
-struct knn_args {
-    const double *Zt; int64_t ldzt; int64_t n;   // train scores, column-major n x dd
-    const double *Zq; int64_t ldzq; int m;       // query scores, column-major m x dd
-    int dd, k;
-    double h, cri, tol;
-    int *ind;      // [m][k]
-    double *dist;  // [m][k]
-    double *w;     // [m][k]
-    int nseg;      // the training rows are scanned in nseg segments by different workgroups (block b: segment b % nseg, query group b / nseg)
-    double *ckey;  // [m][nseg][k] squared distances of every segment's k best (ascending; +inf beyond the segment's rows)
-    int *cidx;     // [m][nseg][k]
-    int dbg;       // measurement switch (JCH_KNN_DBG; results then wrong by design): 1 = the bar starts at -inf (no candidate is ever kept: the bare scan)
-};
+// (struct knn_args: lwplsr_dev.h)
 
 // NT threads per workgroup, QB queries per workgroup (every loaded training value serves QB queries).  <256, 4>: two workgroups
 // per CU (default); <512, 8> (round 3, JCH_KNN_WIDE=1): ONE workgroup of eight waves per CU — the same waves in flight, half the
@@ -864,6 +852,18 @@ static int32_t launch_locw(jch_ctx *ctx, locw_args &g)
     return launch_locw_q<KC, 16>(ctx, g);
 }
 
+// the shape fits one of the batched local-fit kernels (the conditions of launch_locw_q / jch_locw_kspace_feasible)
+static bool locw_batched_fits(const locw_args &g)
+{
+    if (g.q > 16 || g.nlv_hi > 48 || g.ldr > JCH_SWEEP_MAXP) return false;
+    if (jch_locw_kspace_feasible(g)) return true;
+    const int KC = g.ldr <= 128 ? 1 : g.ldr <= 256 ? 2 : g.ldr <= 512 ? 4 : g.ldr <= 1024 ? 8 : 16;
+    const size_t Q = g.q <= 1 ? 1 : g.q <= 2 ? 2 : g.q <= 4 ? 4 : g.q <= 8 ? 8 : 16;
+    const size_t lds = sizeof(double) * ((1 + Q) * g.k + (5 + Q) * g.ldr + 4 * KC * 128 + 128 + 4 * Q + 16 + 5 * Q * (Q + 2) +
+                                         2 * (Q + 2) + 8 + 4 * (Q * (Q + 1) / 2 + Q + 1)) + sizeof(int) * (size_t)g.k + 64;
+    return lds <= 150 * 1024;
+}
+
 // ---------------------------------------------------------------- C ABI
 // The model-constant part of a prediction: what `lwplsr(X, Y; ...)` holds (src/lwplsr.jl:1-12, 114-131) in the form the
 // kernels want it — the row-major copy of Xtrain for the 4 KB-contiguous neighbour gathers, device copies of Ytrain and of
@@ -901,6 +901,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     double *ddist = (double *)ctx->gemm_out.ptr, *dw = ddist + (size_t)m * k, *dpred = dw + (size_t)m * k;
     int *dind = (int *)(dpred + (size_t)m * le * q);
     hipEvent_t ev1 = jch_ev(ctx), ev2 = nullptr, ev3 = nullptr;   // profiling: (copy) | kNN + weights | local fits
+    bool generic_fits = false;
     {
         knn_args a;
         a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
@@ -914,12 +915,16 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         const bool wide = k <= KNN_CAP - 512 && e_w && atoi(e_w) == 1 && m > 4;
         const int qb = wide ? 8 : KNN_QB, nt = wide ? 512 : 256;
         const size_t lds = (sizeof(double) + sizeof(int)) * qb * KNN_CAP + sizeof(double) * (qb * (size_t)dd + qb) + sizeof(int) * qb + 64;
-        if (lds > 150 * 1024) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: score dimension %lld too large", (long long)dd);
+        // outside the scan's envelope (k beyond the candidate buffers, a search space too wide for its LDS, 2^29 rows): the generic
+        // selection, one workgroup per query (lwplsr_generic.hip); JCH_KNN_GENERIC=1 forces it (tests)
+        const char *e_g = getenv("JCH_KNN_GENERIC");
+        if (k > KNN_CAP - 256 || lds > 150 * 1024 || n >= ((int64_t)1 << 29) || (e_g && atoi(e_g) == 1)) {
+            JCH_TRY(jch_launch_knn_generic(ctx, a));
+        } else {
         // row segments: as many as keep every segment at >= 4 trips and the merged candidate lists inside one sort (nseg * k <= KNN_CAP)
         // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
         // its own compaction sorts)
         // (round 3, with the sort-free compactions: 2 segments 0.60 ms, 3: 0.51, 4: 0.59, 5: 0.57, 6: 0.56, 8: 0.59)
-        if (n >= ((int64_t)1 << 29)) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_predict: 2^29 training rows or more");
         int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_FCAP / k), n / (4 * nt * KNN_RB)));
         if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_FCAP / k));
         a.nseg = nseg;
@@ -934,6 +939,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8) * nseg), dim3(512), lds, ctx->stream, a);
         else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB) * nseg), dim3(256), lds, ctx->stream, a);
         hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
+        }
     }
     ev2 = jch_ev(ctx);
     // neighbours, distances and weights are final here: their copies to the host (3.2 MB at cfg5, into pages of the caller's
@@ -955,6 +961,13 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         { const char *e = getenv("JCH_LOCW_DBG"); g.dbg = e ? atoi(e) : 0; }
         // neighbour-space kernel (lwplsr_kspace.hip: the gathered rows are read ONCE, the fit runs on their Gram matrix held in
         // registers) when the shape fits it; the p-space kernel (one sweep of the slab per LV) otherwise
+        const char *e_lg = getenv("JCH_LOCW_GENERIC");
+        if (!locw_batched_fits(g) || (e_lg && atoi(e_lg) == 1)) {   // outside the batched kernels' envelope: one fit per query (lwplsr_generic.hip)
+            const hipError_t pe = hipMemsetAsync(dpred, 0, sizeof(double) * (size_t)m * le * q, ctx->stream);
+            if (pe != hipSuccess) return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_predict: %s", hipGetErrorString(pe));
+            JCH_TRY(jch_lw_generic_fits(ctx, g, n));
+            generic_fits = true;
+        } else
         if (jch_locw_kspace_supported(g)) JCH_TRY(jch_launch_locw_kspace(ctx, g));
         else
         if (ldr <= 128) JCH_TRY(launch_locw<1>(ctx, g));
@@ -964,7 +977,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         else JCH_TRY(launch_locw<16>(ctx, g));
     }
     JCH_HIP(ctx, hipGetLastError());
-    ev3 = jch_ev(ctx);
+    ev3 = generic_fits ? nullptr : jch_ev(ctx);   // (the per-query fits recycle the event pool: no stage times for that path)
     // (the local fits are in the queue: whatever the host does from here on runs beside them)
     hipStream_t cs = side_copies ? ctx->aux_stream : ctx->stream;
     hipError_t ce = hipSuccess;
@@ -990,12 +1003,11 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
 
 static int32_t lw_check(jch_ctx *ctx, const char *who, int64_t n, int64_t p, int64_t q, int64_t dd, int64_t m, int32_t &k, int32_t nlv_lo, int32_t nlv_hi)
 {
-    if (n < 1 || p < 1 || m < 1 || dd < 1 || k < 1 || nlv_lo < 0 || nlv_hi < nlv_lo) return jch_fail(ctx, JCH_EINVAL, "%s: bad arguments", who);
-    if (q < 1 || q > 16) return jch_fail(ctx, JCH_EINVAL, "%s: the batched local-PLS kernel handles 1 <= q <= 16 (got q=%lld)", who, (long long)q);
-    if (p > JCH_SWEEP_MAXP) return jch_fail(ctx, JCH_EINVAL, "%s: p > %d not supported", who, JCH_SWEEP_MAXP);
+    if (n < 1 || p < 1 || m < 1 || dd < 1 || k < 1 || q < 1 || nlv_lo < 0 || nlv_hi < nlv_lo) return jch_fail(ctx, JCH_EINVAL, "%s: bad arguments", who);
+    if (n >= ((int64_t)1 << 31) - 1 || p > (1 << 20) || m >= ((int64_t)1 << 31) - 1) return jch_fail(ctx, JCH_EINVAL, "%s: n, p or m too large", who);
     if (k > n) k = (int32_t)n;                                    // src/getknn.jl:33
-    if (k > KNN_CAP - 256) return jch_fail(ctx, JCH_EINVAL, "%s: k > %d not supported", who, KNN_CAP - 256);
-    if (nlv_hi > 48) return jch_fail(ctx, JCH_EINVAL, "%s: nlv > 48 not supported", who);
+    // (no envelope limits: shapes outside the batched kernels' — k > 768; local fits with p > 2048, q > 16, nlv > 48 or beyond
+    // their LDS budget — run the generic paths of lwplsr_generic.hip)
     return JCH_OK;
 }
 
@@ -1029,8 +1041,9 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
         JCH_TRY(up(Zq, m, dd, ldzq, dZq, ldzqd)); JCH_TRY(up(Xq, m, p, ldxq, dXq, ldxqd));
     }
     // ---- the model-constant piece, in the ctx workspace (rebuilt on every call: use jch_lwplsr_prepare to keep it)
-    JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
-    double *Xrm = (double *)ctx->xr.ptr;
+    // (a buffer of its own: the per-query fits of the generic path use the fit workspace, ctx->xr included)
+    JCH_TRY(jch_reserve(ctx, ctx->lw_xrm, sizeof(double) * (size_t)n * ldr));
+    double *Xrm = (double *)ctx->lw_xrm.ptr;
     ctx->ev_used = 0;
     ctx->prof = jch_profile{};
     hipEvent_t ev0 = jch_ev(ctx);
@@ -1046,8 +1059,8 @@ extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *X
     if (!ctx) return JCH_EINVAL;
     if (!model_out) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_prepare: model_out is NULL");
     *model_out = nullptr;
-    if (!Xtrain || !Ytrain || !Ztrain || n < 1 || p < 1 || q < 1 || q > 16 || dd < 1 || ldx < n || ldy < n || ldzt < n || p > JCH_SWEEP_MAXP)
-        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_prepare: bad arguments (1 <= q <= 16, p <= %d)", JCH_SWEEP_MAXP);
+    if (!Xtrain || !Ytrain || !Ztrain || n < 1 || p < 1 || q < 1 || dd < 1 || ldx < n || ldy < n || ldzt < n || p > (1 << 20))
+        return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_prepare: bad arguments");
     if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_lwplsr_prepare: bad loc");
     JCH_HIP(ctx, hipSetDevice(ctx->device));
     jch_lwplsr_model *mo = new (std::nothrow) jch_lwplsr_model();
@@ -1177,7 +1190,7 @@ extern "C" int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, 
                                     const double *weights, double *S, double *mu)
 {
     if (!ctx) return JCH_EINVAL;
-    if (!A || !S || n < 1 || d < 1 || d > JCH_MAXQ || lda < n) return jch_fail(ctx, JCH_EINVAL, "jch_weighted_cov: bad arguments (d <= %d)", JCH_MAXQ);
+    if (!A || !S || n < 1 || d < 1 || d > (1 << 15) || lda < n) return jch_fail(ctx, JCH_EINVAL, "jch_weighted_cov: bad arguments");
     if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_weighted_cov: bad loc");
     JCH_HIP(ctx, hipSetDevice(ctx->device));
     const int dd = (int)d, ldr = (dd + 1) & ~1, qpad = ((dd + 15) / 16) * 16;
@@ -1196,6 +1209,30 @@ extern "C" int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, 
     }
     JCH_TRY(jch_reserve(ctx, ctx->dnorm, sizeof(double) * (size_t)n));
     JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
+    if (d > JCH_MAXQ) {
+        // wide A (round 4; the Mahalanobis branch of getknn on raw spectra, nlvdis = 0: src/getknn.jl:37-49, src/lwplsr.jl:21): the
+        // centred row-major copy from K2 (with A's first column standing in for Y), then the tiled MFMA SYRK of kern2.hip on it
+        JCH_TRY(jch_reserve(ctx, ctx->yr, sizeof(double) * (size_t)n * 16));
+        JCH_TRY(jch_reserve(ctx, ctx->small, sizeof(double) * ((size_t)dd * 16 + 4 * (size_t)dd + 64) + 4096));
+        JCH_TRY(jch_reserve(ctx, ctx->gram, sizeof(double) * (size_t)dd * ldr));
+        double *K1 = (double *)ctx->small.ptr, *mom1 = K1 + (size_t)dd * 16, *scl1 = mom1 + dd + 1, *hdr1 = scl1 + dd + 2;
+        double *dn1 = (double *)ctx->dnorm.ptr, *G = (double *)ctx->gram.ptr;
+        JCH_TRY(jch_launch_weights(ctx, dw, n, dn1, hdr1));
+        JCH_TRY(jch_launch_moments(ctx, dA, ldad, dA, ldad, dn1, n, dd, 1, nullptr, mom1));
+        std::vector<double> ones1((size_t)dd + 1, 1.0);
+        JCH_HIP(ctx, hipMemcpyAsync(scl1, ones1.data(), sizeof(double) * ((size_t)dd + 1), hipMemcpyHostToDevice, ctx->stream));
+        JCH_TRY(jch_launch_center_xty(ctx, const_cast<double *>(dA), ldad, const_cast<double *>(dA), ldad, dn1, n, dd, 1, mom1, scl1, false,
+                                      (double *)ctx->xr.ptr, ldr, (double *)ctx->yr.ptr, 16, K1, false));
+        JCH_TRY(jch_launch_syrk(ctx, (const double *)ctx->xr.ptr, n, dd, ldr, dn1, G, ldr));
+        std::vector<double> hG((size_t)dd * ldr), hm1(dd);
+        JCH_HIP(ctx, hipMemcpyAsync(hG.data(), G, sizeof(double) * hG.size(), hipMemcpyDeviceToHost, ctx->stream));
+        JCH_HIP(ctx, hipMemcpyAsync(hm1.data(), mom1, sizeof(double) * dd, hipMemcpyDeviceToHost, ctx->stream));
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < dd; ++i)
+            for (int j = 0; j < dd; ++j) S[i + (size_t)j * dd] = hG[(size_t)i * ldr + j];
+        if (mu) for (int i = 0; i < dd; ++i) mu[i] = hm1[i];
+        return JCH_OK;
+    }
     JCH_TRY(jch_reserve(ctx, ctx->yr, sizeof(double) * (size_t)n * qpad));
     JCH_TRY(jch_reserve(ctx, ctx->small, sizeof(double) * ((size_t)dd * qpad + 4 * (size_t)dd + 64) + 4096));
     double *K = (double *)ctx->small.ptr, *mom = K + (size_t)dd * qpad, *scl = mom + 2 * dd, *hdr = scl + 2 * dd;

@@ -19,3 +19,26 @@ struct locw_args {
 bool jch_locw_kspace_feasible(const locw_args &g);
 bool jch_locw_kspace_supported(const locw_args &g);
 int32_t jch_launch_locw_kspace(jch_ctx *ctx, locw_args &g);
+
+// Arguments of the kNN + weights stage (lwplsr.hip: k_knn_scan / k_knn_finish; lwplsr_generic.hip: k_knn_generic) — src/getknn.jl:29-57,
+// src/wdist.jl:64-75.
+struct knn_args {
+    const double *Zt; int64_t ldzt; int64_t n;   // train scores, column-major n x dd
+    const double *Zq; int64_t ldzq; int m;       // query scores, column-major m x dd
+    int dd, k;
+    double h, cri, tol;
+    int *ind;      // [m][k]
+    double *dist;  // [m][k]
+    double *w;     // [m][k]
+    int nseg;      // the training rows are scanned in nseg segments by different workgroups (block b: segment b % nseg, query group b / nseg)
+    double *ckey;  // [m][nseg][k] squared distances of every segment's k best (ascending; +inf beyond the segment's rows)
+    int *cidx;     // [m][nseg][k]
+    int dbg;       // measurement switch (JCH_KNN_DBG; results then wrong by design): 1 = the bar starts at -inf (no candidate is ever kept: the bare scan)
+};
+
+// lwplsr_generic.hip: the paths WITHOUT shape limits (any k <= n, any p, q, nlv) behind the batched kernels' envelope.
+// kNN + weights of all m queries: exact selection of the k smallest distances per query, (distance, index) order, wdist weights
+int32_t jch_launch_knn_generic(jch_ctx *ctx, const knn_args &a);
+// local fits one query at a time: gather the neighbour rows, jch_plskern_fit on them, jch_predict on the query row (the
+// reference's own schedule, src/locwlv.jl:18-39); dpred [m][le][q] device
+int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n);

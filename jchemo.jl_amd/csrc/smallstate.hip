@@ -12,25 +12,28 @@
 
 #define NT 256
 
-// out[k] (k < ncols) = sum_j A[j*lda + k] * x[j], j < rows.  ncols <= 64.  scratch >= 256 doubles.
+// out[k] (k < ncols) = sum_j A[j*lda + k] * x[j], j < rows; column tiles of 64.  scratch >= 256 doubles.
 __device__ static void block_matTvec(const double *__restrict__ A, int lda, int rows, int ncols,
                                      const double *__restrict__ x, double *out_lds, double *scratch)
 {
-    const int cw = ncols <= 16 ? 16 : (ncols <= 32 ? 32 : 64);
-    const int groups = NT / cw;
-    const int k = threadIdx.x % cw, g = threadIdx.x / cw;
-    double s = 0.0;
-    if (k < ncols)
-        for (int j = g; j < rows; j += groups) s += A[(size_t)j * lda + k] * x[j];
-    __syncthreads();
-    scratch[g * cw + k] = s;
-    __syncthreads();
-    if (threadIdx.x < ncols) {
-        double t = 0.0;
-        for (int gg = 0; gg < groups; ++gg) t += scratch[gg * cw + threadIdx.x];
-        out_lds[threadIdx.x] = t;
+    for (int c0 = 0; c0 < ncols; c0 += 64) {
+        const int nc = min(64, ncols - c0);
+        const int cw = nc <= 16 ? 16 : (nc <= 32 ? 32 : 64);
+        const int groups = NT / cw;
+        const int k = threadIdx.x % cw, g = threadIdx.x / cw;
+        double s = 0.0;
+        if (k < nc)
+            for (int j = g; j < rows; j += groups) s += A[(size_t)j * lda + c0 + k] * x[j];
+        __syncthreads();
+        scratch[g * cw + k] = s;
+        __syncthreads();
+        if (threadIdx.x < nc) {
+            double t = 0.0;
+            for (int gg = 0; gg < groups; ++gg) t += scratch[gg * cw + threadIdx.x];
+            out_lds[c0 + threadIdx.x] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // Parallel cyclic Jacobi on the symmetric q x q matrix in A0 (LDS, ld = lda).  On return the eigenvalues are
@@ -104,6 +107,8 @@ struct lv_args {
     int p, q, qpad, ldr, a, nlv, algo, do_a, do_b;   // algo: 0 plskern, 1 plsnipals, 2 plssimp, 4 plswold (phase B only)
     int maxit;      // plswold
     double tol;
+    double *ws;     // global workspace (round 4: no limit on q or nlv): dots [nlv], then for q > 64 the eigen-solver's matrices
+                    // A0, A1, V0, V1 [4 q (q + 1)], cs [2 (q + 2)], partner / flag (ints), and plswold's four q-vectors
 };
 
 __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
@@ -111,13 +116,18 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int p = g.p, q = g.q, qpad = g.qpad, ldr = g.ldr, a = g.a, tid = threadIdx.x;
     const int lda = q + 1;
+    const int qv = (q + 63) & ~63;
     double *scratch = lds;                 // [256]
-    double *vec = scratch + 256;           // [64]   c / v / dots
-    double *dots = vec + 64;               // [nlv]  (<= 256 reserved)
-    double *A0 = dots + 256, *A1 = A0 + q * lda, *V0 = A1 + q * lda, *V1 = V0 + q * lda;
-    double *cs = V1 + q * lda;             // [2*(q+1)]
-    int *partner = reinterpret_cast<int *>(cs + 2 * (q + 2));  // [q+1]
+    double *vec = scratch + 256;           // [qv]   c / v / dots
+    double *dots = g.ws;                   // [nlv]  global (any nlv)
+    // the eigen-solver's q x q matrices: LDS up to q = 64, the global workspace beyond (same code, generic pointers)
+    const bool eig_lds = q <= JCH_MAXQ;
+    double *A0 = eig_lds ? vec + qv : g.ws + ((g.nlv + 7) & ~7);
+    double *A1 = A0 + q * lda, *V0 = A1 + q * lda, *V1 = V0 + q * lda;
+    double *cs = V1 + q * lda;             // [2*(q+2)]
+    int *partner = reinterpret_cast<int *>(cs + 2 * (q + 2));  // [q+2]
     int *flag = partner + (q + 2);
+    double *wvec = reinterpret_cast<double *>(partner + ((q + 2 + 2 + 1) & ~1));   // plswold: b, a_prev, G b, delta  [4 q]
     double *K = g.s.K;
     const double *zt = g.s.zt;
 
@@ -241,38 +251,42 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
         __syncthreads();
         if (g.algo == 4) {
             // plswold: the inner loop of src/plswold.jl:79-92 as a power iteration on G = K'K (see k_wold_b, siblings.hip);
-            // one wave, lane j < q owns component j (q <= 64)
+            // one wave, lane l owns the components l, l + 64, ... (q <= 64: one each — the arithmetic of the earlier one-per-lane form)
             if (tid < 64) {
                 const int lane = tid;
-                double b = lane == 0 ? 1.0 : 0.0, aprev = 0.0;
+                double *vb = wvec, *va = wvec + q, *vg = va + q, *vd = vg + q;
+                auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+                for (int c = lane; c < q; c += 64) { vb[c] = c == 0 ? 1.0 : 0.0; va[c] = 0.0; }
                 int k = 1;
                 for (;;) {
-                    if (lane < q) vec[lane] = b;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    double gb = 0.0;
-                    if (lane < q)
-                        for (int kk = 0; kk < q; ++kk) gb += A0[lane * lda + kk] * vec[kk];
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    const double n2 = jch_wave_sum(lane < q ? b * gb : 0.0), g2 = jch_wave_sum(lane < q ? gb * gb : 0.0);
-                    const double acur = b / sqrt(n2);
+                    wsync();
+                    double pn2 = 0.0, pg2 = 0.0;
+                    for (int c = lane; c < q; c += 64) {
+                        double gb = 0.0;
+                        for (int kk = 0; kk < q; ++kk) gb += A0[c * lda + kk] * vb[kk];
+                        vg[c] = gb;
+                        pn2 += vb[c] * gb; pg2 += gb * gb;
+                    }
+                    const double n2 = jch_wave_sum(pn2), g2 = jch_wave_sum(pg2);
                     bool stop = k >= g.maxit;
                     if (k >= 2) {
-                        const double dlt = lane < q ? acur - aprev : 0.0;
-                        if (lane < q) vec[lane] = dlt;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                        double gd = 0.0;
-                        if (lane < q)
-                            for (int kk = 0; kk < q; ++kk) gd += A0[lane * lda + kk] * vec[kk];
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-                        const double dif = jch_wave_sum(lane < q ? dlt * gd : 0.0);
+                        for (int c = lane; c < q; c += 64) vd[c] = vb[c] / sqrt(n2) - va[c];
+                        wsync();
+                        double pd = 0.0;
+                        for (int c = lane; c < q; c += 64) {
+                            double gd = 0.0;
+                            for (int kk = 0; kk < q; ++kk) gd += A0[c * lda + kk] * vd[kk];
+                            pd += vd[c] * gd;
+                        }
+                        const double dif = jch_wave_sum(pd);
                         if (dif < g.tol) stop = true;
                     }
                     if (stop) {
-                        if (lane < q) vec[lane] = acur;
+                        for (int c = lane; c < q; c += 64) vec[c] = vb[c] / sqrt(n2);
                         break;
                     }
-                    aprev = acur;
-                    b = gb / sqrt(g2);
+                    wsync();
+                    for (int c = lane; c < q; c += 64) { va[c] = vb[c] / sqrt(n2); vb[c] = vg[c] / sqrt(g2); }
                     ++k;
                 }
                 if (lane == 0 && g.s.niter) g.s.niter[a] = (double)k;
@@ -349,9 +363,16 @@ int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int
     if (fast) return jch_launch_lv_update_fast(ctx, s, p, q, qpad, ldr, g.a, nlv, algo, g.do_a, g.do_b, nslice, ldz, fuse_p2p, bf_src, bf_ld, bf_ldr);
     if (fuse_p2p || bf_src) return jch_fail(ctx, JCH_EINVAL, "internal: the fused inbox all-reduce / bf16 fix-up need the fast small-state kernel");
     if (nslice != 1) return jch_fail(ctx, JCH_EINVAL, "internal: generic small-state kernel needs a single zt slice");
-    if (nlv > 256) return jch_fail(ctx, JCH_EINVAL, "nlv > 256 not supported");
-    const int lda = q + 1;
-    const size_t lds = sizeof(double) * (256 + 64 + 256 + 4 * (size_t)q * lda + 2 * (q + 2)) + sizeof(int) * (q + 2 + 2);
+    const int lda = q + 1, qv = (q + 63) & ~63;
+    const size_t eig = sizeof(double) * (4 * (size_t)q * lda + 2 * (q + 2)) + sizeof(int) * ((q + 2 + 2 + 1) & ~1) + sizeof(double) * 4 * (size_t)q;
+    const size_t lds = sizeof(double) * (256 + qv) + (q <= JCH_MAXQ ? eig : 0);
+    JCH_TRY(jch_reserve(ctx, ctx->lvws, sizeof(double) * ((size_t)((nlv + 7) & ~7)) + eig + 256));
+    g.ws = (double *)ctx->lvws.ptr;
+    static jch_per_device_once attr_once;
+    if (!attr_once.done(ctx->device)) {
+        JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_update, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_once.mark(ctx->device);
+    }
     hipLaunchKernelGGL(k_lv_update, dim3(1), dim3(NT), lds, ctx->stream, g);
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;

@@ -517,6 +517,21 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
             g.s.w[j] = wn;
             g.s.r[j] = rn;
             if (g.s.rs) g.s.rs[j] = j < p ? rn / g.s.scl[j] : 0.0;
+            if (g.s.kr && !g.do_a) rl[j] = rn;          // (split path, first call: rl is free — nothing was staged into it)
+        }
+    }
+    if (g.s.kr && !g.do_a) {   // split small-state path (smallstate_split.hip): K' r, the numerators of LV 0's c
+        __syncthreads();
+        {
+            const int k = tid & 15, gr = tid >> 4;
+            scratch[gr * 16 + k] = k < QP ? kcol_dot(Kl, ldk, k, rl, gr, FT / 16, p) : 0.0;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            double t = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < FT / 16; ++gg) t += scratch[gg * 16 + tid];
+            g.s.kr[tid] = tid < q ? t : 0.0;
         }
     }
     JCH_STAMP(15);

@@ -1,0 +1,413 @@
+// K3/K5 split path (round 4) — the per-LV small-state step of the plskern-shaped loop (src/plskern.jl:150-174) as TWO kernels:
+//
+//   k_lv_spread  (one 256-thread block per 16 rows of the p x q kernel matrix K, i.e. per 16 columns of X; 32 blocks at p = 500)
+//       everything of the step that is parallel over p and needs no more than a block-local sum:
+//         zp    = sum of the sweep's per-block partial rows        (the former k_reduce_part, now for 16 columns per block)
+//         c     = K' r / tt                 (K' r was formed when r was: `kr`, 16 doubles — the only division by tt is here)
+//         K    <- K - zp c'                 (16 x 16 entries per block, one per thread)
+//         P_a   = zp / tt,  W_a = w,  R_a = r                     (src/plskern.jl:168-174)
+//       and the PARTIALS of the three quantities the second kernel needs summed over p:
+//         s_i   = P_i . zp  (i < a)        -> Z_i <- Z_i - s_i c'   (Z = P'K, the state of the r-recursion, smallstate_fast.hip)
+//         Z_a   = zp' K_new / tt
+//         G     = K_new' K_new             (16 x 16 Gram matrix: the input of the dominant-direction step, :150-155)
+//   k_lv_solve   (ONE 512-thread block) sums the 32 partial Gram matrices / Z rows, finds the dominant eigenvector v of G on
+//       wave 0 (lv_device.h) WHILE the other seven waves stage K_new into LDS, then w = K v / |K v|, r = (K v - R (Z v)) / |K v|
+//       (:156-161) and the next LV's `kr` = K' r.
+//
+// Why: the single-workgroup kernel (smallstate_fast.hip) pulled K (64 KB), the 8 slice sums (32 KB) and the finished P and R
+// rows (200 KB at LV 24) through ONE CU's load path before any arithmetic — 11.9 k of its 38.6 k cycles — and ran the K update,
+// the P.zp dots and the Gram build on one CU.  Here that half runs on 32 CUs and the single-workgroup kernel starts at "sum the
+// partial Gram matrices"; K_new and the R rows arrive during the eigenvector window, off the critical path.  Same arithmetic as
+// the one-kernel path except for the ORDER of the sums over p (block partials): results agree to rounding, not to the bit; the
+// replicated state stays bit-identical across ranks (every rank runs the same kernels on the same all-reduced input).
+#include <stdlib.h>
+
+#include "jch_internal.h"
+#include "lv_device.h"
+
+#define SP_NT 256
+#define SP_GP 272          // doubles per block in gpart before the s_i: 256 Gram entries + 16 of zp' K_new
+
+struct lvs_args {
+    jch_small s;
+    int p, q, ldr, a, nlv;
+    const double *part;    // [nb][ldpart] partial rows of the sweep output: zp_raw at [0, ldr), tt at [itt], st at [ist]
+    int nb, ldpart, itt, ist;   // ist < 0: no st
+    int mode;              // 0: centred copy (zp = zp_raw); 1: f64 raw mode (zp = zp_raw - mshift st, / scl with scaling);
+                           // 2: bf16 storage mode (zp = (zp_raw - mom st) / scl)
+    int nblk, gld;         // blocks of k_lv_spread, doubles per block in s.gpart
+    p2p_dev px;            // P2P instantiation: the inbox transport (p2p.hip), one exchange per block
+};
+
+#define JCH_SSTAMP(k) do { if (g.s.dbg && tid == 0) g.s.dbg[512 + 16 * (g.a + 1) + (k)] = (double)__builtin_readcyclecounter(); } while (0)
+
+// P2P: the cross-GPU all-reduce of the sweep output happens HERE, block by block: every block pushes its 16 column sums + [tt, st]
+// into its own 24-double piece of slot [parity][rank] of every rank's inbox, publishes / waits on its OWN flags and adds the ranks'
+// pieces in rank order (the same bits on every rank) — the exchange of smallstate_fast.hip's fused kernel, 32 blocks wide.
+template <bool P2P>
+__global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
+{
+    __shared__ double sc[16][18];
+    __shared__ double tot[18];
+    __shared__ double zpl[16], cl[16];
+    __shared__ double Knl[16][17];
+    const int tid = threadIdx.x, col = tid & 15, gr = tid >> 4;
+    const int p = g.p, a = g.a, j0 = blockIdx.x * 16;
+    if (g.s.dbg && tid == 0 && blockIdx.x == 0) g.s.dbg[512 + 16 * (a + 1) + 5] = (double)__builtin_readcyclecounter();
+    // ---- every load this block needs is issued here (one trip to L2)
+    const int jrow = min(j0 + gr, p - 1);
+    const double kold = g.s.K[(size_t)jrow * 16 + col];
+    const int jc = j0 + col, jcc = min(jc, p - 1);
+    double krv = 0.0, wv = 0.0, rv = 0.0, msh = 0.0, scl = 1.0;
+    if (tid < 16) {
+        krv = g.s.kr[tid];
+        wv = g.s.w[jcc]; rv = g.s.r[jcc];
+        if (g.mode == 1) { msh = g.s.mshift[jcc]; if (g.s.rs) scl = g.s.scl[jcc]; }
+        else if (g.mode == 2) { msh = g.s.mom[jcc]; scl = g.s.scl[jcc]; }
+    }
+    double pre[16];     // P_i[j0 .. j0 + 15] of the finished LV i = tid - 16 (threads 16 .. 16 + a)
+    const int ipre = tid - 16;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) pre[jj] = (ipre >= 0 && ipre < a) ? g.s.P[(size_t)ipre * p + min(j0 + jj, p - 1)] : 0.0;
+    // sums of the partial rows: thread (gr, col) adds rows gr, gr + 16, ... of column j0 + col; fixed order
+    const int cidx = min(jc, g.ldr - 1);
+    double acc = 0.0, acc2 = 0.0;
+    const int xidx = col == 0 ? g.itt : (g.ist >= 0 ? g.ist : g.itt);
+    for (int b0 = gr; b0 < g.nb; b0 += 16 * 8) {
+        double v[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t row = (size_t)min(b0 + 16 * u, g.nb - 1) * g.ldpart;
+            v[u] = g.part[row + cidx];
+            x[u] = col < 2 ? g.part[row + xidx] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool live = b0 + 16 * u < g.nb;
+            acc += live ? v[u] : 0.0;
+            acc2 += live ? x[u] : 0.0;
+        }
+    }
+    sc[gr][col] = acc;
+    if (col < 2) sc[gr][16 + col] = acc2;
+    __syncthreads();
+    if (tid < 18) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sc[k][tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+    if constexpr (P2P) {
+        __shared__ int bail;
+        const int par = (int)(g.px.epoch & 1ull), blk = blockIdx.x;
+        char *mine = g.px.peer[g.px.rank];
+        if (tid == 0) bail = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+        __syncthreads();
+        if (bail) return;
+        const long long ts0 = blk == 0 ? p2p_stat_begin(g.px, tid) : 0;
+        if (tid < 18) {
+            const double v = tot[tid];
+            for (int r = 0; r < g.px.nranks; ++r) p2p_slot(g.px.peer[r], par, g.px.rank, g.px.nranks, g.px.cap)[blk * 24 + tid] = v;
+        }
+        __threadfence_system();
+        __syncthreads();
+        p2p_publish_and_wait_block(g.px, tid, blk);
+        __syncthreads();
+        if (tid == 0) bail = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+        __syncthreads();
+        if (bail) return;
+        if (tid < 18) {
+            double s = 0.0;
+            for (int r = 0; r < g.px.nranks; ++r) s += p2p_load_slot(p2p_slot(mine, par, r, g.px.nranks, g.px.cap) + blk * 24 + tid);
+            tot[tid] = s;
+        }
+        if (blk == 0) p2p_stat_end(g.px, tid, ts0);
+        __syncthreads();
+    }
+    if (g.s.dbg && tid == 0 && blockIdx.x == 0) g.s.dbg[512 + 16 * (a + 1) + 6] = (double)__builtin_readcyclecounter();
+    const double tt = tot[16], st = g.ist >= 0 ? tot[17] : 0.0;
+    if (tid < 16) {
+        double zp = tot[tid];
+        if (g.mode == 1) zp = g.s.rs ? (zp - msh * st) / scl : zp - msh * st;
+        else if (g.mode == 2) zp = (zp - msh * st) / scl;
+        if (jc >= p) zp = 0.0;
+        zpl[tid] = zp;
+        const double c = tid < g.q ? krv / tt : 0.0;
+        cl[tid] = c;
+        if (jc < p) {
+            g.s.P[(size_t)a * p + jc] = zp / tt;
+            g.s.W[(size_t)a * p + jc] = wv;
+            g.s.R[(size_t)a * p + jc] = rv;
+        }
+        if (blockIdx.x == 0) {
+            if (tid < g.q) g.s.C[(size_t)a * g.q + tid] = c;
+            if (tid == 0) g.s.TT[a] = tt;
+        }
+    }
+    __syncthreads();
+    {   // K <- K - zp c' : row j0 + gr, column col (pad columns stay exactly zero: c is zero there)
+        const bool live = j0 + gr < p;
+        const double kn = kold - zpl[gr] * cl[col];
+        if (live) g.s.K[(size_t)(j0 + gr) * 16 + col] = kn;
+        Knl[gr][col] = live ? kn : 0.0;
+    }
+    __syncthreads();
+    double *gp = g.s.gpart + (size_t)blockIdx.x * g.gld;
+    {   // partial Gram matrix of this block's 16 rows of K_new
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 16; jj += 2) {
+            s0 += Knl[jj][gr] * Knl[jj][col];
+            s1 += Knl[jj + 1][gr] * Knl[jj + 1][col];
+        }
+        gp[gr * 16 + col] = s0 + s1;
+    }
+    if (tid < 16) {   // partial of zp' K_new
+        double s = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) s += zpl[jj] * Knl[jj][tid];
+        gp[256 + tid] = s;
+    } else if (ipre < a) {   // partial of P_i . zp
+        double s = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) s += pre[jj] * zpl[jj];       // (zpl is zero beyond p)
+        gp[SP_GP + ipre] = s;
+    }
+    for (int i = ipre + (SP_NT - 16); ipre >= 0 && i < a; i += SP_NT - 16) {   // (more than 240 finished LVs)
+        double s = 0.0;
+        for (int jj = 0; jj < 16; ++jj) s += g.s.P[(size_t)i * p + min(j0 + jj, p - 1)] * zpl[jj];
+        gp[SP_GP + i] = s;
+    }
+    if (g.s.dbg && tid == 0 && blockIdx.x == 0) g.s.dbg[512 + 16 * (a + 1) + 7] = (double)__builtin_readcyclecounter();
+}
+
+template <int QP>
+__global__ __launch_bounds__(FT) void k_lv_solve(lvs_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int p = g.p, q = g.q, ldr = g.ldr, a = g.a, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int an = a + 1;                          // finished LVs (rows of P / R / Z valid in global memory, row a from k_lv_spread)
+    constexpr int ldk = QP | 1, lda = QP + 2;
+    double *Kl = lds;                              // [p][ldk]
+    double *rnl = Kl + (size_t)p * ldk;            // [ldr]  the new r (for K' r)
+    double *scratch = rnl + ldr;                   // [2 FT]
+    double *cl = scratch + 2 * FT;                 // [16]
+    double *vl = cl + 16;                          // [16]
+    double *zal = vl + 16;                         // [16]   zp' K_new
+    double *sl = zal + 16;                         // [nlv]  s_i = P_i . zp
+    double *ul = sl + ((g.nlv + 1) & ~1);          // [nlv]  u = Z v
+    double *Zl = ul + ((g.nlv + 1) & ~1);          // [nlv][QP]
+    double *G0 = Zl + (size_t)g.nlv * QP, *A0 = G0 + QP * lda, *A1 = A0 + QP * lda, *V0 = A1 + QP * lda, *V1 = V0 + QP * lda;
+    double *csl = V1 + QP * lda;                   // [2 (QP + 2)]
+    JCH_SSTAMP(0);
+    // ---- loads: first what the eigenvector needs (partial Gram matrices), then what can arrive while it is being computed
+    const int nent = SP_GP + a;
+    double gacc = 0.0;
+    {
+        const int e = min(tid, nent - 1);
+        {   // the first 32 blocks' partials in ONE batch of loads (p <= 512: all of them)
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = g.s.gpart[(size_t)min(u, g.nblk - 1) * g.gld + e];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) gacc += u < g.nblk ? v[u] : 0.0;
+        }
+        for (int b0 = 32; b0 < g.nblk; b0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = g.s.gpart[(size_t)min(b0 + u, g.nblk - 1) * g.gld + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gacc += b0 + u < g.nblk ? v[u] : 0.0;
+        }
+    }
+    if (g.s.dbg && tid == 0) { g.s.dbg[512 + 16 * (g.a + 1) + 12] = (double)__builtin_readcyclecounter() + (gacc == 1.234e300 ? 1.0 : 0.0); }
+    const double cpre = tid < q ? g.s.C[(size_t)a * q + tid] : 0.0;
+    const double tt = g.s.TT[a];
+    const double zpre = tid < a * QP ? g.s.Z[tid] : 0.0;
+    // (every LDS word is written by exactly ONE thread before the barrier below — no zero-fill pass of its own, one barrier)
+    for (int e = tid; e < 4 * QP * lda; e += FT) A0[e] = 0.0;   // A0, A1, V0, V1: zero padding
+    if (tid < 16) { cl[tid] = cpre; vl[tid] = 0.0; }
+    for (int e = tid; e < g.nlv; e += FT) ul[e] = 0.0;
+    if (tid < 256) {
+        if ((tid >> 4) < QP && (tid & 15) < QP) G0[(tid >> 4) * lda + (tid & 15)] = gacc;
+        if ((tid & 15) == 0 && (tid >> 4) < QP) { G0[(tid >> 4) * lda + QP] = 0.0; G0[(tid >> 4) * lda + QP + 1] = 0.0; }
+    } else if (tid < SP_GP) zal[tid - 256] = gacc;
+    else if (tid < nent) sl[tid - SP_GP] = gacc;
+    for (int e = tid + FT; e < nent; e += FT) {   // (more than 240 finished LVs)
+        double s = 0.0;
+        for (int b = 0; b < g.nblk; ++b) s += g.s.gpart[(size_t)b * g.gld + e];
+        sl[e - SP_GP] = s;
+    }
+    if (tid < a * QP) Zl[tid] = zpre;
+    for (int e = tid + FT; e < a * QP; e += FT) Zl[e] = g.s.Z[e];
+    JCH_SSTAMP(13);
+    __syncthreads();
+    // the loads the tail needs go out only NOW: a barrier waits for every outstanding load of the wave, and the 128 KB of R rows
+    // in front of the barrier above kept the eigenvector waiting for them (they arrive during the eigenvector window instead)
+    double rreg[32];   // R[i][tid], i < min(an, 32)   (tail)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) rreg[i] = (i < an && tid < p) ? g.s.R[(size_t)i * p + tid] : 0.0;
+    JCH_SSTAMP(1);
+    if (wv == 0) {
+        if (q > 1) {
+            bool solved;
+            if constexpr (QP == 16) solved = dominant_by_squaring_mfma16(q, lda, G0, vl, g.s.dbg ? g.s.dbg + an : nullptr,
+                                                                      g.s.dbg ? g.s.dbg + 512 + 16 * (a + 1) + 9 : nullptr);
+            else solved = dominant_by_squaring<QP>(q, lda, G0, A0, A1, vl, g.s.dbg ? g.s.dbg + an : nullptr);
+            if (!solved) {
+                for (int e = lane; e < QP * lda; e += 64) A0[e] = G0[e];
+                wavesync();
+                jacobi_wave(q, lda, A0, A1, V0, V1, csl, vl, g.s.dbg ? g.s.dbg + an : nullptr);
+            }
+        } else if (lane == 0) vl[0] = 1.0;
+    } else {
+        // ---- the other seven waves meanwhile: K_new into LDS (flat, coalesced), the Z rows brought up to date
+        const int wt = tid - 64, WT = FT - 64, tot = p * 16;
+        for (int base = 0; base < tot; base += WT * 8) {
+            double kr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kr[i] = g.s.K[min(base + wt + WT * i, tot - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = base + wt + WT * i;
+                if (e < tot && (e & 15) < QP) Kl[(e >> 4) * ldk + (e & 15)] = kr[i];
+            }
+        }
+        for (int e = wt; e < a * QP; e += WT) {   // Z_i <- Z_i - s_i c'  (i < a)
+            const double z = Zl[e] - sl[e / QP] * cl[e & (QP - 1)];
+            Zl[e] = z;
+            g.s.Z[e] = z;
+        }
+        if (wt < QP) {                            // new row Z_a = zp' K_new / tt
+            const double z = zal[wt] / tt;
+            Zl[a * QP + wt] = z;
+            g.s.Z[a * QP + wt] = z;
+        }
+    }
+    __syncthreads();
+    JCH_SSTAMP(2);
+    if (tid < an) {   // u = Z v
+        double u = 0.0;
+#pragma unroll
+        for (int k = 0; k < QP; ++k) u += Zl[tid * QP + k] * vl[k];
+        ul[tid] = u;
+    }
+    for (int i = tid + FT; i < an; i += FT) {
+        double u = 0.0;
+        for (int k = 0; k < QP; ++k) u += Zl[i * QP + k] * vl[k];
+        ul[i] = u;
+    }
+    // w_raw = K v ; ||w_raw||
+    double wr[JCH_SWEEP_MAXP / FT];
+    double ssq = 0.0;
+#pragma unroll
+    for (int it = 0; it < JCH_SWEEP_MAXP / FT; ++it) {
+        wr[it] = 0.0;
+        if (it * FT >= p) continue;
+        const int j = min(tid + it * FT, p - 1);
+        double wv_ = 0.0;
+#pragma unroll
+        for (int k = 0; k < QP; ++k) wv_ += Kl[j * ldk + k] * vl[k];
+        if (tid + it * FT >= p) wv_ = 0.0;
+        wr[it] = wv_;
+        ssq += wv_ * wv_;
+    }
+    const double inv = 1.0 / sqrt(jch_block_sum<FT>(ssq, scratch));   // (its barriers also publish ul)
+    JCH_SSTAMP(3);
+    // w = w_raw / ||.|| ;  r = (w_raw - R (Z v)) / ||.||   ==  w - sum_i (w . P_i) R_i   (src/plskern.jl:156-161)
+#pragma unroll
+    for (int it = 0; it < JCH_SWEEP_MAXP / FT; ++it) {
+        const int j = tid + it * FT;
+        if (j < ldr) {
+            double wn = 0.0, rn = 0.0;
+            if (j < p) {
+                wn = wr[it] * inv;
+                rn = wr[it];
+                double r0 = 0.0, r1 = 0.0;
+                int i0 = 0;
+                if (it == 0) {
+#pragma unroll
+                    for (int i = 0; i < 32; i += 2) {
+                        r0 += rreg[i] * ul[min(i, g.nlv - 1)];          // rreg is 0 beyond an
+                        r1 += rreg[i + 1] * ul[min(i + 1, g.nlv - 1)];
+                    }
+                    i0 = an < 32 ? an : 32;
+                }
+                for (int i = i0; i < an; ++i) r0 += g.s.R[(size_t)i * p + j] * ul[i];
+                rn -= r0 + r1;
+                rn *= inv;
+            }
+            g.s.w[j] = wn;
+            g.s.r[j] = rn;
+            if (g.s.rs) g.s.rs[j] = j < p ? rn / g.s.scl[j] : 0.0;
+            rnl[j] = rn;
+        }
+    }
+    __syncthreads();
+    {   // kr = K' r : the numerators of the next LV's c (same partial order as the one-kernel path's c = K' r / tt)
+        const int k = tid & 15, gg = tid >> 4;
+        scratch[gg * 16 + k] = k < QP ? kcol_dot(Kl, ldk, k, rnl, gg, FT / 16, p) : 0.0;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < FT / 16; ++gg) t += scratch[gg * 16 + tid];
+        g.s.kr[tid] = tid < q ? t : 0.0;
+    }
+    JCH_SSTAMP(4);
+}
+
+static int qp_of(int q) { return q <= 1 ? 1 : (q <= 2 ? 2 : (q <= 4 ? 4 : (q <= 8 ? 8 : 16))); }
+
+int jch_lv_split_blocks(int p) { return (p + 15) / 16; }
+int jch_lv_split_gld(int nlv) { return (SP_GP + nlv + 7) & ~7; }
+
+size_t jch_lv_solve_lds_bytes(int p, int q, int ldr, int nlv)
+{
+    const int QP = qp_of(q), ldk = QP | 1, lda = QP + 2;
+    return sizeof(double) * ((size_t)p * ldk + ldr + 2 * FT + 48 + 2 * (size_t)((nlv + 1) & ~1) + (size_t)nlv * QP + 5 * (size_t)QP * lda + 2 * (QP + 2) + 8);
+}
+
+// LV a: the sweep's partial rows (or the all-reduced slices) -> K_new, P_a / W_a / R_a / C_a / TT_a, then (unless it was the last
+// LV) the next w, r and kr.
+bool jch_lv_split_p2p_ok(const jch_ctx *ctx, int p)
+{
+    return jch_lv_split_blocks(p) <= P2P_MAXBLK && (size_t)jch_lv_split_blocks(p) * 24 <= ctx->p2p.cap;
+}
+
+int32_t jch_launch_lv_split(jch_ctx *ctx, const jch_small &s, int p, int q, int ldr, int a, int nlv, const double *part, int nb,
+                            int ldpart, int itt, int ist, int mode, bool solve, bool fuse_p2p)
+{
+    if (!s.kr || !s.gpart || !part || nb < 1) return jch_fail(ctx, JCH_EINVAL, "internal: split small-state path without its buffers");
+    lvs_args g;
+    g.s = s; g.p = p; g.q = q; g.ldr = ldr; g.a = a; g.nlv = nlv; g.part = part; g.nb = nb; g.ldpart = ldpart; g.itt = itt; g.ist = ist;
+    g.mode = mode; g.nblk = jch_lv_split_blocks(p); g.gld = jch_lv_split_gld(nlv);
+    g.px = p2p_dev{};
+    if (fuse_p2p) {
+        if (!jch_lv_split_p2p_ok(ctx, p)) return jch_fail(ctx, JCH_EINVAL, "internal: per-block inbox exchange outside its envelope");
+        jch_p2p_next(ctx, &g.px);
+        hipLaunchKernelGGL(k_lv_spread<true>, dim3(g.nblk), dim3(SP_NT), 0, ctx->stream, g);
+    } else hipLaunchKernelGGL(k_lv_spread<false>, dim3(g.nblk), dim3(SP_NT), 0, ctx->stream, g);
+    if (solve) {
+        const size_t lds = jch_lv_solve_lds_bytes(p, q, ldr, nlv);
+        static jch_per_device_once attr_once;
+        if (!attr_once.done(ctx->device)) {
+#define JCH_ATTR(QP) JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_solve<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+            JCH_ATTR(1); JCH_ATTR(2); JCH_ATTR(4); JCH_ATTR(8); JCH_ATTR(16);
+#undef JCH_ATTR
+            attr_once.mark(ctx->device);
+        }
+        switch (qp_of(q)) {
+        case 1: hipLaunchKernelGGL((k_lv_solve<1>), dim3(1), dim3(FT), lds, ctx->stream, g); break;
+        case 2: hipLaunchKernelGGL((k_lv_solve<2>), dim3(1), dim3(FT), lds, ctx->stream, g); break;
+        case 4: hipLaunchKernelGGL((k_lv_solve<4>), dim3(1), dim3(FT), lds, ctx->stream, g); break;
+        case 8: hipLaunchKernelGGL((k_lv_solve<8>), dim3(1), dim3(FT), lds, ctx->stream, g); break;
+        default: hipLaunchKernelGGL((k_lv_solve<16>), dim3(1), dim3(FT), lds, ctx->stream, g); break;
+        }
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}

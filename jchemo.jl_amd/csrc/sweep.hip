@@ -548,7 +548,8 @@ int32_t jch_sweep_tickets(jch_ctx *ctx, int **out)
 
 template <int KC, int R, int NBUF>
 static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int ldr, const double *d, const double *rvec,
-                                 double *tcol, double *zt, int ldz, int max_slices, int *nslice_out, int m, const double *mu)
+                                 double *tcol, double *zt, int ldz, int max_slices, int *nslice_out, int m, const double *mu,
+                                 jch_part_view *pv)
 {
     const int64_t ngroups = (n + R - 1) / R;
     const size_t lds = sizeof(double) * (4 * KC * 128 + 16);
@@ -580,6 +581,12 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
                        tickets, zt, ldz, fused ? nslice : 0);
     (void)jch_ev(ctx);  // (end)
+    if (pv && !fused) {   // split small-state path: k_lv_spread sums the block partials itself (no k_reduce_part launch)
+        pv->part = part; pv->nb = nb; pv->ldpart = ldpart;
+        *nslice_out = 1;
+        JCH_HIP(ctx, hipGetLastError());
+        return JCH_OK;
+    }
     if (!fused)
         hipLaunchKernelGGL(k_reduce_part, dim3((m + 63) / 64, JCH_ZT_SLICES), dim3(1024), 0, ctx->stream, part, nb, ldpart, m, nslice, zt, ldz);
     if (nslice > 1) nslice = JCH_ZT_SLICES;
@@ -788,10 +795,11 @@ int32_t jch_launch_sweep_lazy(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
 
 int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *rvec,
                          const double *Yr, int qpad, int q_extra, double *tcol, double *zt, int ldz, int max_slices,
-                         int *nslice_out, const double *mu)
+                         int *nslice_out, const double *mu, jch_part_view *pv)
 {
     (void)p;
     const bool nip = q_extra > 0;
+    if (pv) *pv = jch_part_view{};
     if (mu && (nip || ldr > JCH_SWEEP_MAXP)) return jch_fail(ctx, JCH_EINVAL, "internal: raw-mode sweep is for plskern-shaped fits with p <= %d", JCH_SWEEP_MAXP);
     const int m = ldr + 1 + (nip ? qpad : (mu ? 1 : 0));
     // Default: software-prefetched kernels with 8 rows x 4 KB (32 KB) per wave in flight ahead of the 32 KB being reduced
@@ -807,7 +815,7 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
         const char *e2 = getenv("JCH_SWEEP_V2"), *eb = getenv("JCH_SWEEP_NBUF");
         const int v2 = e2 ? atoi(e2) : 1, nbuf = eb ? atoi(eb) : 2;
         if (v2 && !nip && ldr >= 2) {
-#define JCH_SWEEP_V2_CASE(KC, R, NB) return launch_sweep_v2_t<KC, R, NB>(ctx, Xr, n, ldr, d, rvec, tcol, zt, ldz, max_slices, nslice_out, m, mu)
+#define JCH_SWEEP_V2_CASE(KC, R, NB) return launch_sweep_v2_t<KC, R, NB>(ctx, Xr, n, ldr, d, rvec, tcol, zt, ldz, max_slices, nslice_out, m, mu, pv)
             if (ldr <= 128) JCH_SWEEP_V2_CASE(1, 8, 2);
             if (ldr <= 256) JCH_SWEEP_V2_CASE(2, 8, 2);
             if (ldr <= 512) {

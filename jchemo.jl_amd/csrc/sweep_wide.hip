@@ -117,3 +117,22 @@ int32_t jch_launch_sweep_wide(jch_ctx *ctx, const double *Xr, int64_t n, int ldr
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
 }
+
+// c_raw = Y'Dt for a response block wider than the NIPALS sweep's one-lane-per-response layout (qpad > 64; round 4): the column
+// accumulation of k_colacc on the row-major Yr [n][qpad], panels of 2048 columns.  out [qpad].
+int32_t jch_launch_ytdt(jch_ctx *ctx, const double *Yr, int64_t n, int qpad, const double *d, const double *tcol, double *out)
+{
+    const int nb2 = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)ctx->cus * 2));
+    const int ldp2 = 2048;
+    JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb2 * ldp2));
+    double *part = (double *)ctx->part.ptr;
+    static jch_per_device_once attr;
+    if (!attr.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_colacc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.mark(ctx->device); }
+    for (int c0 = 0; c0 < qpad; c0 += 2048) {
+        const int width = std::min(2048, qpad - c0);
+        hipLaunchKernelGGL(k_colacc, dim3(nb2), dim3(256), sizeof(double) * 4 * 2048, ctx->stream, Yr, n, qpad, c0, width, d, tcol, part, ldp2);
+        hipLaunchKernelGGL(k_reduce_cols, dim3((width + 63) / 64), dim3(1024), 0, ctx->stream, part, nb2, ldp2, width, out + c0);
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}

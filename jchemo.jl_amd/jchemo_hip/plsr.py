@@ -485,8 +485,6 @@ def vip(fm: Plsr, Y=None, *, nlv: Optional[int] = None, ctx: Optional[Context] =
     else:
         A_ = np.asfortranarray(np.hstack([np.asarray(Y, dtype=np.float64), T]))   # layout only
         w = np.ascontiguousarray(fm.weights)
-    if q + k > 64:
-        raise NotImplementedError("vip(object, Y): q + nlv > 64 is not supported")
     ctx = ctx or default_context((T.device.index or 0) if dev else 0)
     S = np.empty((q + k, q + k), order="F")
     aa, lda = _addr_ld(A_)
@@ -575,8 +573,6 @@ def _knn_train_space(obj: Lwplsr, ctx):
         stages.append((_model_vec(obj.fm.xmeans), _model_vec(obj.fm.xscales), np.asfortranarray(obj.fm.R[:, :_nlv_arg(obj.fm, None)], dtype=np.float64)))
     if obj.metric == "mahal":
         d = Zt.shape[1]
-        if d > 64:
-            raise NotImplementedError("Mahalanobis neighbours in more than 64 dimensions are not supported (use nlvdis > 0)")
         S = _cov_uncorrected(Zt, ctx)
         if d == 1:
             Uinv = np.array([[1.0 / np.sqrt(S[0, 0])]])
@@ -684,8 +680,11 @@ def _merge_lwplsr_parts(parts) -> "LwplsrPred":
 
 
 def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, rank: Optional[int] = None,
-                   world: Optional[int] = None, gather=None) -> LwplsrPred:
+                   world: Optional[int] = None, gather=None, lists: bool = True) -> LwplsrPred:
     """`predict(object::Lwplsr, X; nlv)` — src/lwplsr.jl:134-166.
+
+    `lists = False` (not in the reference, whose result always carries them): predictions only — the neighbour lists, distances
+    and weights (3.2 MB at cfg5) stay on the device and `listnn / listd / listw` come back as None.
 
     Multi-GPU ("replicas", one process per GPU holding the whole training set): pass this process' `rank` and the
     `world` size; the call predicts the slice `query_shard(m, rank, world)` on its GPU and returns the FULL result on
@@ -698,7 +697,7 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, r
         lo, hi = query_shard(X.shape[0], int(rank), int(world))
         part = None
         if hi > lo:
-            part = lwplsr_predict(obj, X[lo:hi], nlv=nlv, ctx=ctx)
+            part = lwplsr_predict(obj, X[lo:hi], nlv=nlv, ctx=ctx)   # (replica split: always with the lists, the merge expects them)
             if _is_torch(part.pred) or (isinstance(part.pred, list) and part.pred and _is_torch(part.pred[0])):  # pragma: no cover
                 part = LwplsrPred([t.cpu().numpy() for t in part.pred] if isinstance(part.pred, list) else part.pred.cpu().numpy(),
                                   part.listnn, part.listd, part.listw)
@@ -731,12 +730,16 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, r
     hi = min(hi, p)                                            # src/locwlv.jl:14
     le = hi - lo + 1
     k = min(obj.k, n)
-    batched = q <= 16                                          # the batched kernel's envelope (include/jchemo_hip.h)
-    # model-constant device data (row-major Xtrain, Ytrain, whitened training scores): prepared once per object
-    # (q > 16: the kernel is still used — on the first y column — for neighbours + weights)
-    st = _lwplsr_prepared(obj, ctx, dev, q if batched else 1)
-    pred = np.empty((m, le, q if batched else 1))
-    ind = np.empty((m, k), dtype=np.int32); dist = np.empty((m, k)); w = np.empty((m, k))
+    # model-constant device data (row-major Xtrain, Ytrain, whitened training scores): prepared once per object.  No shape limits:
+    # outside the batched kernels' envelope (k > 768; local fits with p > 2048, q > 16, nlv > 48) the library runs its generic
+    # paths — an exact selection per query, then one jch_plskern_fit + jch_predict per query, the reference's own schedule
+    # (src/locwlv.jl:18-39; csrc/lwplsr_generic.hip)
+    st = _lwplsr_prepared(obj, ctx, dev, q)
+    pred = np.empty((m, le, q))
+    if lists:
+        ind = np.empty((m, k), dtype=np.int32); dist = np.empty((m, k)); w = np.empty((m, k))
+    else:
+        ind = dist = w = None
     if st["device_map"]:
         qa, ldq = None, 0                                          # the handle maps the queries itself
     else:
@@ -746,30 +749,10 @@ def lwplsr_predict(obj: Lwplsr, X, *, nlv=None, ctx: Optional[Context] = None, r
     if dev:
         torch.cuda.current_stream(X.device).synchronize()
     ctx.check(_lib.load().jch_lwplsr_predict_prepared(ctx._h, st["handle"], _lib.LOC_DEVICE if dev else _lib.LOC_HOST, qa, ldq, xqa, m, ldxq, k,
-                                                      float(obj.h), float(obj.tol), int(obj.scal), lo, hi, pred.ctypes.data, ind.ctypes.data,
-                                                      dist.ctypes.data, w.ctypes.data))
+                                                      float(obj.h), float(obj.tol), int(obj.scal), lo, hi, pred.ctypes.data, _np(ind),
+                                                      _np(dist), _np(w)))
     if getattr(obj, "verbose", False):                            # src/locwlv.jl:19,40 (`print(i, " ")` per query, then a newline)
         print("".join(f"{i} " for i in range(1, m + 1)))
-    if not batched:
-        # one weighted plskern + predict per query through the same device library (unbatched; src/locwlv.jl:18-39)
-        rng = list(range(lo, hi + 1))
-        out = np.empty((m, q, le))
-        for i in range(m):
-            s_ = ind[i].astype(np.int64)
-            if dev:
-                si = torch.as_tensor(s_, device=X.device)
-                Xl = colmajor_empty(k, p, X.device); Xl.copy_(Xt.index_select(0, si))
-                Yl = colmajor_empty(k, q, X.device); Yl.copy_(Yt.index_select(0, si))
-                xq_i = colmajor_empty(1, p, X.device); xq_i.copy_(X[i:i + 1])
-            else:
-                Xl = np.asfortranarray(Xt[s_]); Yl = np.asfortranarray(Yt[s_]); xq_i = np.asfortranarray(X[i:i + 1])
-            fmi = plskern(Xl, Yl, w[i], nlv=max(max(rng), 1), scal=obj.scal, ctx=ctx)
-            pr = predict(fmi, xq_i, nlv=rng, ctx=ctx)
-            pr = [pr] if le == 1 else pr
-            for a_, pa_ in enumerate(pr):
-                out[i, :, a_] = (pa_.cpu().numpy() if _is_torch(pa_) else pa_)[0]
-        preds = [out[:, :, a_].copy() for a_ in range(le)]
-        return LwplsrPred(preds[0] if le == 1 else preds, ind, dist, w)
     preds = [pred[:, i, :].copy() for i in range(le)]
     return LwplsrPred(preds[0] if le == 1 else preds, ind, dist, w)
 
@@ -1032,8 +1015,6 @@ def _class_score_stats(fm: Plsr, yv, lev, ctx):
     T = fm.T
     dev = _is_torch(T)
     n, a = T.shape
-    if a > 64:
-        raise NotImplementedError("plslda / plsqda: more than 64 LVs are not supported")
     ctx = ctx or default_context((T.device.index or 0) if dev else 0)
     aa, lda_ = _addr_ld(T)
     if dev:

@@ -76,6 +76,22 @@ function jchemo_module()
     _jchemo[]
 end
 
+# ---- tables: the reference returns DataFrames (gridscore.jl:196-220, gridcv.jl:211-227, plskern.jl:258-259) --------------------
+const _DATAFRAMES_ID = Base.PkgId(Base.UUID("a93c6f00-e57d-5684-b7b6-d8193f3e46c0"), "DataFrames")   # Project.toml:8 of the reference
+"The loaded `DataFrames` module (a dependency of Jchemo, so present whenever Jchemo is), or `nothing`."
+dataframes_module() = get(Base.loaded_modules, _DATAFRAMES_ID, nothing)
+
+"""
+`_table(cols)`: `cols` is a NamedTuple of equal-length column vectors IN THE REFERENCE'S COLUMN ORDER.  With DataFrames loaded the
+result is `DataFrame(cols)` — the type the reference returns —, otherwise the NamedTuple itself (a Tables.jl column table with the
+same column names, so `DataFrame(t)` gives the reference's table).
+"""
+function _table(cols::NamedTuple)
+    D = dataframes_module()
+    D === nothing ? cols : Base.invokelatest(getfield(D, :DataFrame), cols)
+end
+_ynames(q) = Tuple(Symbol("y", i) for i in 1:q)                     # `namy = map(string, repeat(["y"], q), 1:q)`
+
 # ---- fallback result record: field names / shapes of Jchemo.Plsr (src/plskern.jl:1-14) ---------------
 struct Plsr{TT_, WT}
     T::TT_                      # n x nlv   (Matrix{Float64}, or ROCArray for device-resident fits)
@@ -288,9 +304,8 @@ end
 """
     explvarx(object, X)
 
-The table of `summary(object::Plsr, X)` (src/plskern.jl:246-260) as a column table `(nlv, var, pvar, cumpvar)` (the
-reference wraps the same four columns in a `DataFrame`; `DataFrame(explvarx(fm, X))` gives exactly that), with
-`sstot` computed on the GPU.  `object`: either record; X: the data the model was fitted on.
+The table of `summary(object::Plsr, X)` (src/plskern.jl:246-260): a `DataFrame` with the columns `nlv, var, pvar, cumpvar`
+when DataFrames is loaded (it is whenever Jchemo is), the same columns as a NamedTuple otherwise; `sstot` computed on the GPU.  `object`: either record; X: the data the model was fitted on.
 """
 function explvarx(object, X; ctx = default_ctx())
     X = _in(X); n, nlv = size(X, 1), _nlv_fit(object)
@@ -304,7 +319,7 @@ function explvarx(object, X; ctx = default_ctx())
     end
     tt_adj = vec(sum(object.P .^ 2, dims = 1)) .* object.TT
     pvar = tt_adj / ss[]
-    (nlv = collect(1:nlv), var = tt_adj / n, pvar = pvar, cumpvar = cumsum(pvar))
+    _table((nlv = collect(1:nlv), var = tt_adj / n, pvar = pvar, cumpvar = cumsum(pvar)))   # src/plskern.jl:258: DataFrame(nlv, var, pvar, cumpvar)
 end
 
 "`summary(object::JchemoHIP.Plsr, X)` — src/plskern.jl:246-260: `(explvarx = table,)`.  (A `Jchemo.Plsr` returned by a
@@ -439,7 +454,7 @@ function _predict_lwplsr(object, X, nlv, ctx)
     Zt, qmap, _ = _knn_train_space(object, Xt, ctx)
     Zt = _colocate_mat(Zt, X); Zq = _colocate_mat(qmap(X), X)
     k = min(object.k, n); le = length(rng)
-    q <= 16 || error("predict(::Lwplsr): the batched kernel handles q <= 16 responses")
+    # (no shape limits: outside the batched kernels' envelope the library runs its per-query generic paths, include/jchemo_hip.h)
     pred = zeros(q, le, m); ind = zeros(Int32, k, m); dist = zeros(k, m); w = zeros(k, m)   # C layout [m][le][q] == Julia (q, le, m)
     Yt = _colocate_mat(_in(object.Y), X)
     GC.@preserve Xt Yt Zt Zq X check(ctx, ccall((:jch_lwplsr_predict, LIB), Int32,
@@ -559,21 +574,25 @@ function _pred_matrix(fm, X, rng, ctx)
     _affine(Tq, nothing, nothing, Bc[1:size(Tq, 2), :], repeat(fm.ymeans, length(rng)), ctx)
 end
 
-function _grid_table(pars, rng, res)
+# Columns of the reference's result table, in its order (src/gridscore.jl:196-220: `hcat(dat, res)` with dat = the `pars` columns,
+# each combination repeated le_nlv times, then `nlv`; res = y1 ... yq), rows combination-major.
+function _grid_cols(pars, rng, res::AbstractMatrix)
     rows = _pars_rows(pars)
-    cols = (nlv = repeat(collect(rng), length(rows)),)
+    cols = NamedTuple()
     if pars !== nothing
-        cols = merge(cols, NamedTuple{keys(pars)}(Tuple([r[nm] for r in rows for _ in rng] for nm in keys(pars))))
+        cols = NamedTuple{keys(pars)}(Tuple([r[nm] for r in rows for _ in rng] for nm in keys(pars)))
     end
-    merge(cols, (res = res,))
+    cols = merge(cols, (nlv = repeat(collect(rng), length(rows)),))
+    merge(cols, NamedTuple{_ynames(size(res, 2))}(Tuple(res[:, j] for j in 1:size(res, 2))))
 end
 
 """
     gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars = nothing, verbose = false)
 
 src/gridscore.jl:167-221: one fit at `maximum(nlv)` per parameter combination, the predictions of the whole nlv range from ONE
-pass over `X`, the scores from device-side sums.  Returns the columns of the reference's DataFrame as a NamedTuple
-`(nlv, <pars...>, res)` with `res` (ncomb * le_nlv) x q, combination-major (`DataFrame(...)` of it gives the reference's table).
+pass over `X`, the scores from device-side sums.  Returns what the reference returns (:196-220): a `DataFrame` with the columns
+`<pars...>, nlv, y1 ... yq`, one row per (combination, nlv), combination-major — as a NamedTuple of those columns when DataFrames
+is not loaded.
 """
 function gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars = nothing, verbose = false, ctx = default_ctx())
     pars === nothing || !(:nlv in keys(pars)) || error("Argument `pars` must not contain `nlv`")
@@ -592,7 +611,7 @@ function gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars = nothing, verb
         end
     end
     verbose && println("-- End.")
-    _grid_table(pars, rng, reduce(vcat, blocks))
+    _table(_grid_cols(pars, rng, reduce(vcat, blocks)))
 end
 
 """
@@ -602,7 +621,10 @@ src/gridcv.jl:187-228.  The reference copies `rmrow(X, s)` for every segment; he
 weighted fit with weight 0 on the held-out rows (same means, X'DY and loadings as the fit on the remaining rows), whose scores on
 the held-out rows already are their transformed rows, so the predictions for every nlv are a GEMM on the n x nlv scores.
 `score`: one of `msep, rmsep, ssr, bias, r2, cor2`; `fun`: a PLS fit of this module taking `(X, Y, weights; nlv, ...)`.
-Returns `(nlv, <pars...>, res, res_rep)`: `res` the mean over replications and segments, `res_rep[rep][segm]` the per-fold tables.
+Returns what the reference returns (:211-227): `(res = table, res_rep = table)` — `res_rep` with the columns
+`repl, segm, <pars...>, nlv, y1 ... yq` (one row per replication, segment, combination and nlv), `res` the means of `y1 ... yq` over
+replications and segments per `(nlv, <pars...>)` group in order of first appearance (`combine(groupby(res_rep, [:nlv; pars...]), mean)`);
+DataFrames when that package is loaded, NamedTuples of the same columns otherwise.
 """
 function gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false, ctx = default_ctx())
     score isa ScoreFun || error("gridcvlv: score must be one of msep, rmsep, ssr, bias, r2, cor2")
@@ -635,8 +657,19 @@ function gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false, 
         push!(res_rep, zres)
     end
     verbose && println("/ End.")
+    # res_rep: per replication the segments' tables stacked, behind the columns repl, segm (src/gridcv.jl:211-222)
+    per = length(rng) * length(_pars_rows(pars))                    # rows per fold
+    foldcols = [_grid_cols(pars, rng, z) for zres in res_rep for z in zres]
+    repl = reduce(vcat, [fill(i, per * length(zres)) for (i, zres) in enumerate(res_rep)])
+    segmc = reduce(vcat, [repeat(1:length(zres), inner = per) for zres in res_rep])
+    stacked = NamedTuple{keys(first(foldcols))}(Tuple(reduce(vcat, [c[nm] for c in foldcols]) for nm in keys(first(foldcols))))
+    rep_cols = merge((repl = repl, segm = segmc), stacked)
+    # res: groupby(res_rep, [:nlv; keys(pars)...]) in order of first appearance = the row order of one fold, means of y1 ... yq (:223-226)
     allfolds = reduce(vcat, res_rep)
-    merge(_grid_table(pars, rng, sum(allfolds) ./ length(allfolds)), (res_rep = res_rep,))
+    g1 = _grid_cols(pars, rng, sum(allfolds) ./ length(allfolds))
+    gkeys = pars === nothing ? (:nlv,) : (:nlv, keys(pars)...)
+    res_cols = merge(NamedTuple{gkeys}(Tuple(g1[nm] for nm in gkeys)), NamedTuple{_ynames(q)}(Tuple(g1[nm] for nm in _ynames(q))))
+    (res = _table(res_cols), res_rep = _table(rep_cols))
 end
 
 # ---- PLSR-DA (src/plsrda.jl) -----------------------------------------------------------------------------------------------------
@@ -727,7 +760,6 @@ end
 function vip(object, Y; nlv = nothing, ctx = default_ctx())
     a = _nlv_fit(object); p = size(object.W, 1); k = nlv === nothing ? a : min(nlv, a)
     T = object.T[:, 1:k]; Y = _colocate_mat(_in(Y), T); q = size(Y, 2)
-    q + k <= 64 || error("vip(object, Y): q + nlv > 64 is not supported")
     A_ = hcat(Y, T); n = size(A_, 1); w = _colocate(object.weights, A_)
     S = zeros(q + k, q + k)
     GC.@preserve A_ w check(ctx, ccall((:jch_weighted_cov, LIB), Int32,

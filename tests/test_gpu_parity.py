@@ -475,6 +475,7 @@ def test_slice_sums_inside_the_sweep_are_bit_identical(shape, J, ctx, monkeypatc
     Lt = rng.standard_normal((n, 2 * nlv))
     X = np.asfortranarray(Lt @ rng.standard_normal((2 * nlv, p)) + 0.4 * rng.standard_normal((n, p)))
     Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.2 * rng.standard_normal((n, q)))
+    monkeypatch.setenv("JCH_LV_SPLIT", "0")        # (the one-kernel small-state path: it consumes the slice sums this test is about)
     ref = J.plskern(X, Y, nlv=nlv, ctx=ctx)
     monkeypatch.setenv("JCH_SWEEP_FUSED_REDUCE", "1")
     for _ in range(3):
@@ -768,8 +769,8 @@ def test_sibling_limits_and_wold_options(J, ctx):
     Xw = np.asfortranarray(rng.standard_normal((300, 2300))); Yw = np.asfortranarray(Xw[:, :3] @ rng.standard_normal((3, 2)) + 0.1 * rng.standard_normal((300, 2)))
     for name in ("plssimp", "plswold"):                     # p > 2048: two-pass wide sweep + generic small-state kernel
         _sib_cmp(getattr(O, name)(Xw, Yw, nlv=4, scal=True), getattr(J, name)(Xw, Yw, nlv=4, scal=True, ctx=ctx), tol=1e-8)
-    with pytest.raises(J.JchError):
-        J.plssimp(X, np.asfortranarray(rng.standard_normal((400, 65))), nlv=2, ctx=ctx)      # q > 64: loud error
+    Y65 = np.asfortranarray(X[:, :20] @ rng.standard_normal((20, 65)) + 0.2 * rng.standard_normal((400, 65)))
+    _sib_cmp(O.plssimp(X, Y65, nlv=2), J.plssimp(X, Y65, nlv=2, ctx=ctx), tol=1e-8)          # q > 64 (round 4): no limit any more
     Y4 = np.asfortranarray(Y[:, :4])
     for maxit in (1, 2, 5):
         ref = O.plswold(X, Y4, nlv=3, maxit=maxit)
@@ -1243,13 +1244,9 @@ def test_lwplsr_kspace_matches_pspace(case, J, ctx):
         os.environ["JCH_LOCW_KSPACE"] = "2"
         ks = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
         os.environ["JCH_LOCW_KSPACE"] = "0"
-        if c["p"] > 1024 and c["q"] > 4:    # the p-space kernel's LDS bookkeeping does not fit this shape: it must say so, and the
-            with pytest.raises(J.JchError):  # default dispatch must fall through to the neighbour-space kernel instead of failing
-                J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
-            os.environ.pop("JCH_LOCW_KSPACE")
-            ps = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
-        else:
-            ps = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
+        # (p > 1024 with q > 4: the p-space kernel's LDS bookkeeping does not fit and, with the neighbour-space kernel switched off,
+        # the call runs the per-query generic fits — round 4: no shape is refused; the comparison below then is k-space vs generic)
+        ps = J.predict(J.lwplsr(X, Y, ctx=ctx, **kw), Xq, nlv=rng, ctx=ctx)
     finally:
         if keep is None:
             os.environ.pop("JCH_LOCW_KSPACE", None)
@@ -1295,3 +1292,43 @@ def test_plswold_zero_weight_rows_both_modes(J, ctx):
     c = J.plswold(Xd, Yd, torch.from_numpy(w).cuda(), nlv=nlv, zero_weight_nan=True, ctx=ctx)
     Tc = c.T.cpu().numpy()
     assert np.all(np.isnan(Tc[zero])) and np.array_equal(Tc[keep], b.T[keep])
+
+
+@pytest.mark.parametrize("shape", [dict(n=3000, p=500, q=10, nlv=25), dict(n=900, p=37, q=1, nlv=12), dict(n=1200, p=130, q=2, nlv=9),
+                                   dict(n=2000, p=257, q=3, nlv=20), dict(n=2500, p=64, q=7, nlv=30), dict(n=1500, p=1000, q=16, nlv=15),
+                                   dict(n=700, p=16, q=5, nlv=16), dict(n=400, p=301, q=12, nlv=40)])
+@pytest.mark.parametrize("variant", ["raw", "scal_w", "centred", "rosa"])
+def test_split_small_state_matches_one_kernel_path(shape, variant, J, ctx, monkeypatch):
+    """Round 4: the per-LV small-state step as two kernels (smallstate_split.hip: a p-parallel kernel on (p + 15) / 16 CUs + a
+    single-workgroup kernel that starts at the eigenvector) against the one-kernel path (JCH_LV_SPLIT=0) and the oracle: the same
+    arithmetic with the sums over p taken block-wise, so agreement to rounding (1e-8 on the leading LVs: a PLS1 fit on uniform columns loses a digit per LV in ANY summation order), every QP instantiation (q = 1 ... 16),
+    raw mode / scaling + weights / centred copy, plsrosa, nlv beyond 32 (R rows past the register prefetch)."""
+    n, p, q, nlv = (shape[k] for k in ("n", "p", "q", "nlv"))
+    X = CO.fill_uniform(401, n, p) + 3.0
+    B0 = CO.fill_uniform(402, p, q) - 0.5
+    Y = X @ B0 + 0.1 * CO.fill_uniform(403, n, q)
+    w = CO.fill_uniform(404, n, 1)[:, 0] + 0.2 if variant == "scal_w" else None
+    scal = variant == "scal_w"
+    fn, ofn = (J.plsrosa, O.plsrosa) if variant == "rosa" else (J.plskern, O.plskern)
+    if variant == "centred":
+        monkeypatch.setenv("JCH_CENTRED_COPY", "1")
+    fm = fn(X, Y, w, nlv=nlv, scal=scal, ctx=ctx)
+    monkeypatch.setenv("JCH_LV_SPLIT", "0")
+    fm1 = fn(X, Y, w, nlv=nlv, scal=scal, ctx=ctx)
+    ref = ofn(X, Y, w, nlv=nlv, scal=scal)
+    k = fm.T.shape[1]
+    assert k == fm1.T.shape[1] == min(n, p, nlv)
+    # the leading LVs (conditioning of later ones on collinear-ish uniform data is a property of the data, not of the path)
+    kk = min(k, 8)
+    s1 = O.sign_align(fm1.W[:, :kk], fm.W[:, :kk])
+    for f in FIELDS:
+        assert O.rel_fro(getattr(fm1, f)[:, :kk], getattr(fm, f)[:, :kk] * s1) < 1e-8, (f, "split vs one kernel")
+    assert O.rel_fro(fm1.TT[:kk], fm.TT[:kk]) < 1e-8
+    s = O.sign_align(ref.W[:, :kk], fm.W[:, :kk])
+    for f in FIELDS:
+        assert O.rel_fro(getattr(ref, f)[:, :kk], getattr(fm, f)[:, :kk] * s) < 1e-8, (f, "split vs oracle")
+    # invariants on ALL LVs: T'DT = diag(TT), R'P = I
+    d = fm.weights
+    G = (fm.T * d[:, None]).T @ fm.T
+    assert np.abs(G - np.diag(fm.TT)).max() < 1e-9 * np.abs(fm.TT).max()
+    assert np.abs(fm.R.T @ fm.P - np.eye(k)).max() < 1e-8
