@@ -542,6 +542,146 @@ __global__ __launch_bounds__(256, NH <= 2 ? 2 : 1) void k_center_xty_bf16_panel(
     }
 }
 
+// ---------------------------------------------------------------- K2pb on the bf16 matrix pipe (round 4)
+// UNIT weights, no scaling, q <= 15: the operands of X'[Y | 1] are then the RAW bf16 values themselves — exact bf16 — and the
+// product runs on v_mfma_f32_16x16x32_bf16 (16 cycles per 16 x 16 x 32 against 8 x 64 cycles of v_mfma_f64_16x16x4 for the same
+// 32 rows: the f64 pipe time of K2pb, 0.21 of its 0.53 ms, disappears).  The 16-B load of 8 consecutive rows of one column IS the
+// A operand of a 32-row block (lane l: m = column l & 15, k = rows 8 (l >> 4) ..+7), the same load of a Y column the B operand;
+// every bf16 x bf16 product is exact in f32, a block's 32-term sum is taken in f32 inside the instruction and added to an f64
+// accumulator right after it, so the only rounding beyond the f64 path's is the f32 sum of 32 exact products per block
+// (measured on cfg3-like data at n = 1e6: K within 6e-7, on data with a signal 2e-9 — the mode's budget is 1e-3 / 1e-4).
+// Centring happens afterwards in f64 on the p x q sums (k_bf16_m32_fix): K = (X'Y - (X'1) ybar') / n, means = X'1 / n.
+// Same tile walk, LDS transposition and row-major stores as k_center_xty_bf16_panel; Yr is not written (plskern never reads it).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float v4f32b __attribute__((ext_vector_type(4)));
+template <int NT, int NH>
+__global__ __launch_bounds__(256, NH <= 2 ? 2 : 1) void k_xty_bf16_panel_m32(
+    const bf16_t *__restrict__ Xc, int64_t ldx, const bf16_t *__restrict__ Yc, int64_t ldy, int64_t nfull, int p, int q,
+    bf16_t *__restrict__ Xr, int ldr, double *__restrict__ Kpart, int kp_rows)
+{
+    constexpr int TH = 32 * NH;
+    constexpr int pitch = 516;
+    extern __shared__ __attribute__((aligned(16))) double bp_lds[];
+    bf16_t *xt = reinterpret_cast<bf16_t *>(bp_lds);           // [TH][pitch] raw tile, row-major
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, cidx = lane & 15;
+    const int cg0 = blockIdx.y * 512;
+    const int wcols = min(ldr - cg0, 512);
+    const int64_t istep = (int64_t)gridDim.x * TH;
+    // B operand: lane (g, n) holds rows 32 h + 8 g ..+7 of y column n (n < q), ones for n == q (column sums of X), zeros beyond
+    const size_t yoff = (size_t)min(cidx, q - 1) * (size_t)ldy;
+    const unsigned ymask = cidx < q ? 0xffffffffu : 0u, yones = cidx == q ? 0x3f803f80u : 0u;
+    v4u32 Bf[NH], Bn[NH];
+    auto issue_b = [&](int64_t i0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) Bn[h] = *reinterpret_cast<const v4u32 *>(Yc + (size_t)(i0 + 32 * h + 8 * g) + yoff);
+    };
+    auto take_b = [&]() {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            Bf[h] = v4u32{(Bn[h].x & ymask) | yones, (Bn[h].y & ymask) | yones, (Bn[h].z & ymask) | yones, (Bn[h].w & ymask) | yones};
+    };
+    v4f64 acc[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+    constexpr int RING = NT < 4 ? NT : 4;
+    v4u32 R[RING][NH];
+    const int jlane = cg0 + 16 * wv + cidx;
+    auto issue_piece = [&](int64_t i0, int ct) {
+        const size_t coff = (size_t)min(jlane + 64 * ct, p - 1) * (size_t)ldx;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            R[ct % RING][h] = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(Xc + (size_t)(i0 + 32 * h + 8 * g) + coff));
+    };
+    int64_t i0 = (int64_t)blockIdx.x * TH;
+    if (i0 < nfull) {
+        issue_b(i0);
+#pragma unroll
+        for (int ct = 0; ct < RING; ++ct) issue_piece(i0, ct);
+    }
+    auto tile = [&](auto has_next, int64_t i0) {
+        take_b();
+        if (decltype(has_next)::value) issue_b(i0 + istep);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const int cc = 64 * ct + 16 * wv + cidx;
+            const unsigned lmask = cg0 + cc < p ? 0xffffffffu : 0u;
+            bf16_t *xw = xt + 8 * g * pitch + (cc < wcols ? cc : wcols + (cc & 3));
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const v4u32 a = {R[ct % RING][h].x & lmask, R[ct % RING][h].y & lmask, R[ct % RING][h].z & lmask, R[ct % RING][h].w & lmask};
+                const unsigned w4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned w = w4[e >> 1];
+                    xw[(32 * h + e) * pitch] = (bf16_t)((e & 1) ? (w >> 16) : w);
+                }
+                const v4f32b pr = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, Bf[h]),
+                                                                          v4f32b{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[ct][reg] += (double)pr[reg];
+            }
+            if (ct + RING < NT) issue_piece(i0, ct + RING);
+            else if (decltype(has_next)::value) issue_piece(i0 + istep, ct + RING - NT);
+        }
+        __syncthreads();   // tile complete in LDS
+        {
+            const int c16n = wcols >> 3;
+#pragma unroll 4
+            for (int row = wv; row < TH; row += 4) {
+                for (int c16 = lane; c16 < c16n; c16 += 64) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(xt + row * pitch + 8 * c16);
+                    const v2u64b v = {src[0], src[1]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<v2u64b *>(Xr + (size_t)(i0 + row) * (size_t)ldr + cg0 + 8 * c16));
+                }
+            }
+        }
+        __syncthreads();   // the tile may be overwritten
+    };
+    for (; i0 + istep < nfull; i0 += istep) tile(std::true_type{}, i0);
+    if (i0 < nfull) tile(std::false_type{}, i0);
+    // D[m][n] of v_mfma_f32_16x16x32: n = lane & 15 (y column), m = 4 (lane >> 4) + reg (x column within the wave's 16)
+    double *kp = Kpart + ((size_t)blockIdx.x * kp_rows) * 16;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int jj = 64 * ct + 16 * wv + 4 * g + reg;
+            if (jj < 512 && cg0 + jj < kp_rows) kp[(size_t)(cg0 + jj) * 16 + cidx] = acc[ct][reg];
+        }
+    }
+}
+// the ragged tail (n % TH rows) of the m32 path: raw sums x' [y | 1] in f64 into one Kpart slot + the tail's rows of the copy
+__global__ __launch_bounds__(256) void k_xty_bf16_tail_m32(const bf16_t *__restrict__ Xc, int64_t ldx, const bf16_t *__restrict__ Yc, int64_t ldy,
+                                                           int64_t r0, int nt, int p, int q, bf16_t *__restrict__ Xr, int ldr,
+                                                           double *__restrict__ kslot, int kp_rows)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kp_rows * 16) return;
+    const int j = e >> 4, k = e & 15;
+    double s = 0.0;
+    if (j < p && k <= q)
+        for (int r = 0; r < nt; ++r) {
+            const double x = (double)bf2f(Xc[(size_t)(r0 + r) + (size_t)j * (size_t)ldx]);
+            s += k < q ? x * (double)bf2f(Yc[(size_t)(r0 + r) + (size_t)k * (size_t)ldy]) : x;
+        }
+    kslot[e] = s;
+    if (k == 0 && j < ldr)
+        for (int r = 0; r < nt; ++r) Xr[(size_t)(r0 + r) * (size_t)ldr + j] = j < p ? Xc[(size_t)(r0 + r) + (size_t)j * (size_t)ldx] : (bf16_t)0;
+}
+// K = (X'Y - (X'1) ybar') / n, means = X'1 / n from the all-reduced raw sums (column q of K = X'1; ybar at ymeans); hdr[1] = n
+__global__ __launch_bounds__(256) void k_bf16_m32_fix(double *__restrict__ K, int qpad, int p, int q, const double *__restrict__ ymeans,
+                                                      const double *__restrict__ hdr, double *__restrict__ means)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= p) return;
+    const double inv = 1.0 / hdr[1];
+    const double mj = K[(size_t)j * qpad + q] * inv;
+    for (int k = 0; k < q; ++k) K[(size_t)j * qpad + k] = K[(size_t)j * qpad + k] * inv - mj * ymeans[k];
+    for (int k = q; k < qpad; ++k) K[(size_t)j * qpad + k] = 0.0;
+    means[j] = mj;
+}
+
 // fixed-order sum of the per-block XtY partials [nbx][kp_rows][16] (several hundred slots): 4 groups of blocks per entry with
 // 4 independent chains each, combined in group order (same scheme as k_reduce_kpart_wide, prologue.hip)
 __global__ __launch_bounds__(256) void k_reduce_kpart_bw(const double *__restrict__ Kpart, int nbx, int kp_rows, int p, int qpad,
@@ -934,7 +1074,8 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
 
 template <int KC, int R>
 static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, int ldr_b, const double *d, const double *rvec,
-                                      const double *mom, const double *scl, int p, double *tcol, double *zt8, int ldzb, int *nslice)
+                                      const double *mom, const double *scl, int p, double *tcol, double *zt8, int ldzb, int *nslice,
+                                      jch_part_view *pv = nullptr /*split small-state path on one rank / with the per-block inbox: leave the block partials unreduced*/)
 {
     const size_t lds = sizeof(double) * (4 * KC * 512 + 8);
     static int bpc = 0;
@@ -957,6 +1098,7 @@ static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n,
     (void)jch_ev(ctx);
     hipLaunchKernelGGL((k_sweep_bf16_v2<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
     (void)jch_ev(ctx);
+    if (pv) { pv->part = part; pv->nb = nb; pv->ldpart = ldpart; *nslice = 1; JCH_HIP(ctx, hipGetLastError()); return JCH_OK; }
     JCH_TRY(jch_launch_reduce_part8(ctx, part, nb, ldpart, m, zt8, ldzb, nslice));
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;
@@ -1024,6 +1166,7 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
     if (d.scal) JCH_TRY(launch_moments_bf16(ctx, Xc, ldx, Yc, ldy, dn, n, p, q, s.mom, s.scl));
     else hipLaunchKernelGGL(k_fill_b, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
     }
+    bool m32 = false;
     {
         const int ptiles = (ldr_b + 63) / 64, kp_rows = ptiles * 64, ygroups = qpad / 16;
         const int64_t nchunks = (n + 63) / 64;
@@ -1044,6 +1187,33 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         const int NHv = k2nh == 4 ? 4 : 2, THv = 32 * NHv;
         const int64_t nfull = (n / THv) * THv;
         const bool panel = k2panel && v8 && qpad == 16 && ldy % 8 == 0 && ((uintptr_t)Yc) % 16 == 0 && ((uintptr_t)dn) % 16 == 0 && nfull > 0;
+        // unit weights, raw mode: the products on the bf16 matrix pipe (k_xty_bf16_panel_m32; JCH_BF16_K2_M32=0: the f64 products)
+        const char *e_m32 = getenv("JCH_BF16_K2_M32");
+        m32 = panel && raw_b && !wdev && !(e_m32 && atoi(e_m32) == 0) && NHv == 2;
+        if (m32) {
+            const int ncg = (ldr_b + 511) / 512;
+            const int wmax = std::min(ldr_b, 512), ntile = (wmax + 63) / 64;
+            const int NTv = ntile <= 1 ? 1 : (ntile <= 2 ? 2 : (ntile <= 4 ? 4 : 8));
+            const int bpc = k2pbpc > 0 ? k2pbpc : 2;
+            int G = std::max(1, ctx->cus * bpc / ncg);
+            G = (int)std::min<int64_t>(G, nfull / THv);
+            const int kpr = ncg * 512;
+            const bool tail = nfull < n;
+            JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)(G + 1) * kpr * 16));
+            Kpart = (double *)ctx->kpart.ptr;
+            const size_t lds = sizeof(bf16_t) * (size_t)THv * 516 + 16;
+#define JCH_K2M(NT) do { \
+                static jch_per_device_once once_; \
+                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_xty_bf16_panel_m32<NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
+                hipLaunchKernelGGL((k_xty_bf16_panel_m32<NT, 2>), dim3(G, ncg), dim3(256), lds, ctx->stream, Xc, ldx, Yc, ldy, nfull, p, q, Xr, ldr_b, Kpart, kpr); } while (0)
+            if (NTv == 1) JCH_K2M(1); else if (NTv == 2) JCH_K2M(2); else if (NTv == 4) JCH_K2M(4); else JCH_K2M(8);
+#undef JCH_K2M
+            JCH_HIP(ctx, hipGetLastError());
+            if (tail)
+                hipLaunchKernelGGL(k_xty_bf16_tail_m32, dim3((kpr * 16 + 255) / 256), dim3(256), 0, ctx->stream, Xc, ldx, Yc, ldy, nfull, (int)(n - nfull), p, q,
+                                   Xr, ldr_b, Kpart + (size_t)G * kpr * 16, kpr);
+            hipLaunchKernelGGL(k_reduce_kpart_bw, dim3((p * qpad + 63) / 64), dim3(256), 0, ctx->stream, Kpart, G + (tail ? 1 : 0), kpr, p, qpad, s.K);
+        } else
         if (panel) {
             const int ncg = (ldr_b + 511) / 512;                       // 512-column groups (blockIdx.y)
             const int wmax = std::min(ldr_b, 512), ntile = (wmax + 63) / 64;
@@ -1095,7 +1265,9 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
                                 s.scl, Xr, ldr_b, Yr, qpad, Kpart, kp_rows);
         if (!panel) hipLaunchKernelGGL(k_reduce_kpart_b, dim3((p * qpad + 255) / 256), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, qpad, s.K);
         JCH_TRY(jch_allreduce_f64(ctx, s.K, (size_t)p * qpad));
-        if (raw_b) {   // means = pivot + K[:, q]; Y means next to them; divisors = 1
+        if (raw_b) {   // means = pivot + K[:, q] (m32: centring of the raw sums); Y means next to them; divisors = 1
+            if (m32) hipLaunchKernelGGL(k_bf16_m32_fix, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, s.K, qpad, p, q, s.scl + p, s.hdr, s.mom);
+            else
             hipLaunchKernelGGL(k_extract_means_b, dim3((p + 255) / 256), dim3(256), 0, ctx->stream, s.K, qpad, p, q, s.scl, s.mom);
             JCH_HIP(ctx, hipMemcpyAsync(s.mom + p, s.scl + p, sizeof(double) * (size_t)q, hipMemcpyDeviceToDevice, ctx->stream));
             hipLaunchKernelGGL(k_fill_b, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, s.scl, p + q, 1.0);
@@ -1111,13 +1283,16 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         static int rsel = -1;
         if (rsel < 0) { const char *e = getenv("JCH_BF16_R"); rsel = e ? atoi(e) : 4; }   // measured at n = 1e6, p = 500 with the prefetch: R = 2 / 4 / 8 -> 5.35 / 5.84 / 5.40 TB/s (without: 4.67 / 5.07)
         int nslice = 1;
+        jch_part_view pv;
+        const bool fuse_now = fast && ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED") && (size_t)(ldr_b + 2) <= ctx->p2p.cap;
+        jch_part_view *pvp = (fast && s.kr && (ctx->nranks == 1 || fuse_now)) ? &pv : nullptr;   // split path: k_lv_spread sums the block partials
         {   // v2 kernels (permlane row sums, rotating buffers); JCH_BF16_V2=0 selects the round-1 kernels below (read per call)
             const char *e2 = getenv("JCH_BF16_V2");
             const int v2 = e2 ? atoi(e2) : 1;
             if (v2 && ldr_b >= 8 && ldr_b <= 1024) {
-                if (ldr_b <= 512) { if (v2 == 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)));
-                                    else JCH_TRY((launch_sweep_bf16_v2_t<1, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice))); }
-                else JCH_TRY((launch_sweep_bf16_v2_t<2, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice)));
+                if (ldr_b <= 512) { if (v2 == 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
+                                    else JCH_TRY((launch_sweep_bf16_v2_t<1, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp))); }
+                else JCH_TRY((launch_sweep_bf16_v2_t<2, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
                 goto swept;
             }
         }
@@ -1138,10 +1313,12 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
         // all-reduces them and applies the centring / scaling fix-up itself; generic kernel: separate steps.
         if (fast) {
             const bool fuse = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED") && (size_t)(ldr_b + 2) <= ctx->p2p.cap;
-            if (!fuse) JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));
-            else ctx->coll_transport = JCH_TRANSPORT_INBOX_FUSED;
-            if (s.kr)   // split small-state path (smallstate_split.hip): the slices are summed (and, with the inbox, exchanged) by its p-parallel kernel
-                JCH_TRY(jch_launch_lv_split(ctx, s, p, q, ldr_small, a, nlv, zt8, nslice, ldzb, ldr_b, ldr_b + 1, 2, a + 1 < nlv, fuse));
+            if (!fuse && !pv.part) JCH_TRY(jch_allreduce_slices(ctx, zt8, ldr_b + 2, nslice, ldzb, &nslice));
+            else if (fuse) ctx->coll_transport = JCH_TRANSPORT_INBOX_FUSED;
+            if (s.kr) {   // split small-state path (smallstate_split.hip): the partial rows / slices are summed (and, with the inbox, exchanged) by its p-parallel kernel
+                if (!pv.part) { pv.part = zt8; pv.nb = nslice; pv.ldpart = ldzb; }
+                JCH_TRY(jch_launch_lv_split(ctx, s, p, q, ldr_small, a, nlv, pv.part, pv.nb, pv.ldpart, ldr_b, ldr_b + 1, 2, a + 1 < nlv, fuse));
+            }
             else
             JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr_small, a, nlv, 0, nslice, ldz, true, fuse, zt8, ldzb, ldr_b));
         } else {

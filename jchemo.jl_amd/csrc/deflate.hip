@@ -543,8 +543,11 @@ __global__ __launch_bounds__(1024) void k_reduce_kpart3(const double *__restrict
 // waves of a block share the rows of a chunk and split its spans (s = wave + 4 u), so the B operand d_i * y_i (with this
 // LV's Y step applied) and the pending scores are staged ONCE per chunk in LDS, double-buffered: one barrier per chunk,
 // nothing else.  Pending loadings of the lane's 2 NS columns sit in registers.  X is prefetched one chunk ahead.
-template <int NS, int STEPS, int MP, int MINB>
-__global__ __launch_bounds__(256, MINB) void k_kpass_mfma_lazy(double *__restrict__ Xr, int64_t n, int ldr, double *__restrict__ Yr, int q,
+// NW (round 4): waves per block.  NW = 8 with half the spans per wave (NS = 2 at p <= 512) keeps a wave's state inside 256
+// registers, so TWO waves share a SIMD: one wave's products and pending corrections run while the other waits for its rows (with
+// one wave per SIMD at 337 registers 56 % of the wave cycles were issue stalls and nothing else was resident to use them).
+template <int NS, int STEPS, int MP, int MINB, int NW>
+__global__ __launch_bounds__(64 * NW, MINB) void k_kpass_mfma_lazy(double *__restrict__ Xr, int64_t n, int ldr, double *__restrict__ Yr, int q,
                                                          const double *__restrict__ dw, const double *__restrict__ pend_p, int ldp, int npend,
                                                          const double *__restrict__ tpend, int64_t tstride, const double *__restrict__ cvec,
                                                          int flush, double *__restrict__ Kpart, int kp_rows)
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256, MINB) void k_kpass_mfma_lazy(double *__restric
     double pk[MP][NS][2];
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        const int col = 32 * (wv + 4 * u) + 2 * c16;
+        const int col = 32 * (wv + NW * u) + 2 * c16;
         in[u] = col < ldr;
         coff[u] = in[u] ? col : ldr - 2;
 #pragma unroll
@@ -574,9 +577,10 @@ __global__ __launch_bounds__(256, MINB) void k_kpass_mfma_lazy(double *__restric
     const int64_t nchunks = (n + RB - 1) / RB;
     const int knew = npend - 1;
     // staging roles: thread (row = tid >> 4, y = tid & 15) builds the B entry, thread (k = tid >> 4, row = tid & 15) a score
-    const int srow = tid >> 4, sy = tid & 15;
+    // (with NW = 8 the second 256 threads have no staging role: their srow / tk fall outside RB / npend <= MP <= 16 rows ... 15)
+    const int srow = tid < 256 ? tid >> 4 : RB, sy = tid & 15;
     const double cy = sy < q ? cvec[sy] : 0.0;
-    const int tk = tid >> 4, trow = tid & 15;
+    const int tk = tid < 256 ? tid >> 4 : MP, trow = tid & 15;
     // X is prefetched one whole chunk ahead.  (Rotating two buffers and re-requesting every consumed step for chunk c + 2 G
     // — 1.5 chunks in flight — was measured SLOWER for the read-only pass, 968 against 800 us at cfg2 shape: the loads then
     // queue behind each step's eight 64-cycle MFMAs instead of going out ahead of all of them.)
@@ -669,13 +673,13 @@ __global__ __launch_bounds__(256, MINB) void k_kpass_mfma_lazy(double *__restric
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int j = 32 * (wv + 4 * u) + 2 * (4 * reg + g) + h;
+                    const int j = 32 * (wv + NW * u) + 2 * (4 * reg + g) + h;
                     if (j < kp_rows) kp[(size_t)j * 16 + c16] = acc[u][h][reg];
                 }
     }
 }
 
-template <int NS, int STEPS, int MP, int MINB = 1>
+template <int NS, int STEPS, int MP, int MINB = 1, int NW = 4>
 static int32_t launch_kpass_mfma_lazy_t(jch_ctx *ctx, double *Xr, int64_t n, int p, int ldr, double *Yr, int q, const double *d,
                                         const double *pend_p, int npend, const double *tpend, int64_t tstride, const double *cvec,
                                         bool flush, double *Knext)
@@ -690,7 +694,7 @@ static int32_t launch_kpass_mfma_lazy_t(jch_ctx *ctx, double *Xr, int64_t n, int
     JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nb * kp_rows * 16));
     double *Kpart = (double *)ctx->kpart.ptr;
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL((k_kpass_mfma_lazy<NS, STEPS, MP, MINB>), dim3(nb), dim3(256), 0, ctx->stream, Xr, n, ldr, Yr, q, d, pend_p,
+    hipLaunchKernelGGL((k_kpass_mfma_lazy<NS, STEPS, MP, MINB, NW>), dim3(nb), dim3(64 * NW), 0, ctx->stream, Xr, n, ldr, Yr, q, d, pend_p,
                        jch_nipals_lazy_pitch(ldr), npend, tpend, tstride, cvec, flush ? 1 : 0, Knext ? Kpart : nullptr, kp_rows);
     (void)jch_ev(ctx);
     if (Knext) {
@@ -744,7 +748,15 @@ int32_t jch_launch_kpass_lazy(jch_ctx *ctx, double *Xr, int64_t n, int p, int ld
             // (measured at cfg2 shape, read-only pass: 16-row chunks 800-845 us; 32-row chunks with 2 loadings 802; 8-row chunks
             // 914, with two blocks per CU and 3 loadings 745 — but rewriting every 3rd LV instead of every 6th costs as much;
             // 4-row chunks with two blocks per CU 896)
-            if (ldr <= 512) JCH_KM(4, 4, 6);
+            // round 4, measured and NOT the default (JCH_KPASS_NW=8): eight waves per block, two per SIMD, half the spans per wave
+            // (200 registers instead of 337).  plsnipals q = 10 at cfg2 shape: 548.5 LV/s against 550.8 with four waves (pass 1.682
+            // against 1.675 ms per LV), plswold 523.7 against 534.9 — a second resident wave does not fill the issue stalls: the f64
+            // products and the vector work of BOTH waves queue for the same SIMD (the pipe does not overlap them), and
+            // the bytes in flight per CU are unchanged.
+            const char *e_nw = getenv("JCH_KPASS_NW");
+            const bool nw8 = e_nw && atoi(e_nw) == 8;
+            if (ldr <= 512) { if (nw8) JCH_KM(2, 4, 6, 1, 8); JCH_KM(4, 4, 6); }
+            if (nw8) JCH_KM(4, 2, 3, 1, 8);
             JCH_KM(8, 2, 3);
 #undef JCH_KM
         }

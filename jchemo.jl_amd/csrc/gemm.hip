@@ -322,7 +322,9 @@ int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p,
             // 10 -> 16 columns: 2 x 4 waves 0.71 ms, 8 waves 0.73, 12 waves 0.75, tiled kernel 0.73.  JCH_GEMM_NW = 4 / 8 overrides.)
             const char *enw = getenv("JCH_GEMM_NW"), *ert = getenv("JCH_GEMM_RT");
             const int nw = enw ? (atoi(enw) == 4 ? 4 : 8) : (kpad == 16 ? 4 : 8);
-            const int rt = ert ? (atoi(ert) == 1 ? 1 : (atoi(ert) == 4 ? 4 : 2)) : 2;   // row tiles per wave-tile: 256 rt bytes per column piece
+            // row tiles per wave-tile = 256 rt bytes per column piece.  Measured at cfg2 (round 4, tools/bench_accessors.py, whole call):
+            // transform (32 columns) rt = 1 / 2 / 4: 0.905 / 0.877 / 0.846 ms; predict at one nlv (16 columns): 0.839 / 0.769 / 0.768 ms
+            const int rt = ert ? (atoi(ert) == 1 ? 1 : (atoi(ert) == 2 ? 2 : 4)) : 4;
             const int bpc = std::max(1, std::min((int)((158 * 1024) / ldsp), 8 / nw));
             const unsigned nb = (unsigned)std::min<int64_t>((m + 32 * rt * nw - 1) / (32 * rt * nw), (int64_t)ctx->cus * bpc);
 #define JCH_G32P(NT, NW, RT) do { \

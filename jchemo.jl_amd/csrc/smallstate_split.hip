@@ -202,7 +202,15 @@ __global__ __launch_bounds__(FT) void k_lv_solve(lvs_args g)
     double *G0 = Zl + (size_t)g.nlv * QP, *A0 = G0 + QP * lda, *A1 = A0 + QP * lda, *V0 = A1 + QP * lda, *V1 = V0 + QP * lda;
     double *csl = V1 + QP * lda;                   // [2 (QP + 2)]
     JCH_SSTAMP(0);
-    // ---- loads: first what the eigenvector needs (partial Gram matrices), then what can arrive while it is being computed
+    // ---- loads: what the eigenvector needs (the partial Gram matrices) and the few words the Z update needs; the three small ones
+    // go out FIRST (behind the wait for the partials they were a second round trip).  Everything the tail needs (K_new, the R rows)
+    // is requested after the barrier and arrives while wave 0 solves.
+    // (Measured and rejected, round 4: NO barrier here — wave 0 summing all 256 Gram entries for itself, 128 loads per lane, and every
+    // other thread its own Z entry, 33 loads each: the eigenvector started later, 11.0 k cycles against 9.6 k, and the Z updates
+    // outlasted it at the late LVs; small state 0.51 -> 0.555 ms per fit.)
+    const double cpre = tid < q ? g.s.C[(size_t)a * q + tid] : 0.0;
+    const double tt = g.s.TT[a];
+    const double zpre = tid < a * QP ? g.s.Z[tid] : 0.0;
     const int nent = SP_GP + a;
     double gacc = 0.0;
     {
@@ -222,10 +230,6 @@ __global__ __launch_bounds__(FT) void k_lv_solve(lvs_args g)
             for (int u = 0; u < 8; ++u) gacc += b0 + u < g.nblk ? v[u] : 0.0;
         }
     }
-    if (g.s.dbg && tid == 0) { g.s.dbg[512 + 16 * (g.a + 1) + 12] = (double)__builtin_readcyclecounter() + (gacc == 1.234e300 ? 1.0 : 0.0); }
-    const double cpre = tid < q ? g.s.C[(size_t)a * q + tid] : 0.0;
-    const double tt = g.s.TT[a];
-    const double zpre = tid < a * QP ? g.s.Z[tid] : 0.0;
     // (every LDS word is written by exactly ONE thread before the barrier below — no zero-fill pass of its own, one barrier)
     for (int e = tid; e < 4 * QP * lda; e += FT) A0[e] = 0.0;   // A0, A1, V0, V1: zero padding
     if (tid < 16) { cl[tid] = cpre; vl[tid] = 0.0; }
@@ -242,10 +246,8 @@ __global__ __launch_bounds__(FT) void k_lv_solve(lvs_args g)
     }
     if (tid < a * QP) Zl[tid] = zpre;
     for (int e = tid + FT; e < a * QP; e += FT) Zl[e] = g.s.Z[e];
-    JCH_SSTAMP(13);
     __syncthreads();
-    // the loads the tail needs go out only NOW: a barrier waits for every outstanding load of the wave, and the 128 KB of R rows
-    // in front of the barrier above kept the eigenvector waiting for them (they arrive during the eigenvector window instead)
+    // the loads the tail needs go out only NOW: a barrier waits for every outstanding load of the wave
     double rreg[32];   // R[i][tid], i < min(an, 32)   (tail)
 #pragma unroll
     for (int i = 0; i < 32; ++i) rreg[i] = (i < an && tid < p) ? g.s.R[(size_t)i * p + tid] : 0.0;

@@ -170,7 +170,7 @@ def test_plsrda_with_70_classes(J, ctx):
 def test_sibling_nlv_beyond_256_outside_the_lds_envelope(alg, J, ctx):
     """plssimp / plswold with nlv > 256 where their LDS-resident kernels do not apply (here p > 2048): the generic small-state
     kernel keeps its per-LV dot products in global memory.  Leading LVs against the oracle; for plswold (X deflated: the scores
-    stay D-orthogonal) the invariant on all 260 columns.  (SIMPLS itself loses orthogonality once X'Y is exhausted — the oracle's
+    stay D-orthogonal) the invariant on the first 100 columns.  (SIMPLS itself loses orthogonality once X'Y is exhausted — the oracle's
     own scores are at 5e-5 by LV 50 and O(1) by LV 100 on this data — so there is no such invariant to assert for it.)"""
     n, p, q, nlv = 300, 2100, 2, 260
     X = O.rand_matrix(91, n, p)
@@ -184,10 +184,10 @@ def test_sibling_nlv_beyond_256_outside_the_lds_envelope(alg, J, ctx):
     # implementation —, so the per-LV quantities T, P, W, C are compared)
     for f in (("T", "P", "R", "C") if alg == "simp" else ("T", "P", "W", "C")):
         assert O.rel_fro(getattr(ref, f)[:, :20], getattr(fm, f)[:, :20] * s) < TOL, f
-    if alg == "wold":
+    if alg == "wold":   # (beyond ~LV 100 the Y residual of this data is rounding noise and NIPALS degenerates — in the oracle as well: 2e-3 by LV 150)
         d = fm.weights
-        G = (fm.T * d[:, None]).T @ fm.T
-        assert np.abs(G - np.diag(np.diag(G))).max() < 1e-8 * np.abs(np.diag(G)).max()
+        G = (fm.T[:, :100] * d[:, None]).T @ fm.T[:, :100]
+        assert np.abs(G - np.diag(np.diag(G))).max() < 1e-10 * np.abs(np.diag(G)).max()
 
 
 def test_vip_and_plslda_beyond_64_columns(J, ctx):

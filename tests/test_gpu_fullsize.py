@@ -176,7 +176,7 @@ def test_cfg3_bf16_one_rank_share_full_lvs(J, tctx):
     errs = {f: O.rel_fro(getattr(ref, f), (T if f == "T" else getattr(fm, f)) * s) for f in FIELDS}
     errs["B"] = O.rel_fro(ref.R @ ref.C.T, fm.R @ fm.C.T)
     print("cfg3 share (n = 1e6, bf16) vs f64 oracle on rounded inputs:", {k: f"{v:.1e}" for k, v in errs.items()})
-    assert O.rel_fro(ref.xmeans, fm.xmeans) < 1e-12                    # fp64 statistics from the exact bf16 values
+    assert O.rel_fro(ref.xmeans, fm.xmeans) < 1e-7                     # unit weights: column sums from the bf16 matrix pipe's f32 block sums (round 4)
     assert max(errs[f] for f in FIELDS) < 1e-3, errs
     assert errs["B"] < 1e-4, errs
 
@@ -207,7 +207,7 @@ def test_cfg3_bf16_whole_config_on_one_gpu(J, tctx):
     e64 = {f: O.rel_fro(getattr(f64, f) if f != "T" else f64.T.cpu().numpy(), (T.cpu().numpy() if f == "T" else getattr(fm, f)) * s) for f in ("P", "C", "W", "R")}
     e64["T"] = float(torch.linalg.norm(f64.T - T * torch.from_numpy(s).cuda()) / torch.linalg.norm(f64.T))
     e64["B"] = O.rel_fro(f64.R @ f64.C.T, fm.R @ fm.C.T)
-    assert O.rel_fro(f64.xmeans, fm.xmeans) < 1e-12
+    assert O.rel_fro(f64.xmeans, fm.xmeans) < 1e-7
     assert max(e64[f] for f in FIELDS) < 1e-3, e64
     assert e64["B"] < 1e-4, e64
     # ---- the C oracle at full n on the same rounded values, leading LVs

@@ -215,7 +215,9 @@ def test_bf16_storage_mode(shape, J):
     s = O.sign_align(ref.W, fm.W)
     errs = {f: O.rel_fro(getattr(ref, f), (T if f == "T" else getattr(fm, f)) * s) for f in ("T", "P", "C", "W", "R")}
     errs["B"] = O.rel_fro(ref.R @ ref.C.T, fm.R @ fm.C.T)
-    assert O.rel_fro(ref.xmeans, fm.xmeans) < 1e-12 and O.rel_fro(ref.xscales, fm.xscales) < 1e-12   # fp64 from exact bf16 values
+    # fp64 statistics from the exact bf16 values; unit weights without scaling (round 4): the column sums come out of the bf16 matrix
+    # pipe's f32 block sums (k_xty_bf16_panel_m32) — 1e-9 relative, five orders below the mode's budget
+    assert O.rel_fro(ref.xmeans, fm.xmeans) < (1e-12 if scal else 1e-7) and O.rel_fro(ref.xscales, fm.xscales) < 1e-12
     assert max(errs[f] for f in ("T", "P", "C", "W", "R")) < 1e-3, errs
     assert errs["B"] < 1e-4, errs
     with pytest.raises(J.JchError):
@@ -1192,8 +1194,9 @@ def test_bf16_row_panel_prologue_matches_tile_kernel(shape, nh, J):
     Yb = J.colmajor_empty(ld, q, dtype=torch.bfloat16)[:n]; Yb.copy_(torch.from_numpy(Y))
     w = 0.25 + O.splitmix64_uniform(7, 0, n) if scal else None
     tctx = J.Context(0, stream="torch")
-    keep = {k_: os.environ.get(k_) for k_ in ("JCH_BF16_K2_PANEL", "JCH_BF16_K2_NH")}
+    keep = {k_: os.environ.get(k_) for k_ in ("JCH_BF16_K2_PANEL", "JCH_BF16_K2_NH", "JCH_BF16_K2_M32")}
     try:
+        os.environ["JCH_BF16_K2_M32"] = "0"      # (the f64 products of this kernel; the bf16-pipe variant has its own test below)
         os.environ["JCH_BF16_K2_PANEL"] = "0"
         old = J.plskern(Xb, Yb, w, nlv=nlv, scal=scal, ctx=tctx)
         os.environ["JCH_BF16_K2_PANEL"] = "1"; os.environ["JCH_BF16_K2_NH"] = str(nh)
@@ -1217,6 +1220,44 @@ def test_bf16_row_panel_prologue_matches_tile_kernel(shape, nh, J):
     for f in ("P", "C", "W", "R"):
         assert O.rel_fro(getattr(ref, f), getattr(new, f) * s) < 1e-3, f
     assert O.rel_fro(ref.T, new.T.cpu().numpy() * s) < 1e-3
+    tctx.close()
+
+
+@pytest.mark.parametrize("shape", [(4096, 500, 10, 8), (5003, 130, 3, 6), (640, 64, 1, 4), (3000, 700, 15, 5), (64, 40, 2, 3)])
+@pytest.mark.parametrize("data", ["uniform", "signal", "magnitudes"])
+def test_bf16_prologue_on_the_bf16_matrix_pipe(shape, data, J, monkeypatch):
+    """Round 4: unit weights, no scaling — X'[Y | 1] of the bf16 prologue on v_mfma_f32_16x16x32_bf16 (k_xty_bf16_panel_m32: the raw
+    bf16 values are the operands, every product exact in f32, 32-term block sums in f32, f64 across blocks, centring afterwards on
+    the p x q sums) against the f64-product kernel (JCH_BF16_K2_M32=0) and the oracle on the rounded inputs, inside the mode's
+    budget (1e-3 on T / P / C / W, 1e-4 on predictions).  `magnitudes`: columns spanning 2^-20 ... 2^20 (the adversarial case for an
+    f32 block sum followed by a centring subtraction); ragged tails, one piece, two column groups, q = 15 (ones column = the last pad)."""
+    import torch
+    n, p, q, nlv = shape
+    ld = (n + 7) // 8 * 8
+    X = CO.fill_uniform(20250112, n, p); Y = CO.fill_uniform(20250113, n, q)
+    if data == "signal":
+        Y = X[:, :q] * 0.7 + 0.3 * Y
+    if data == "magnitudes":
+        X = X * np.exp2(np.round(np.linspace(-20, 20, p)))[None, :]
+        Y = (X[:, :q] / np.exp2(np.round(np.linspace(-20, 20, p)))[None, :q] + 0.2 * Y) * np.exp2(np.round(np.linspace(-10, 10, q)))[None, :]
+    Xb = J.colmajor_empty(ld, p, dtype=torch.bfloat16)[:n]; Xb.copy_(torch.from_numpy(X))
+    Yb = J.colmajor_empty(ld, q, dtype=torch.bfloat16)[:n]; Yb.copy_(torch.from_numpy(Y))
+    tctx = J.Context(0, stream="torch")
+    new = J.plskern(Xb, Yb, nlv=nlv, ctx=tctx)
+    monkeypatch.setenv("JCH_BF16_K2_M32", "0")
+    old = J.plskern(Xb, Yb, nlv=nlv, ctx=tctx)
+    assert O.rel_fro(old.xmeans, new.xmeans) < 1e-6 and O.rel_fro(old.ymeans, new.ymeans) < 1e-12
+    s = O.sign_align(old.W, new.W)
+    assert O.rel_fro(old.W[:, 0], new.W[:, 0] * s[0]) < 2e-5                     # w_1 is a function of X'DY alone: the f32 block sums
+    Xr, Yr = Xb.to(torch.float64).cpu().numpy(), Yb.to(torch.float64).cpu().numpy()
+    ref = CO.plskern(Xr, Yr, None, nlv=nlv, scal=False)
+    s = O.sign_align(ref.W, new.W)
+    assert O.rel_fro(ref.xmeans, new.xmeans) < 1e-6
+    for f in ("P", "C", "W", "R"):
+        assert O.rel_fro(getattr(ref, f), getattr(new, f) * s) < 1e-3, f
+    assert O.rel_fro(ref.T, new.T.cpu().numpy() * s) < 1e-3
+    Xq = Xb[: min(n, 200)]
+    assert O.rel_fro(O.predict(ref, Xr[: min(n, 200)], nlv=nlv), J.predict(new, Xq, nlv=nlv, ctx=tctx).cpu().numpy()) < 1e-4
     tctx.close()
 
 
