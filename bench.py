@@ -46,12 +46,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 T
 README_PLSKERN_LVS = 25 / 8.100469   # README.md:90-91: plskern n=1e6 p=500 q=10 nlv=25 in 8.10 s (i9-10885H)
 
 
-PMC_FILE = "profiles/r03_pmc_sweep.json"
+PMC_FILE = "profiles/r04_pmc_traffic.json"
 
 
 def pmc_traffic(algo, n_local, p):
-    """HBM bytes per sweep launch from the COMMITTED PMC pass (profiles/r03_pmc_sweep.json: FETCH_SIZE x2 gfx950 correction
-    + WRITE_SIZE, separate rocprofv3 passes, tools/final_profiles_r03.sh), scaled by rows when this rank holds a different
+    """HBM bytes per sweep launch from the COMMITTED PMC pass (profiles/r04_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction
+    + WRITE_SIZE, separate rocprofv3 passes, tools/final_pmc_r04.sh), scaled by rows when this rank holds a different
     share.  Not measured in the bench run itself (counters need the profiler); None for shapes without a committed pass."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
@@ -59,6 +59,20 @@ def pmc_traffic(algo, n_local, p):
         w = pm["workload"]
         if algo == w["algo"] and p == w["p"]:
             return pm["hbm_bytes_per_launch"] * (n_local / w["n"])
+    except Exception:
+        pass
+    return None
+
+
+def pmc_config_traffic(key, **shape):
+    """HBM bytes per `launch` (in the unit of that configuration's roofline block) of one of the OTHER bench configurations, from
+    the same committed PMC file (`configs`: cfg4_plsnipals per LV, bf16_share per sweep launch, cfg5_lwplsr per call of 1000
+    queries); None when the shape differs from the one the counters were collected at."""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            c = json.load(f)["configs"][key]
+        if all(c.get(k_) == v_ for k_, v_ in shape.items()):
+            return c["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None
@@ -169,9 +183,12 @@ def secondary_fit(J, _lib, lib, ctx, dev, *, label, algo, n, p, q, nlv, bf16, st
     assert np.all(np.isfinite(TT[:k])) and np.all(TT[:k] > 0), "secondary fit produced non-finite / non-positive t't"
     kernel = ("k_sweep_lazy + k_kpass_lazy (per LV: two reads of X, rows rewritten every 6th LV; bytes_per_launch = bytes actually moved per LV)"
               if algo == "plsnipals" else "k_sweep_bf16_v2 (fused sweep over the bf16 row-major copy)" if bf16 else "k_sweep")
+    roof = _roof(sb, sw, nl, kernel)
+    roof["traffic"] = pmc_config_traffic("bf16_share", n=n, p=p) if bf16 else (pmc_config_traffic("cfg4_plsnipals", n=n, p=p) if algo == "plsnipals" else None)
+    roof["traffic_source"] = PMC_FILE + ": committed rocprofv3 --pmc passes of this configuration's kernels (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); NOT measured in this run"
     out = {"config": label, "metric": "latent-variables/sec", "value": k * steps / dt, "unit": "LV/s", "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "dtype": "bf16 storage / f32 rows / f64 state" if bf16 else "f64",
-           "roofline": _roof(sb, sw, nl, kernel),
+           "roofline": roof,
            "device_ms_per_step": {"fit": fit / steps, "prologue": pro / steps, "dominant_kernels": sw / steps,
                                   "small_state_and_gaps": (fit - pro - sw) / steps}}
     del X, Y, T, wn
@@ -224,6 +241,8 @@ def secondary_lwplsr(J, lib, ctx, dev, calls):
                              note="algorithmic bytes = the gathered neighbour rows m k p 8 (SURVEY §8d: the path is latency / occupancy bound, "
                                   "the HBM fraction is reported for completeness; profiles/ holds the counted traffic)"),
            "device_ms_per_step": {k_: v / calls for k_, v in dev_ms.items()}}
+    out["roofline"]["traffic"] = pmc_config_traffic("cfg5_lwplsr", m=m, k=k, p=p)
+    out["roofline"]["traffic_source"] = PMC_FILE + ": committed rocprofv3 --pmc passes of k_locw_kspace at this shape; NOT measured in this run"
     # the local fits are a matrix-pipe + vector kernel since round 3 (k_locw_kspace: the k x k Gram matrix of the gathered rows on
     # v_mfma_f64_16x16x4, then the LVs on it): its second bound, against the 78.6 TFLOP/s of the f64 matrix pipe
     lf_s = dev_ms["local_fits"] / calls * 1e-3
@@ -252,6 +271,7 @@ def main():
     ap.add_argument("--algo", choices=["plskern", "plsnipals", "plskern2", "plssimp", "plsrosa", "plswold"], default="plskern",
                     help="plskern2 = opt-in kernel algorithm #2 (Gram once; not the reference's algorithm, never the headline)")
     ap.add_argument("--dtype", choices=["f64", "bf16"], default="f64", help="bf16 = storage mode of BASELINE configs[2]")
+    ap.add_argument("--one-pass", action="store_true", help="plsnipals / plswold: the OPT-IN one-pass variant (JCH_NIPALS_ONE_PASS; never the default)")
     ap.add_argument("--scal", action="store_true", help="scale the columns by their stds (scal = true; not the headline configuration)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the CPU baseline run (0 = all n: no extrapolation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -357,7 +377,7 @@ def main():
     Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
     xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
     desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=int(args.scal), dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0,
-                        reserved=1 if args.algo == "plskern2" else 0)
+                        reserved=1 if args.algo == "plskern2" else (4 if (args.one_pass and args.algo in ("plsnipals", "plswold")) else 0))
     got = C.c_int32(0)
     entry = {"plsnipals": lib.jch_plsnipals_fit, "plssimp": lib.jch_plssimp_fit, "plsrosa": lib.jch_plsrosa_fit}.get(args.algo, lib.jch_plskern_fit)
     niter = np.zeros(kmax)
@@ -522,7 +542,7 @@ def main():
             "vs_baseline_source": "README.md:90-91 of the reference: plskern 8.10 s on an i9-10885H laptop = 3.09 LV/s (BASELINE.md §1, context only; the 10x target is vs_cpu_baseline)",
             "vs_baseline": value / README_PLSKERN_LVS if (args.algo == "plskern" and not bf16 and not args.scal and (n_total, p, q, nlv) == (1_000_000, 500, 10, 25)) else None,
             "dtype": "bf16 storage / f32 rows / f64 state" if bf16 else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.algo} n={n_total} p={p} q={q} nlv={nlv} {'bf16-stored' if bf16 else 'Float64'} "
+            "config": {"workload": f"{args.algo}{' (OPT-IN one-pass variant, not the reference algorithm)' if (args.one_pass and args.algo in ('plsnipals', 'plswold')) else ''} n={n_total} p={p} q={q} nlv={nlv} {'bf16-stored' if bf16 else 'Float64'} "
                                    f"({'BASELINE.json configs[1]' if (args.algo, n_total, p, q, nlv, bf16) == ('plskern', 1000000, 500, 10, 25, False) else 'variant'}), "
                                    f"X/Y device-resident column-major, rows sharded over {world} GPU(s)",
                        "n": n_total, "p": p, "q": q, "nlv": k, "rows_per_gpu": n, "timed": "prologue + LV loop, device-resident",

@@ -51,7 +51,9 @@ extern "C" {
 
 /* storage type of X / Y handed to a fit */
 #define JCH_F64 0
-#define JCH_BF16 1 /* bf16 storage, fp32 row arithmetic, fp64 small state (BASELINE config 3); device-resident only */
+#define JCH_BF16 1 /* bf16 storage (BASELINE config 3); device-resident only.  jch_plskern_fit (p <= 2048): bf16-resident kernels, fp32 row
+                      arithmetic, fp64 small state; every other fit: the inputs are widened exactly to Float64 on the device and the
+                      Float64 path runs (same contract — the Float64 algorithm on the bf16-rounded inputs —, no bandwidth saving) */
 
 typedef struct jch_ctx jch_ctx; /* opaque: device, stream, RCCL communicator, workspace pool */
 
@@ -109,12 +111,20 @@ typedef struct jch_pls_desc {
     int32_t reserved; /* option bits.  0 = the reference's algorithm (improved kernel #1, one sweep over X per LV);
                          bit 0 (1) = OPT-IN kernel algorithm #2 (X'DX once, no pass over X and no collective in the LV
                          loop; plskern, q <= 16, p <= 2048): same results up to rounding;
-                         JCH_WOLD_REF_ZERO_WEIGHT_NAN (jch_plswold_fit only): see below */
+                         JCH_WOLD_REF_ZERO_WEIGHT_NAN (jch_plswold_fit only): see below;
+                         JCH_NIPALS_ONE_PASS (jch_plsnipals_fit / jch_plswold_fit): see below */
 } jch_pls_desc;
 /* jch_plswold_fit: give the rows with weight 0 NaN scores, as the reference does (src/plswold.jl:107 divides by sqrt(w) = 0).
  * Default (bit clear): finite scores t_i = x_i' r for those rows — what a cross-validation fold with zero weights on its
  * held-out rows needs (gridcvlv). */
 #define JCH_WOLD_REF_ZERO_WEIGHT_NAN 2
+/* jch_plsnipals_fit / jch_plswold_fit, OPT-IN (never the default: it is not what the reference computes, src/plsnipals.jl:71 recomputes
+ * X'DY from the deflated matrices every LV): ONE pass over X per LV.  The next kernel matrix follows from the exact identity
+ * K_{a+1} = (X - t p')'D(Y - t c') = K_a - zp_raw c_raw' / tt (t is D-orthogonal to its own residuals), c_raw = Y'Dt is taken
+ * against the UNdeflated Y (equal for the same reason), and the second read of X per LV disappears; the deflated rows are still
+ * written back every few LVs (the postponed write-back needs q <= 16, p <= 2048, inplace = 0, Float64: JCH_EINVAL otherwise).
+ * Same results up to rounding (gate of the tests: 1e-9 against the default path on well-conditioned LVs). */
+#define JCH_NIPALS_ONE_PASS 4
 
 /*
  * jch_plskern_fit — replaces `plskern!` / `plskern` (src/plskern.jl:106-178): weight normalisation
@@ -333,6 +343,10 @@ JCH_API int32_t jch_ctx_allreduce_probe(jch_ctx *ctx, int32_t transport, double 
  * ("raw") prologue was repeated on the centred working copy because the sampled pivot turned out to be further than 64
  * sample standard deviations from a column mean (results are those of the centred formulation). */
 #define JCH_COUNTER_PIVOT_REFITS 0
+/* which = JCH_COUNTER_LOCW_REFITS: queries of jch_lwplsr_predict* that the neighbour-space local-fit kernel flagged as lying more
+ * than 64 local standard deviations (along the offset) from the mean of their neighbours — possible because the neighbours are
+ * chosen in the score space, not in p-space — and that were refitted by the per-query path (explicit centring). */
+#define JCH_COUNTER_LOCW_REFITS 1
 JCH_API int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_t *out);
 
 #ifdef __cplusplus

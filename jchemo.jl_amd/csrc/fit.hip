@@ -26,6 +26,16 @@ __global__ __launch_bounds__(256) void k_nan_zero_weight_rows(double *__restrict
         for (int a = 0; a < nlv; ++a) T[(size_t)i + (size_t)a * (size_t)n] = __builtin_nan("");
 }
 
+// bf16 -> f64, column by column (the values are exact): the inputs of a fit that has no bf16-resident kernels of its own
+__global__ __launch_bounds__(256) void k_widen_bf16(const unsigned short *__restrict__ src, int64_t ld, int64_t n, int64_t cols, double *__restrict__ dst)
+{
+    const int64_t tot = n * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (int64_t)gridDim.x * 256) {
+        const int64_t j = e / n, i = e - j * n;
+        dst[e] = (double)__uint_as_float(((unsigned)src[(size_t)i + (size_t)j * (size_t)ld]) << 16);
+    }
+}
+
 namespace {
 
 struct fit_io {
@@ -47,8 +57,6 @@ int32_t validate(jch_ctx *ctx, const fit_io &io, const char *who)
     if (d->n < 1 || d->p < 1 || d->q < 1) return jch_fail(ctx, JCH_EINVAL, "%s: empty input (n=%lld p=%lld q=%lld)", who,
                                                          (long long)d->n, (long long)d->p, (long long)d->q);
     if (d->q > (1 << 12)) return jch_fail(ctx, JCH_EINVAL, "%s: q=%lld too large", who, (long long)d->q);
-    if (d->p > JCH_SWEEP_MAXP && d->dtype != JCH_F64)
-        return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld > %d is supported for Float64 only", who, (long long)d->p, JCH_SWEEP_MAXP);
     if (d->p > (1 << 20)) return jch_fail(ctx, JCH_EINVAL, "%s: p=%lld too large", who, (long long)d->p);
     if (d->nlv < 1) return jch_fail(ctx, JCH_EINVAL, "%s: nlv=%d must be >= 1", who, d->nlv);
     if (d->dtype != JCH_F64 && d->dtype != JCH_BF16) return jch_fail(ctx, JCH_EINVAL, "%s: unknown dtype %d", who, d->dtype);
@@ -184,6 +192,25 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     if (!ctx) return JCH_EINVAL;
     JCH_TRY(validate(ctx, io, who));
     JCH_HIP(ctx, hipSetDevice(ctx->device));
+    if (io.d->dtype == JCH_BF16 && (algo != ALGO_KERN || io.d->p > JCH_SWEEP_MAXP)) {
+        // bf16-stored inputs WITHOUT bf16-resident kernels (every fit but plskern; plskern with p > 2048; round 4): the contract of the
+        // mode is "the Float64 algorithm on the bf16-rounded inputs" (bf16.hip), so the inputs are widened once — exactly — into
+        // Float64 device buffers and the Float64 path runs on them.  No bandwidth saving there, but no refusal either.
+        const jch_pls_desc &db = *io.d;
+        JCH_HIP(ctx, hipSetDevice(ctx->device));
+        JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * (size_t)db.n * db.p));
+        JCH_TRY(jch_reserve(ctx, ctx->ystage, sizeof(double) * (size_t)db.n * db.q));
+        const unsigned nbw = (unsigned)std::min<int64_t>(((int64_t)db.n * db.p + 255) / 256, (int64_t)ctx->cus * 16);
+        hipLaunchKernelGGL(k_widen_bf16, dim3(nbw), dim3(256), 0, ctx->stream, (const unsigned short *)io.X, io.ldx, db.n, db.p, (double *)ctx->xstage.ptr);
+        hipLaunchKernelGGL(k_widen_bf16, dim3(std::max(1u, std::min(nbw, (unsigned)(((int64_t)db.n * db.q + 255) / 256)))), dim3(256), 0, ctx->stream,
+                           (const unsigned short *)io.Y, io.ldy, db.n, db.q, (double *)ctx->ystage.ptr);
+        JCH_HIP(ctx, hipGetLastError());
+        jch_pls_desc dw = db;
+        dw.dtype = JCH_F64;
+        fit_io io2 = io;
+        io2.d = &dw; io2.X = ctx->xstage.ptr; io2.ldx = db.n; io2.Y = ctx->ystage.ptr; io2.ldy = db.n;
+        return fit_impl(ctx, io2, algo, allow_raw);
+    }
     const jch_pls_desc &d = *io.d;
     const int64_t n = d.n;
     const int p = (int)d.p, q = (int)d.q;
@@ -286,9 +313,15 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         if (defer_m > 1) pend_p = cv.take((size_t)defer_m * jch_nipals_lazy_pitch(ldr));
     }
 
+    // OPT-IN one-pass NIPALS (JCH_NIPALS_ONE_PASS): the next X'DY by a rank-one update in the small-state kernel, rows written back
+    // every defer_m-th LV by a pass that computes nothing else
+    const bool onepass = (d.reserved & JCH_NIPALS_ONE_PASS) != 0 && (algo == ALGO_NIPALS || algo == ALGO_WOLD);
+    double *zero16 = nullptr;
+    if ((d.reserved & JCH_NIPALS_ONE_PASS) && !(onepass && pend_p && !inplace))
+        return jch_fail(ctx, JCH_EINVAL, "%s: JCH_NIPALS_ONE_PASS needs plsnipals / plswold with q <= 16, p <= 2048, inplace = 0, Float64", who);
+    if (onepass) { zero16 = cv.take(16); JCH_HIP(ctx, hipMemsetAsync(zero16, 0, sizeof(double) * 16, ctx->stream)); s.variant = 3; }
     if (s.dbg) JCH_HIP(ctx, hipMemsetAsync(s.dbg, 0, sizeof(double) * (512 + 16 * (nlv_cap + 2)), ctx->stream));
     if (d.dtype == JCH_BF16) {   // bf16 storage mode (plskern only): its own prologue + sweep, same small-state kernels
-        if (algo != ALGO_KERN) return jch_fail(ctx, JCH_EINVAL, "%s: bf16 storage is implemented for plskern only", who);
         const bool fastb = q <= 16 && p <= JCH_SWEEP_MAXP && jch_lv_fast_lds_bytes(p, q, qpad, ldr, nlv_cap) <= 150 * 1024 && !getenv("JCH_SMALLSTATE_GENERIC");
         {   // split small-state path (see the f64 loop below); the fused inbox exchange keeps the one-kernel path
             const char *e_sp = getenv("JCH_LV_SPLIT");
@@ -470,6 +503,18 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             const bool last = a + 1 == nlv;
             if (!last || inplace) {
                 // X -= t zp', Y -= t c' fused with the next K = X'DY (src/plsnipals.jl:86-87,71; src/plswold.jl:98-99)
+                if (pend_p && onepass) {   // K_{a+1} is already in place (phase A); only the write-back of the rows, every defer_m-th LV
+                    if (npend == 0) pend_a0 = a;
+                    JCH_HIP(ctx, hipMemcpyAsync(pend_p + (size_t)npend * jch_nipals_lazy_pitch(ldr), s.zpc, sizeof(double) * (size_t)ldr,
+                                                hipMemcpyDeviceToDevice, ctx->stream));
+                    ++npend;
+                    if (npend == defer_m && !last) {
+                        JCH_TRY(jch_launch_kpass_lazy(ctx, Xr, n, p, ldr, Yr, qpad, q, dn, pend_p, npend, defer_m,
+                                                      Tdev + (size_t)pend_a0 * (size_t)n, n, zero16, true, nullptr));
+                        npend = 0; ++x_writes; ++x_reads;
+                    }
+                    --x_reads;   // (balanced by the unconditional ++x_reads below: this LV made no second pass)
+                } else
                 if (pend_p) {
                     if (npend == 0) pend_a0 = a;
                     JCH_HIP(ctx, hipMemcpyAsync(pend_p + (size_t)npend * jch_nipals_lazy_pitch(ldr), s.zpc, sizeof(double) * (size_t)ldr,

@@ -308,6 +308,70 @@ __global__ __launch_bounds__(64 * NW) void k_affine_gemm32p(const double *__rest
     }
 }
 
+// SHORT rows, WIDE output (round 4): the second stage of `predict` over an nlv range (m x nlv scores -> m x q (nlv + 1) predictions,
+// 25 -> 260 columns at cfg2) and of `xfit` (scores -> m x p).  The general kernel re-read its input once per 128 output columns and
+// wrote 64-row pieces; here a wave keeps its 64 input rows (p <= 64 columns: <= 16 k-steps) in registers, walks ALL output column
+// tiles against the coefficient matrix in LDS and writes 512-B runs per output column.  The pass is bound by its OUTPUT (2.08 GB at
+// cfg2 against 0.2 GB read).
+template <int KS, int RT>   // KS k-steps of 4 input columns held in registers (p <= 4 KS); RT row tiles of 32 per wave-tile
+__global__ __launch_bounds__(256) void k_affine_gemm_wideout(const double *__restrict__ Xc, int64_t m, int p, int64_t ldx,
+                                                           const double *__restrict__ Bs, int kpad, const double *__restrict__ bias,
+                                                           int k, double *__restrict__ out, int64_t ldo)
+{
+    extern __shared__ __attribute__((aligned(16))) double blw[];   // [4 KS][kpad + 1], zero rows beyond p
+    const int PB = kpad + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < 4 * KS * kpad; e += 256) {
+        const int jj = e / kpad, cc = e - jj * kpad;
+        blw[jj * PB + cc] = jj < p ? Bs[(size_t)jj * kpad + cc] : 0.0;
+    }
+    __syncthreads();
+    const int kq = lane >> 4, cl = lane & 15;
+    constexpr int TR = 32 * RT;
+    const int64_t ntile = (m + TR - 1) / TR, tstep = (int64_t)gridDim.x * 4;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntile; tile += tstep) {
+        v2f64 x[KS][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            int64_t ir = tile * TR + 32 * rt + 2 * cl;
+            if (ir > m - 2) ir = m - 2;                         // (m even: re-read the last pair, the stores are guarded)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int j = min(4 * ks + kq, p - 1);          // (columns past p meet zero coefficients)
+                x[ks][rt] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(Xc + ir + (size_t)j * (size_t)ldx));
+            }
+        }
+        const int64_t i0 = tile * TR;
+        for (int ct = 0; ct < kpad / 16; ++ct) {
+            v4f64 acc[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { acc[rt][0] = v4f64{0.0, 0.0, 0.0, 0.0}; acc[rt][1] = v4f64{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const double b = blw[(4 * ks + kq) * PB + 16 * ct + cl];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks][rt].x, b, acc[rt][0], 0, 0, 0);
+                    acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks][rt].y, b, acc[rt][1], 0, 0, 0);
+                }
+            }
+            const int col = 16 * ct + cl;
+            if (col < k) {
+                const double bv = bias[col];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int par = 0; par < 2; ++par)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int64_t i = i0 + 32 * rt + 2 * (kq + 4 * reg) + par;
+                            if (i < m) out[(size_t)i + (size_t)col * (size_t)ldo] = acc[rt][par][reg] + bv;   // (plain stores: L2 merges the 8-B pieces of a line; non-temporal ones were 2x slower)
+                        }
+            }
+        }
+    }
+}
+
 int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p, int64_t ldx, const double *Bs, int k, int kpad,
                                const double *bias, double *out, int64_t ldo)
 {
@@ -354,6 +418,28 @@ int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p,
                            k, out, ldo);
         JCH_HIP(ctx, hipGetLastError());
         return JCH_OK;
+    }
+    {   // short rows, wide output (JCH_GEMM_WIDEOUT=0: the general kernel; JCH_GEMM_WIDEOUT_RT=2: 64-row wave tiles).  predict over
+        // nlv = 0..25 at cfg2 (1e6 x 25 scores -> 260 columns), whole call: general kernel 1.93 ms, this kernel with plain stores
+        // 1.77 (64-row tiles); with NON-TEMPORAL stores 4.14 — the 8-B pieces of an output line come from eight store instructions
+        // and must meet in L2.
+        const char *ew = getenv("JCH_GEMM_WIDEOUT"), *er = getenv("JCH_GEMM_WIDEOUT_RT");
+        const int ks = (p + 3) / 4;
+        const int rtw = (er && atoi(er) == 2) ? 2 : 4;
+        const size_t ldsw = sizeof(double) * (size_t)(4 * (ks <= 4 ? 4 : ks <= 8 ? 8 : 16)) * (kpad + 1);
+        if (!(ew && atoi(ew) == 0) && p <= 64 && kpad > 32 && ldsw <= 150 * 1024 && m >= 4096 && m % 2 == 0 && ldx % 2 == 0 && (((uintptr_t)Xc) & 15) == 0) {
+            const unsigned nb = (unsigned)std::min<int64_t>((m + 32 * rtw * 4 - 1) / (32 * rtw * 4), (int64_t)ctx->cus * 2);
+#define JCH_GW(KS, RT) do { \
+                static jch_per_device_once once_; \
+                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm_wideout<KS, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
+                hipLaunchKernelGGL((k_affine_gemm_wideout<KS, RT>), dim3(nb), dim3(256), ldsw, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo); } while (0)
+            if (ks <= 4) { if (rtw == 2) JCH_GW(4, 2); else JCH_GW(4, 4); }
+            else if (ks <= 8) { if (rtw == 2) JCH_GW(8, 2); else JCH_GW(8, 4); }
+            else JCH_GW(16, 2);
+#undef JCH_GW
+            JCH_HIP(ctx, hipGetLastError());
+            return JCH_OK;
+        }
     }
     dim3 grid((unsigned)((m + 63) / 64), (unsigned)((kpad + 127) / 128));
     hipLaunchKernelGGL(k_affine_gemm, grid, dim3(256), 0, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo);

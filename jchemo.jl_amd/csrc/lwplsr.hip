@@ -902,6 +902,8 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     int *dind = (int *)(dpred + (size_t)m * le * q);
     hipEvent_t ev1 = jch_ev(ctx), ev2 = nullptr, ev3 = nullptr;   // profiling: (copy) | kNN + weights | local fits
     bool generic_fits = false;
+    int *kflags = nullptr;          // k-space kernel: per-query pivot flags (device)
+    locw_args kargs{};
     {
         knn_args a;
         a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
@@ -957,7 +959,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         locw_args g;
         g.Xrm = Xrm; g.ldr = ldr; g.p = (int)p; g.Y = dY; g.ldy = ldyd; g.q = (int)q; g.Xq = dXq; g.ldxq = ldxqd; g.m = (int)m;
         g.ind = dind; g.w = dw; g.k = k; g.scal = scal; g.nlv_lo = nlv_lo; g.nlv_hi = nlv_hi; g.pred = dpred;
-        g.scratch = nullptr; g.slab = 0;
+        g.scratch = nullptr; g.slab = 0; g.flags = nullptr;
         { const char *e = getenv("JCH_LOCW_DBG"); g.dbg = e ? atoi(e) : 0; }
         // neighbour-space kernel (lwplsr_kspace.hip: the gathered rows are read ONCE, the fit runs on their Gram matrix held in
         // registers) when the shape fits it; the p-space kernel (one sweep of the slab per LV) otherwise
@@ -968,8 +970,14 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
             JCH_TRY(jch_lw_generic_fits(ctx, g, n));
             generic_fits = true;
         } else
-        if (jch_locw_kspace_supported(g)) JCH_TRY(jch_launch_locw_kspace(ctx, g));
-        else
+        if (jch_locw_kspace_supported(g)) {
+            // pivot check of the neighbour-space kernel: queries far from their neighbours in p-space are flagged and refitted below
+            JCH_TRY(jch_reserve(ctx, ctx->lw_flags, sizeof(int) * (size_t)m + 256));
+            g.flags = (int *)ctx->lw_flags.ptr;
+            JCH_HIP(ctx, hipMemsetAsync(g.flags, 0, sizeof(int) * (size_t)m, ctx->stream));
+            JCH_TRY(jch_launch_locw_kspace(ctx, g));
+            kflags = g.flags; kargs = g;
+        } else
         if (ldr <= 128) JCH_TRY(launch_locw<1>(ctx, g));
         else if (ldr <= 256) JCH_TRY(launch_locw<2>(ctx, g));
         else if (ldr <= 512) JCH_TRY(launch_locw<4>(ctx, g));
@@ -977,7 +985,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         else JCH_TRY(launch_locw<16>(ctx, g));
     }
     JCH_HIP(ctx, hipGetLastError());
-    ev3 = generic_fits ? nullptr : jch_ev(ctx);   // (the per-query fits recycle the event pool: no stage times for that path)
+    ev3 = generic_fits ? nullptr : jch_ev(ctx);
     // (the local fits are in the queue: whatever the host does from here on runs beside them)
     hipStream_t cs = side_copies ? ctx->aux_stream : ctx->stream;
     hipError_t ce = hipSuccess;
@@ -986,8 +994,24 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     if (w_out && ce == hipSuccess) ce = hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
     if (side_copies) { const hipError_t se = hipStreamSynchronize(cs); if (ce == hipSuccess) ce = se; }   // (before any return: the buffers are the caller's)
     if (ce != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_predict: copy of the neighbour lists failed: %s", hipGetErrorString(ce)); }
+    std::vector<int> hf;
+    if (kflags) {   // the pivot flags of the neighbour-space kernel travel with the predictions (one sync for both)
+        hf.resize((size_t)m);
+        JCH_HIP(ctx, hipMemcpyAsync(hf.data(), kflags, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    }
     JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
     JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (kflags) {   // flagged queries (the exception): refitted by the per-query path, their predictions fetched again
+        std::vector<int> only;
+        for (int i = 0; i < (int)m; ++i) if (hf[(size_t)i]) only.push_back(i);
+        if (!only.empty()) {
+            ctx->locw_refits += (long long)only.size();
+            JCH_TRY(jch_lw_generic_fits(ctx, kargs, n, only.data(), (int)only.size()));
+            JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
+            JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ev3 = nullptr;   // (the refits recycled the event pool: no stage times for this call)
+        }
+    }
     if (ctx->profiling && ev0 && ev1 && ev2 && ev3) {
         // jch_profile of a prediction call: fit_ms = device time of the three stages, prologue_ms = row-major copy + kNN +
         // weights, sweep_ms = the batched local fits (ONE launch), sweep_bytes = the gathered neighbour rows m k ldr 8

@@ -12,6 +12,8 @@ struct locw_args {
     double *scratch; size_t slab;           // per-block global scratch (p-space kernel: Xg [k][ldr], P [nlv][ldr], R [nlv][ldr]; k-space kernel: [ldr] column stds)
     double *pred;                           // [m][le][q], le = nlv_hi - nlv_lo + 1
     int dbg;                                // measurement switches (JCH_LOCW_DBG; results then wrong by design): 1 = every query gathers rows 0 .. k-1
+    int *flags;                             // [m] or null.  k-space kernel: flags[i] = 1 when query i lies too far from its neighbours for the
+                                            // Gram matrix about the query row (pivot check, lwplsr_kspace.hip): the caller refits those queries
 };
 
 // lwplsr_kspace.hip: _feasible: the k-space kernel can take this shape (k <= 208, q <= 8, nlv <= 48, p <= 2048);
@@ -41,4 +43,4 @@ struct knn_args {
 int32_t jch_launch_knn_generic(jch_ctx *ctx, const knn_args &a);
 // local fits one query at a time: gather the neighbour rows, jch_plskern_fit on them, jch_predict on the query row (the
 // reference's own schedule, src/locwlv.jl:18-39); dpred [m][le][q] device
-int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n);
+int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n, const int *only = nullptr /*host: query indices to fit (null: all)*/, int n_only = 0);

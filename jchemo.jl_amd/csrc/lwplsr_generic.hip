@@ -57,7 +57,7 @@ __global__ __launch_bounds__(KG_NT) void k_knn_generic(knn_args g, kg_scratch sc
     extern __shared__ __attribute__((aligned(16))) double zq[];   // [dd]
     __shared__ int hist[256];
     __shared__ unsigned long long s_prefix, s_mask;
-    __shared__ int s_remaining, s_base_less, s_base_eq;
+    __shared__ int s_remaining;
     __shared__ int wl[KG_NT / 64], we[KG_NT / 64];
     __shared__ double sred[8];
     __shared__ int snn[KG_NT / 64];
@@ -109,8 +109,7 @@ __global__ __launch_bounds__(KG_NT) void k_knn_generic(knn_args g, kg_scratch sc
         const unsigned long long kth = s_prefix;
         const int need_eq = s_remaining, n_less = k - need_eq;   // rows strictly below the k-th key; of the rows AT it, the first need_eq
         // ---- the k selected rows: everything below the k-th key, then the ties in row order
-        if (tid == 0) { s_base_less = 0; s_base_eq = 0; }
-        __syncthreads();
+        int base_less = 0, base_eq = 0;        // running counts, the same in every thread (each adds the four waves' totals itself)
         for (int64_t base = 0; base < n; base += KG_NT) {
             const int64_t i = base + tid;
             const double v = i < n ? d2[i] : 0.0;
@@ -119,17 +118,16 @@ __global__ __launch_bounds__(KG_NT) void k_knn_generic(knn_args g, kg_scratch sc
             const unsigned long long ml = __ballot(isl), me = __ballot(ise);
             if (lane == 0) { wl[wv] = __popcll(ml); we[wv] = __popcll(me); }
             __syncthreads();
-            int ol = s_base_less, oe = s_base_eq;
-            for (int w = 0; w < wv; ++w) { ol += wl[w]; oe += we[w]; }
+            int ol = base_less, oe = base_eq, tl = 0, te = 0;
+            for (int w = 0; w < KG_NT / 64; ++w) {
+                if (w < wv) { ol += wl[w]; oe += we[w]; }
+                tl += wl[w]; te += we[w];
+            }
             const unsigned long long below = (1ull << lane) - 1ull;
             if (isl) { const int pos = ol + __popcll(ml & below); skey[pos] = v; sidx[pos] = (int)i; }
             if (ise) { const int rk = oe + __popcll(me & below); if (rk < need_eq) { skey[n_less + rk] = v; sidx[n_less + rk] = (int)i; } }
-            __syncthreads();
-            if (tid == 0) {
-                int tl = 0, te = 0;
-                for (int w = 0; w < KG_NT / 64; ++w) { tl += wl[w]; te += we[w]; }
-                s_base_less += tl; s_base_eq += te;
-            }
+            base_less += tl; base_eq += te;
+            __syncthreads();                       // (wl / we are rewritten by the next trip)
         }
         for (int e = k + tid; e < K2; e += KG_NT) { skey[e] = __builtin_inf(); sidx[e] = 0x7fffffff; }
         __syncthreads();
@@ -254,7 +252,7 @@ __global__ __launch_bounds__(64) void k_lw_place(const double *__restrict__ src,
     }
 }
 
-int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n)
+int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n, const int *only, int n_only)
 {
     (void)n;
     const int p = g.p, q = g.q, k = g.k, m = g.m, le = g.nlv_hi - g.nlv_lo + 1;
@@ -274,7 +272,9 @@ int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n)
     const bool prof = ctx->profiling;
     ctx->profiling = false;                                  // (the per-query fits would recycle the event pool of the enclosing call)
     int32_t st = JCH_OK;
-    for (int i = 0; i < m && st == JCH_OK; ++i) {
+    const int nloop = only ? n_only : m;
+    for (int ii = 0; ii < nloop && st == JCH_OK; ++ii) {
+        const int i = only ? only[ii] : ii;
         double *dst = g.pred + (size_t)i * le * q;
         if (q == 1 && hflags[2 * (size_t)i] != 0.0) {
             hipLaunchKernelGGL(k_lw_fill, dim3((le * q + 255) / 256), dim3(256), 0, ctx->stream, dst, le * q, hflags[2 * (size_t)i + 1]);

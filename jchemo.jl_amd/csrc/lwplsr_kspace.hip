@@ -598,6 +598,20 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
                 ks_block_sums<1>(t1, red);
                 mm = t1[0];
                 if (tid < KP) gv[tid] = tid < k ? mm - uv[tid] : 0.0;
+                if (g.flags) {
+                    // PIVOT CHECK (round 4).  The Gram matrix is taken about the query row, which is assumed to lie among its
+                    // neighbours; they are chosen in the nlvdis-dimensional score space, so in full p-space an outlying or offset
+                    // query need not.  The centred quantities then come out of G0 by cancellation, with an error that grows like
+                    // (|local mean - query| / spread)^2 eps along the offset direction m = mean - query.  Both are in hand:
+                    // u_i = z_i . m, so |m|^2 = d'u = mm and the weighted variance of the rows along m is (d'(u.u) - mm^2) / mm.
+                    // Above a ratio of 64 (the bound of the f64 fit's own raw mode, fit.hip) the query is flagged and the caller
+                    // refits it with the per-query path, which centres explicitly.
+                    double t2[1] = {tid < KP ? dl[tid] * uv[tid] * uv[tid] : 0.0};
+                    ks_block_sums<1>(t2, red);
+                    const double varm = t2[0] - mm * mm;             // = mm * (variance along m)
+                    const bool bad = !(mm * mm <= 4096.0 * varm);    // ratio^2 = mm / var_m = mm^2 / varm > 64^2 (or not finite)
+                    if (tid == 0 && bad && mm > 0.0) g.flags[qi] = 1;
+                }
 #pragma unroll 1
                 for (int y = q; y < Q; ++y) if (tid < KP) Hm[y * KP + tid] = 0.0;
             }

@@ -206,6 +206,11 @@ __global__ __launch_bounds__(NT) void k_lv_update(lv_args g)
                 g.s.zpc[ldr + k] = c;
                 if (k < q) g.s.C[(size_t)a * q + k] = c;
             }
+            if (g.s.variant == 3)     // OPT-IN one-pass NIPALS (JCH_NIPALS_ONE_PASS): K_{a+1} = K_a - zp_raw c_raw' / tt
+                for (int e = tid; e < p * q; e += NT) {
+                    const int j = e / q, k = e % q;
+                    K[(size_t)j * qpad + k] -= zt[j] * (zt[ldr + 1 + k] / tt);
+                }
         }
         if (tid == 0) g.s.TT[a] = tt;
         __syncthreads();

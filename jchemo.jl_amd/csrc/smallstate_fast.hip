@@ -290,6 +290,12 @@ __global__ __launch_bounds__(FT) void k_lv_update_fast(lvf_args g)
                 g.s.zpc[ldr + tid] = c;
                 if (tid < q) g.s.C[(size_t)a * q + tid] = c;
             }
+            if (g.s.variant == 3) {   // OPT-IN one-pass NIPALS (JCH_NIPALS_ONE_PASS): K_{a+1} = K_a - zp_raw c_raw' / tt
+                for (int e = tid; e < p * 16; e += FT) {
+                    const int j = e >> 4, k = e & 15;
+                    if (k < q) K[e] -= ztl[j] * (ztl[ldr + 1 + k] / tt);
+                }
+            }
         }
         if (tid == 0) g.s.TT[a] = tt;
     }

@@ -208,14 +208,20 @@ def plskern_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[
     return _fit("jch_plskern_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
 
 
-def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
-    """`plsnipals` — src/plsnipals.jl:31-35."""
+NIPALS_ONE_PASS = 4            # include/jchemo_hip.h JCH_NIPALS_ONE_PASS
+
+
+def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, one_pass: bool = False) -> Plsr:
+    """`plsnipals` — src/plsnipals.jl:31-35.
+    `one_pass=True` (not in the reference, never the default) opts into ONE pass over X per LV: the next X'DY follows from the exact
+    identity K_{a+1} = K_a - zp_raw c_raw' / tt instead of being recomputed from the deflated matrices (src/plsnipals.jl:71); same
+    results up to rounding (q <= 16, p <= 2048)."""
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
         _addr_ld(X, allow_bf16=True); _addr_ld(Y, allow_bf16=True)
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
-    return _fit("jch_plsnipals_fit", X, Y, weights, nlv, scal, False, ctx)
+    return _fit("jch_plsnipals_fit", X, Y, weights, nlv, scal, False, ctx, NIPALS_ONE_PASS if one_pass else 0)
 
 
 def plsnipals_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
@@ -226,7 +232,7 @@ def plsnipals_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optiona
 def _copy_fit(entry, X, Y, weights, nlv, scal, ctx, wold=None, variant=0):
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
-        _addr_ld(X); _addr_ld(Y)
+        _addr_ld(X, allow_bf16=True); _addr_ld(Y, allow_bf16=True)   # (bf16-stored device tensors: widened exactly by the library where a fit has no bf16 kernels)
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
     return _fit(entry, X, Y, weights, nlv, scal, False, ctx, wold=wold, variant=variant)
@@ -259,11 +265,12 @@ WOLD_REF_ZERO_WEIGHT_NAN = 2   # include/jchemo_hip.h JCH_WOLD_REF_ZERO_WEIGHT_N
 
 
 def plswold(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,
-            zero_weight_nan: bool = False, ctx: Optional[Context] = None) -> Plsr:
+            zero_weight_nan: bool = False, ctx: Optional[Context] = None, one_pass: bool = False) -> Plsr:
     """`plswold` — src/plswold.jl:30-34; `niter` (inner passes per LV) as :93.  `zero_weight_nan = True` reproduces the
     reference's NaN scores for rows whose weight is 0 (:107); the default keeps them finite (t_i = x_i' r), which is what
     lets a cross-validation fold be ONE weighted fit (gridcvlv)."""
-    return _copy_fit("jch_plswold_fit", X, Y, weights, nlv, scal, ctx, wold=(tol, maxit), variant=WOLD_REF_ZERO_WEIGHT_NAN if zero_weight_nan else 0)
+    return _copy_fit("jch_plswold_fit", X, Y, weights, nlv, scal, ctx, wold=(tol, maxit),
+                     variant=(WOLD_REF_ZERO_WEIGHT_NAN if zero_weight_nan else 0) | (NIPALS_ONE_PASS if one_pass else 0))   # one_pass: see plsnipals
 
 
 def plswold_(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,

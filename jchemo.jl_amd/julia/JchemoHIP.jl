@@ -28,7 +28,7 @@ module JchemoHIP
 using LinearAlgebra
 
 export Plsr, Lwplsr, plskern, plskern!, plsnipals, plsnipals!, plssimp, plssimp!, plsrosa, plsrosa!, plswold, plswold!,
-       lwplsr, transform, coef, predict, explvarx, JchCtx, attach!,
+       lwplsr, transform, coef, predict, explvarx, JchCtx, attach!, nipals_one_pass!,
        msep, rmsep, ssr, bias, r2, cor2, mpar, segmkf, segmts, gridscorelv, gridcvlv,
        Plsrda, dummy, plsrda, Mbplsr, mbplsr, vip, xfit, xresid
 
@@ -218,7 +218,7 @@ plskern!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plskern, X, Y, _w(weights, X), nlv, scal, true, ctx)
 "`plsnipals` — src/plsnipals.jl:31-35."
 plsnipals(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
-    _fit(:plsnipals, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx)
+    _fit(:plsnipals, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; options = _nipals_options[])
 "`plsnipals!` — src/plsnipals.jl:37-97: X, Y end up centred/scaled and deflated."
 plsnipals!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plsnipals, X, Y, _w(weights, X), nlv, scal, true, ctx)
@@ -238,7 +238,7 @@ plsrosa!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plsrosa, X, Y, _w(weights, X), nlv, scal, true, ctx)
 "`plswold` — src/plswold.jl:30-34; `niter` filled as :93."
 plswold(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
-    _fit(:plswold, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; tol = tol, maxit = maxit, options = _wold_options[])
+    _fit(:plswold, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; tol = tol, maxit = maxit, options = _wold_options[] | _nipals_options[])
 "`plswold!` — src/plswold.jl:36-111."
 plswold!(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
     _fit(:plswold, X, Y, _w(weights, X), nlv, scal, true, ctx; tol = tol, maxit = maxit, options = _wold_options[])
@@ -248,6 +248,13 @@ plswold!(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = 
 const _wold_options = Ref{Int32}(0)
 "`wold_zero_weight_nan!(true)`: `plswold` gives rows with weight 0 NaN scores as the reference does; `false` (default): finite."
 wold_zero_weight_nan!(on::Bool) = (_wold_options[] = on ? Int32(2) : Int32(0); on)
+
+# JCH_NIPALS_ONE_PASS (include/jchemo_hip.h): OPT-IN, never the default — plsnipals / plswold (the non-`!` forms) with ONE pass over X
+# per LV: K_{a+1} = K_a - zp_raw c_raw' / tt instead of the reference's recomputation of X'DY from the deflated matrices
+# (src/plsnipals.jl:71).  Same results up to rounding.  A module switch for the same reason as above.
+const _nipals_options = Ref{Int32}(0)
+"`nipals_one_pass!(true)`: `plsnipals` / `plswold` use the one-pass variant (q <= 16, p <= 2048); `false` (default): the reference's schedule."
+nipals_one_pass!(on::Bool) = (_nipals_options[] = on ? Int32(4) : Int32(0); on)
 
 # out = ((X - 1*shift') ./ scale') * B .+ bias'   (shift, scale, B, bias on the host; X and out where X lives)
 function _affine(X, shift, scale, B::Matrix{Float64}, bias, ctx)

@@ -198,3 +198,38 @@ def test_vip_and_plslda_beyond_64_columns(J, ctx):
     fm, ref = J.plskern(X, Y, nlv=nlv, ctx=ctx), O.plskern(X, Y, nlv=nlv)
     got, exp = J.vip(fm, Y, ctx=ctx), O.vip(ref, Y)
     assert O.rel_fro(exp["imp"], got["imp"]) < 1e-8
+
+
+def test_lwplsr_kspace_outlying_query_is_refitted(J, ctx, monkeypatch):
+    """the neighbour-space local-fit kernel forms the Gram matrix of the gathered rows about the QUERY row.  Neighbours
+    are chosen in the nlvdis-dimensional score space, so a query may sit ~1e4 spreads away from them in full p-space (here: shifted
+    along a direction the global scores do not see); the centring then comes out of the Gram matrix by cancellation.  The kernel's
+    pivot check flags such queries and the library refits them with the per-query path: predictions equal the oracle's, the ordinary
+    queries of the same call stay on the batched kernel, and the refit counter says how many were redone."""
+    import ctypes as C
+    n, p, m = 3000, 150, 6
+    X, A = _spectra(111, n + m, p, nsrc=5, noise=0.05)
+    y = A[:, 0] - A[:, 1] + 0.3 * A[:, 2]
+    kw = dict(nlvdis=4, metric="eucl", h=2.0, k=160, nlv=5)
+    ofm = O.lwplsr(X[:n], y[:n], **kw)
+    # a direction invisible to the global scores: orthogonal to the columns of R (so the query keeps its neighbours), large in p-space
+    R = ofm.fm.R
+    v = O.rand_matrix(112, p, 1)[:, 0] - 0.5
+    v -= R @ np.linalg.lstsq(R, v, rcond=None)[0]
+    v /= np.linalg.norm(v)
+    Xq = X[n:].copy()
+    Xq[1] += 1e4 * X[:n].std() * v
+    Xq[4] -= 3e3 * X[:n].std() * v
+    ref = O.lwplsr_predict(ofm, Xq, nlv=range(0, 6))
+    monkeypatch.setenv("JCH_LOCW_KSPACE", "2")                    # the neighbour-space kernel wherever the shape fits
+    fm = J.lwplsr(X[:n], y[:n], ctx=ctx, **kw)
+    cnt = C.c_int64(0)
+    lib = J.load()
+    ctx.check(lib.jch_ctx_get_counter(ctx._h, 1, C.byref(cnt))); before = cnt.value
+    res = J.predict(fm, Xq, nlv=range(0, 6), ctx=ctx)
+    ctx.check(lib.jch_ctx_get_counter(ctx._h, 1, C.byref(cnt)))
+    assert cnt.value - before == 2                                # exactly the two shifted queries were refitted
+    assert np.array_equal(res.listnn, ref["listnn"])
+    pred = np.stack(res.pred, axis=2)
+    for i in range(m):
+        assert O.rel_fro(ref["pred"][i], pred[i]) < 1e-7, i

@@ -220,8 +220,15 @@ def test_bf16_storage_mode(shape, J):
     assert O.rel_fro(ref.xmeans, fm.xmeans) < (1e-12 if scal else 1e-7) and O.rel_fro(ref.xscales, fm.xscales) < 1e-12
     assert max(errs[f] for f in ("T", "P", "C", "W", "R")) < 1e-3, errs
     assert errs["B"] < 1e-4, errs
-    with pytest.raises(J.JchError):
-        J.plsnipals(Xb, Yb, nlv=2, ctx=tctx)            # bf16 storage: plskern only, loud error otherwise
+    # the other fits on bf16-stored inputs (round 4): the inputs are widened exactly and the Float64 path runs — the mode's contract
+    # ("the Float64 algorithm on the rounded inputs") to Float64 accuracy
+    for name in ("plsnipals", "plssimp", "plsrosa", "plswold"):
+        fo = getattr(J, name)(Xb, Yb, w, nlv=min(nlv, 6), scal=scal, ctx=tctx)
+        ro = getattr(O, name)(Xq, Yq, w, nlv=min(nlv, 6), scal=scal)
+        so = O.sign_align(ro.R, fo.R)
+        for f in ("P", "C", "R"):
+            assert O.rel_fro(getattr(ro, f), getattr(fo, f) * so) < 1e-8, (name, f)
+        assert O.rel_fro(ro.T, fo.T.cpu().numpy() * so) < 1e-8, name
     tctx.close()
 
 
@@ -1373,3 +1380,38 @@ def test_split_small_state_matches_one_kernel_path(shape, variant, J, ctx, monke
     G = (fm.T * d[:, None]).T @ fm.T
     assert np.abs(G - np.diag(fm.TT)).max() < 1e-9 * np.abs(fm.TT).max()
     assert np.abs(fm.R.T @ fm.P - np.eye(k)).max() < 1e-8
+
+
+@pytest.mark.parametrize("shape", [dict(n=4000, p=500, q=10, nlv=14), dict(n=1500, p=60, q=1, nlv=8), dict(n=2500, p=300, q=4, nlv=13),
+                                   dict(n=1200, p=1500, q=3, nlv=9), dict(n=900, p=2000, q=1, nlv=20), dict(n=3000, p=130, q=16, nlv=7)])
+@pytest.mark.parametrize("alg", ["nipals", "wold"])
+def test_one_pass_nipals_is_the_default_path_to_rounding(shape, alg, J, ctx):
+    """Round 4, OPT-IN (JCH_NIPALS_ONE_PASS, `one_pass=True`; never the default): plsnipals / plswold with ONE pass over X per LV —
+    K_{a+1} = K_a - zp_raw c_raw' / tt in the small-state kernel instead of the recomputation of X'DY from the deflated matrices
+    (src/plsnipals.jl:71), c_raw against the undeflated Y, rows written back every 6th LV.  Gate: <= 1e-9 against the default path
+    and <= 1e-6 against the oracle on the leading LVs; every write-back period (nlv not a multiple of it), both small-state
+    kernels (LDS-resident; generic at p = 1500 / 2000), q = 1 ... 16; plswold's iteration counts unchanged; the `!` variants and
+    shapes outside the postponed write-back refuse the flag."""
+    n, p, q, nlv = (shape[k] for k in ("n", "p", "q", "nlv"))
+    Lt = CO.fill_uniform(501, n, 16) - 0.5
+    X = Lt @ (CO.fill_uniform(502, 16, p) - 0.5) + 0.05 * CO.fill_uniform(503, n, p) + 1.0
+    Y = Lt[:, :q] @ (CO.fill_uniform(504, q, q) - 0.5) + (Lt[:, 3:4] ** 2) + 0.05 * CO.fill_uniform(505, n, q)
+    w = CO.fill_uniform(506, n, 1)[:, 0] + 0.5
+    fn, ofn = (J.plsnipals, O.plsnipals) if alg == "nipals" else (J.plswold, O.plswold)
+    one = fn(X, Y, w, nlv=nlv, scal=True, ctx=ctx, one_pass=True)
+    dflt = fn(X, Y, w, nlv=nlv, scal=True, ctx=ctx)
+    ref = ofn(X, Y, w, nlv=nlv, scal=True)
+    kk = min(nlv, 8)
+    s = O.sign_align(dflt.W[:, :kk], one.W[:, :kk])
+    for f in ("T", "P", "W", "C"):
+        assert O.rel_fro(getattr(dflt, f)[:, :kk], getattr(one, f)[:, :kk] * s) < 1e-9, (f, "one pass vs default")
+    s = O.sign_align(ref.W[:, :kk], one.W[:, :kk])
+    for f in ("T", "P", "W", "C"):
+        assert O.rel_fro(getattr(ref, f)[:, :kk], getattr(one, f)[:, :kk] * s) < 1e-6, (f, "one pass vs oracle")
+    if alg == "wold":
+        assert np.array_equal(dflt.niter[:kk], one.niter[:kk])
+    d = one.weights
+    G = (one.T * d[:, None]).T @ one.T                               # the scores stay D-orthogonal (the rows ARE deflated, lazily)
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-9 * np.abs(np.diag(G)).max()
+    with pytest.raises(J.JchError):                                  # outside the envelope of the postponed write-back: refused, loudly
+        fn(X[:, :20], CO.fill_uniform(507, n, 17), nlv=2, ctx=ctx, one_pass=True)   # q = 17
