@@ -88,6 +88,31 @@ def _blas_threads():
         return 0, "unknown"
 
 
+def _cpu_share():
+    """What the box actually grants this process: scheduler affinity and the cgroup CPU quota (cpu.max / cfs_quota), in cores.  A GPU
+    box of this pool exposes all hardware threads of the host but may cap the CPU TIME of a job (the pool's notes speak of a share
+    of 16 per GPU), which bounds any CPU baseline timed there."""
+    out = {"affinity_cpus": None, "cgroup_quota_cores": None}
+    try:
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    out["cgroup_quota_cores"] = float(txt[0]) / float(txt[1])
+            else:
+                q_ = float(txt[0])
+                if q_ > 0:
+                    out["cgroup_quota_cores"] = q_ / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    return out
+
+
 def cpu_baseline(n_total, p, q, nlv, sample_rows):
     """Both CPU stand-ins for the reference's `plskern!` (README.md:93), at `sample_rows` rows (default: the FULL n, no
     extrapolation), each run twice on all host cores; value = the faster stand-in's better run.
@@ -103,6 +128,11 @@ def cpu_baseline(n_total, p, q, nlv, sample_rows):
     Y = CO.fill_uniform(20250113, ns, q, 0, n_total)
     scale = n_total / ns
     runs = {"openblas": [], "c_port": []}
+    # a cgroup CPU quota below the thread count makes an oversubscribed OpenMP team stall on throttling: cap the C port's team at
+    # twice the quota (the quota itself is reported next to the result)
+    share = _cpu_share()
+    if share["cgroup_quota_cores"]:
+        CO.lib().orc_set_num_threads(int(max(1, min(CO.lib().orc_num_threads(), round(2 * share["cgroup_quota_cores"])))))
     for name, fn in (("c_port", lambda: CO.plskern_(X, Y, None, nlv=nlv, scal=False)),
                      ("openblas", lambda: O.plskern_(X, Y, None, nlv=nlv, scal=False))):
         for _ in range(2):     # `plskern!` is in place: the second run re-centres centred data — same passes, same cost
@@ -129,7 +159,8 @@ def cpu_baseline(n_total, p, q, nlv, sample_rows):
             "thread_cap_note": (f"the reported stand-in ran on {cores} threads of a host with {os.cpu_count()} hardware threads "
                                 f"(OpenBLAS in this image is built for at most {blas_threads} threads; the C port used {omp_threads}); "
                                 "vs_cpu_baseline is a ratio against THAT, context only — the roofline fraction is the quality measure"),
-            "host_cpus": os.cpu_count(), "threads": {"openblas": blas_threads, "blas": blas_name, "c_port_openmp": omp_threads},
+            "host_cpus": os.cpu_count(), "cpu_share": _cpu_share(), "threads": {"openblas": blas_threads, "blas": blas_name, "c_port_openmp": omp_threads},
+            "effective_GBps": {k_: (2 * nlv + 3) * ns * p * 8 / v / 1e9 for k_, v in best.items()},   # the reference schedule: 2 passes over X per LV + 3 in the preamble
             "lv_per_s": lvs, "seconds": {k_: [round(t, 3) for t in v] for k_, v in runs.items()},
             "sample": (f"plskern! (in place, README.md:93) on {'all' if ns == n_total else 'the first'} {ns} of {n_total} rows "
                        f"(p={p}, q={q}, nlv={nlv}), two runs per stand-in, best run reported"

@@ -938,6 +938,11 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
             JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr.mark(ctx->device);
         }
+        // (round 4, measured and removed: eight queries per 256-thread workgroup with 512-entry candidate buffers — half the score
+        // traffic per query — took 1.1 ms for the scan at cfg5 with half as many workgroups, i.e. the same time per workgroup-query:
+        // the scan is NOT bound by its L2 / Infinity Cache traffic; with a dot-product screen |z|^2 + |zq|^2 - 2 z.zq in front of the
+        // exact distance — half the arithmetic per pair — 1.78 ms: the ~1000 survivors per query and segment each pay a divergent
+        // 20-load recomputation.  Results were identical in both.  What bounds the scan is the dependent chain of a wave's trip.)
         if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8) * nseg), dim3(512), lds, ctx->stream, a);
         else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB) * nseg), dim3(256), lds, ctx->stream, a);
         hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);

@@ -44,3 +44,4 @@ int32_t jch_launch_knn_generic(jch_ctx *ctx, const knn_args &a);
 // local fits one query at a time: gather the neighbour rows, jch_plskern_fit on them, jch_predict on the query row (the
 // reference's own schedule, src/locwlv.jl:18-39); dpred [m][le][q] device
 int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n, const int *only = nullptr /*host: query indices to fit (null: all)*/, int n_only = 0);
+
