@@ -21,7 +21,10 @@ for a, b in [("bench.json", "r04_final_bench.json"), ("bench_cfg4.json", "r04_fi
              ("pmc_summary.txt", "r04_pmc_headline_all_kernels.txt"), ("pmc_bf16_summary.txt", "r04_pmc_bf16_traffic.txt"),
              ("pmc_cfg4_summary.txt", "r04_pmc_cfg4_traffic.txt"), ("pmc_nipals_q10_summary.txt", "r04_pmc_plsnipals_q10.txt"),
              ("pmc_lwplsr_summary.txt", "r04_pmc_lwplsr_cfg5.txt"), ("lv_debug_split.err", "r04_lv_debug_stamps_split.txt"),
-             ("lv_debug_one_kernel.err", "r04_lv_debug_stamps_one_kernel.txt")]:
+             ("lv_debug_one_kernel.err", "r04_lv_debug_stamps_one_kernel.txt"),
+             ("bench_plsnipals_q10_one_pass_optin.json", "r04_bench_plsnipals_q10_one_pass_optin.json"),
+             ("bench_plswold_one_pass_optin.json", "r04_bench_plswold_one_pass_optin.json"),
+             ("bench_cfg4_one_pass_optin.json", "r04_bench_cfg4_one_pass_optin.json")]:
     cp(a, b)
 for a in ("plssimp", "plsrosa", "plswold", "plskern2"):
     cp(f"bench_{a}.json", f"r04_sibling_bench_{a}.json" if a != "plskern2" else "r04_final_bench_plskern2_optin.json")

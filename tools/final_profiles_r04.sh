@@ -29,3 +29,7 @@ python tools/bench_accessors.py 2>/dev/null | tail -1 > $O/accessors.json
 JCH_LV_DEBUG=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-path --no-other-configs > /dev/null 2> $O/lv_debug_split.err
 JCH_LV_DEBUG=1 JCH_LV_SPLIT=0 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-path --no-other-configs > /dev/null 2> $O/lv_debug_one_kernel.err
 ls -la $O
+# opt-in one-pass NIPALS (never the default): its bench lines
+python bench.py --algo plsnipals --one-pass --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-other-configs > gpurun_out/final4/bench_plsnipals_q10_one_pass_optin.json 2>/dev/null
+python bench.py --algo plswold --one-pass --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-other-configs > gpurun_out/final4/bench_plswold_one_pass_optin.json 2>/dev/null
+python bench.py --algo plsnipals --one-pass --p 2000 --q 1 --nlv 50 --steps 2 --warmup 1 --no-cpu-baseline --no-host-path --no-other-configs > gpurun_out/final4/bench_cfg4_one_pass_optin.json 2>/dev/null
