@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 103 /* 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
+#define JCH_VERSION 104 /* 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
