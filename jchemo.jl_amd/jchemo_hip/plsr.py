@@ -575,9 +575,10 @@ def _knn_train_space(obj: Lwplsr, ctx):
             stages.append((None, None, D))
         qmap = (lambda Xq: Xq) if D is None else (lambda Xq: _affine(Xq, None, None, D, None, ctx))
     else:
-        Zt = obj.fm.T
-        qmap = lambda Xq: transform(obj.fm, Xq, ctx=ctx)
-        stages.append((_model_vec(obj.fm.xmeans), _model_vec(obj.fm.xscales), np.asfortranarray(obj.fm.R[:, :_nlv_arg(obj.fm, None)], dtype=np.float64)))
+        fm = obj.fm          # (the closures below must not capture `obj`: they live in the module-level handle table, and a strong
+        Zt = fm.T            # reference from there would keep the model — and its device handle — alive for ever)
+        qmap = lambda Xq: transform(fm, Xq, ctx=ctx)
+        stages.append((_model_vec(fm.xmeans), _model_vec(fm.xscales), np.asfortranarray(fm.R[:, :_nlv_arg(fm, None)], dtype=np.float64)))
     if obj.metric == "mahal":
         d = Zt.shape[1]
         S = _cov_uncorrected(Zt, ctx)

@@ -93,3 +93,21 @@ def test_changed_model_fields_rebuild_the_handle(monkeypatch):
     del obj
     gc.collect()
     assert not stub.live
+
+
+def test_model_with_a_global_fit_is_collected(monkeypatch):
+    """The query map of a model with a global PLS fit (nlvdis > 0) is a closure kept in the module-level handle table: it must hold
+    the fit, not the `Lwplsr` object, or the object — and its device handle — would never be released."""
+    stub = _StubLib()
+    monkeypatch.setattr(P._lib, "load", lambda: stub)
+    ctx = _StubCtx()
+    X = np.asfortranarray(np.arange(60.0).reshape(20, 3))
+    Y = np.asfortranarray(np.arange(20.0).reshape(20, 1))
+    fm = P.Plsr(np.asfortranarray(np.ones((20, 2))), np.ones((3, 2)), np.ones((3, 2)), np.ones((3, 2)), np.ones((1, 2)), np.ones(2),
+                np.zeros(3), np.ones(3), np.zeros(1), np.ones(1), np.full(20, 0.05), None)
+    obj = P.Lwplsr(X, Y, fm, "eucl", 1.5, 5, 2, 1e-4, False)
+    st = P._lwplsr_prepared(obj, ctx, False, 1)
+    assert st["device_map"] and len(stub.live) == 1
+    del obj, st
+    gc.collect()
+    assert not stub.live and len(stub.released) == 1
