@@ -819,9 +819,11 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
             if (ldr <= 128) JCH_SWEEP_V2_CASE(1, 8, 2);
             if (ldr <= 256) JCH_SWEEP_V2_CASE(2, 8, 2);
             if (ldr <= 512) {
-                if (nbuf == 3) JCH_SWEEP_V2_CASE(4, 4, 3);
-                // short shards (a 1/8 share of cfg2): 4-row groups leave a finer last round (80.5 against 81.9 us per launch at
-                // 125 k rows on 256 CUs; at 250 k rows the 8-row groups win again, 154.0 against 157.4)
+                // short shards (a 1/8 or 1/4 share of cfg2): 4-row groups leave a finer last round, and a third buffer in the
+                // rotation keeps two groups in flight behind the one being reduced (round 4, three A/B pairs on one box: 125 k rows
+                // 79.0-80.3 against 80.2-81.6 us per launch, 250 k rows 151.4 against 153.9); JCH_SWEEP_NBUF=2 / =3 force either
+                const bool shortshard = n < (int64_t)1280 * ctx->cus;
+                if (nbuf == 3 || (!eb && v2 != 8 && v2 != 4 && shortshard)) JCH_SWEEP_V2_CASE(4, 4, 3);
                 if (v2 == 4 || (v2 != 8 && n < (int64_t)640 * ctx->cus)) JCH_SWEEP_V2_CASE(4, 4, 2);
                 JCH_SWEEP_V2_CASE(4, 8, 2);
             }
