@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 104 /* 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
+#define JCH_VERSION 105 /* 0.1.5: screened kNN (JCH_COUNTER_KNN_SCREENED / _REDONE); 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
@@ -347,6 +347,13 @@ JCH_API int32_t jch_ctx_allreduce_probe(jch_ctx *ctx, int32_t transport, double 
  * than 64 local standard deviations (along the offset) from the mean of their neighbours — possible because the neighbours are
  * chosen in the score space, not in p-space — and that were refitted by the per-query path (explicit centring). */
 #define JCH_COUNTER_LOCW_REFITS 1
+/* which = JCH_COUNTER_KNN_SCREENED: queries of jch_lwplsr_predict* whose neighbours were found by the screened search (all pairs in
+ * f32 on the matrix cores, exact distances for the survivors; score spaces of <= 62 dimensions, k <= 768, n >= 24 k);
+ * which = JCH_COUNTER_KNN_SCREEN_REDONE: those of them the screen could not settle (non-finite scores, or more rows within its
+ * error bound of the k-th distance than a candidate list holds — ties on a lattice) and the exact selection redid.  Results do not
+ * depend on which search ran. */
+#define JCH_COUNTER_KNN_SCREENED 2
+#define JCH_COUNTER_KNN_SCREEN_REDONE 3
 JCH_API int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_t *out);
 
 #ifdef __cplusplus

@@ -84,7 +84,7 @@ extern "C" int32_t jch_ctx_destroy(jch_ctx *ctx)
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     jch_p2p_destroy(ctx);
     for (jch_buf *b : {&ctx->gram, &ctx->xr, &ctx->yr, &ctx->xstage, &ctx->ystage, &ctx->wstage, &ctx->tbuf, &ctx->dnorm, &ctx->part,
-                       &ctx->kpart, &ctx->small, &ctx->colpart, &ctx->gemm_b, &ctx->gemm_out, &ctx->xq, &ctx->tickets, &ctx->qz, &ctx->lw_work, &ctx->lw_xrm, &ctx->lvws, &ctx->lw_flags})
+                       &ctx->kpart, &ctx->small, &ctx->colpart, &ctx->gemm_b, &ctx->gemm_out, &ctx->xq, &ctx->tickets, &ctx->qz, &ctx->lw_work, &ctx->lw_xrm, &ctx->lvws, &ctx->lw_flags, &ctx->lw_screen})
         free_buf(*b);
     if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
@@ -435,6 +435,8 @@ extern "C" int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_
     if (!ctx || !out) return JCH_EINVAL;
     if (which == JCH_COUNTER_PIVOT_REFITS) { *out = ctx->pivot_refits; return JCH_OK; }
     if (which == JCH_COUNTER_LOCW_REFITS) { *out = ctx->locw_refits; return JCH_OK; }
+    if (which == JCH_COUNTER_KNN_SCREENED) { *out = ctx->knn_screened; return JCH_OK; }
+    if (which == JCH_COUNTER_KNN_SCREEN_REDONE) { *out = ctx->knn_screen_redone; return JCH_OK; }
     return JCH_EINVAL;
 }
 

@@ -60,7 +60,7 @@ struct jch_ctx {
     // workspace (grow-only)
     void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
     size_t hstage_bytes = 0;
-    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz, lw_work, lw_xrm, lvws, lw_flags;
+    jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz, lw_work, lw_xrm, lvws, lw_flags, lw_screen;
     // profiling
     bool profiling = false;
     jch_profile prof{};
@@ -82,6 +82,7 @@ struct jch_ctx {
     int sweep_blocks_per_cu = 0;
     // diagnostics
     long long pivot_refits = 0;      // raw-mode fits repeated on the centred copy because the sampled pivot was poor
+    long long knn_screened = 0, knn_screen_redone = 0;   // kNN-LWPLSR queries done by the screened search / redone by the exact selection behind it
     long long locw_refits = 0;       // kNN-LWPLSR queries refitted by the per-query path after the neighbour-space kernel's pivot check
 };
 

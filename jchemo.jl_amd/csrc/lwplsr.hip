@@ -51,33 +51,12 @@ __global__ __launch_bounds__(256) void k_to_rowmajor(const double *__restrict__ 
 
 // ---------------------------------------------------------------- K9: kNN + weights
 #define KNN_QB 4       // queries per workgroup (each loaded training value serves KNN_QB queries; 8 measured slower)
-#define KNN_CAP 1024   // candidate buffer per query (LDS); k <= KNN_CAP - 256
+// (KNN_CAP = 1024, lwplsr_dev.h: candidate buffer per query (LDS); k <= KNN_CAP - 256)
 #define KNN_FCAP 2048  // candidates per query that k_knn_finish merges (segments x k)
 #define KNN_RB 4        // 256-row chunks of the training scores in flight per trip
 #define KNN_CB 8        // score columns loaded together
 
-// bitonic sort of `cap` (a power of two <= KNN_CAP) (key, idx) pairs in LDS, ascending by (key, idx); NT threads
-template <int NT>
-__device__ static void bitonic_sort_n(double *key, int *idx, int cap)
-{
-    const int tid = threadIdx.x;
-    for (int size = 2; size <= cap; size <<= 1) {
-        for (int stride = size >> 1, ls = 31 - __builtin_clz(size >> 1); stride > 0; stride >>= 1, --ls) {
-            __syncthreads();
-            for (int t = tid; t < cap / 2; t += NT) {
-                // (shifts, not t / stride and t % stride: a runtime integer division is ~40 instructions on this ISA and was
-                // 3/4 of the sort's time)
-                const int lo = ((t >> ls) << (ls + 1)) | (t & (stride - 1)), hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const double a = key[lo], b = key[hi];
-                const int ia = idx[lo], ib = idx[hi];
-                const bool gt = (a > b) || (a == b && ia > ib) || (a != a && b == b);   // NaN sorts last
-                if (gt == up) { key[lo] = b; key[hi] = a; idx[lo] = ib; idx[hi] = ia; }
-            }
-        }
-    }
-    __syncthreads();
-}
+// (bitonic_sort_n, knn_finish_tail: lwplsr_dev.h — shared with lwplsr_screen.hip)
 // The same network run by ONE wave (no workgroup barrier between the passes: a wave's LDS operations complete in order): the four
 // waves of a scan workgroup sort the four queries' buffers side by side — 7 us per 1024 entries against 14 us x 4 queries with
 // the workgroup-wide sort, which was half of the scan's time (JCH_KNN_DBG=1 measures the scan without any candidate kept).
@@ -312,7 +291,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
     __shared__ double sred[8];
     __shared__ double smed[2];
     __shared__ int snn[4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const int qi = blockIdx.x, k = g.k;
     const int ncand = g.nseg * k;
     const double *ck = g.ckey + (size_t)qi * ncand;
@@ -351,65 +330,7 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
         }
     }
     __syncthreads();
-    int *oi = g.ind + (size_t)qi * k;
-    double *od = g.dist + (size_t)qi * k, *ow = g.w + (size_t)qi * k;
-    // fewer than k candidates with a finite distance (NaN / Inf in the query's or the training scores: no comparison
-    // against the bar ever holds): the empty places keep the sentinel index.  They are given the in-range row `e` and a
-    // NaN distance — wdist then yields weights 1 for the query exactly as the reference's arithmetic does (every
-    // comparison with NaN is false, 0 / 0 -> NaN -> 1, src/wdist.jl:64-75) and nothing downstream reads out of bounds.
-    for (int e = tid; e < kk; e += 256) {
-        const bool hole = oidx[e] < 0 || (int64_t)oidx[e] >= g.n;
-        oi[e] = hole ? e : oidx[e];
-        const double dv = hole ? __builtin_nan("") : sqrt(okey[e]);
-        okey[e] = dv;
-        od[e] = dv;
-    }
-    __syncthreads();
-    // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
-    const double med = (kk & 1) ? okey[kk / 2] : 0.5 * (okey[kk / 2 - 1] + okey[kk / 2]);
-    // the median of |d - med| by RANK COUNTING (was a second sort): entry e's rank among the kk deviations in the order of the
-    // sort it replaces — by value, then by position, NaN last — is the number of entries that come before it
-    int nn = 0;
-    for (int e = tid; e < kk; e += 256) { const double v = fabs(okey[e] - med); key[e] = v; nn += v == v ? 1 : 0; }
-    for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
-    if (lane == 0) snn[wv] = nn;
-    if (tid < 2) smed[tid] = __builtin_nan("");                // (a target place among the NaNs stays NaN)
-    __syncthreads();
-    nn = snn[0] + snn[1] + snn[2] + snn[3];
-    const int t1 = kk / 2, t0 = (kk & 1) ? -1 : kk / 2 - 1;
-    for (int e = tid; e < kk; e += 256) {
-        const double v = key[e];
-        if (v != v) continue;
-        int r = 0;
-        for (int f = 0; f < kk; ++f) { const double u = key[f]; r += (u < v || (u == v && f < e)) ? 1 : 0; }
-        if (r == t1) smed[1] = v;
-        if (r == t0) smed[0] = v;
-    }
-    __syncthreads();
-    const double zmad = 1.4826 * ((kk & 1) ? smed[1] : 0.5 * (smed[0] + smed[1]));
-    const double cutoff = med + g.cri * zmad;
-    // weights; max with NaN propagation (Julia's `maximum` returns NaN if any NaN is present)
-    double wmax = -__builtin_inf();
-    int anynan = 0;
-    __syncthreads();                                           // (key: the deviations are done with, the weights go there)
-    for (int e = tid; e < kk; e += 256) {
-        const double dv = okey[e];
-        const double wv_ = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
-        key[e] = wv_;
-        if (wv_ != wv_) anynan = 1;
-        else if (wv_ > wmax) wmax = wv_;
-    }
-    for (int o = 32; o > 0; o >>= 1) { wmax = fmax(wmax, __shfl_xor(wmax, o, 64)); anynan |= __shfl_xor(anynan, o, 64); }
-    if (lane == 0) { sred[wv] = wmax; sred[4 + wv] = (double)anynan; }
-    __syncthreads();
-    wmax = fmax(fmax(sred[0], sred[1]), fmax(sred[2], sred[3]));
-    if (sred[4] + sred[5] + sred[6] + sred[7] > 0.0) wmax = __builtin_nan("");
-    for (int e = tid; e < kk; e += 256) {
-        double wv_ = key[e] / wmax;
-        if (wv_ != wv_) wv_ = 1.0;
-        if (wv_ < g.tol) wv_ = g.tol;
-        ow[e] = wv_;
-    }
+    knn_finish_tail(g, qi, kk, key, okey, oidx, sred, smed, snn);
 }
 
 // ---------------------------------------------------------------- K8: batched local weighted plskern (q <= 16)
@@ -880,6 +801,10 @@ struct jch_lwplsr_model {
     // transform(fm, X) followed by the whitening of getknn: two stages) kept on the device — jch_lwplsr_add_query_map
     struct qmap { int p_in = 0, k_out = 0, kpad = 0; double *dB = nullptr; };   // dB: [p_in][kpad] folded B, then kpad folded biases
     std::vector<qmap> qmaps;
+    // the operand-ordered f32 copy of the scores for the screened kNN (lwplsr_screen.hip); absent when the score space is too wide
+    bool has_screen = false;
+    knn_screen screen;
+    void *screen_mem = nullptr;
 };
 
 static void lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t n, int p, double *Xrm, int ldr)
@@ -894,7 +819,7 @@ static void lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t
 static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64_t p, const double *dY, int64_t q, int64_t ldyd,
                       const double *dZt, int64_t ldztd, const double *dZq, int64_t ldzqd, int64_t dd, const double *dXq, int64_t m,
                       int64_t ldxqd, int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi, double *pred,
-                      int32_t *ind_out, double *dist_out, double *w_out, hipEvent_t ev0)
+                      int32_t *ind_out, double *dist_out, double *w_out, hipEvent_t ev0, const knn_screen *scr)
 {
     const int le = nlv_hi - nlv_lo + 1;
     JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * ((size_t)m * k * 2 + (size_t)m * le * q) + sizeof(int) * (size_t)m * k + 256));
@@ -904,6 +829,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     bool generic_fits = false;
     int *kflags = nullptr;          // k-space kernel: per-query pivot flags (device)
     locw_args kargs{};
+    int *sflags = nullptr;          // screened kNN: per-query "redone by the exact selection" flags (device; read back with the predictions)
     {
         knn_args a;
         a.Zt = dZt; a.ldzt = ldztd; a.n = n; a.Zq = dZq; a.ldzq = ldzqd; a.m = (int)m; a.dd = (int)dd; a.k = k;
@@ -920,6 +846,22 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         // outside the scan's envelope (k beyond the candidate buffers, a search space too wide for its LDS, 2^29 rows): the generic
         // selection, one workgroup per query (lwplsr_generic.hip); JCH_KNN_GENERIC=1 forces it (tests)
         const char *e_g = getenv("JCH_KNN_GENERIC");
+        // the screened kNN (lwplsr_screen.hip: all pairs in f32 on the matrix cores, exact distances for the survivors only) when the
+        // shape is inside its envelope; JCH_KNN_SCREEN=0 selects the exact scan below (A/B runs, tests)
+        const char *e_s = getenv("JCH_KNN_SCREEN");
+        const bool screen = !(e_g && atoi(e_g) == 1) && !(e_s && atoi(e_s) == 0) && !a.dbg && jch_knn_screen_shape_ok(n, (int)dd, k);
+        if (screen) {
+            knn_screen local;
+            if (!scr) {   // one-shot call: the model-constant operand copy is rebuilt in the ctx workspace
+                JCH_TRY(jch_reserve(ctx, ctx->lw_screen, jch_knn_screen_model_bytes(n, (int)dd)));
+                JCH_TRY(jch_knn_screen_build(ctx, dZt, ldztd, n, (int)dd, ctx->lw_screen.ptr, &local));
+                scr = &local;
+            }
+            // (one reservation for both flag arrays of a call: the neighbour-space kernel's pivot flags [0, m), the screen's [m, 2 m))
+            JCH_TRY(jch_reserve(ctx, ctx->lw_flags, sizeof(int) * 2 * (size_t)m + 256));
+            sflags = (int *)ctx->lw_flags.ptr + (size_t)m;
+            JCH_TRY(jch_launch_knn_screen(ctx, a, *scr, sflags));
+        } else
         if (k > KNN_CAP - 256 || lds > 150 * 1024 || n >= ((int64_t)1 << 29) || (e_g && atoi(e_g) == 1)) {
             JCH_TRY(jch_launch_knn_generic(ctx, a));
         } else {
@@ -977,7 +919,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         } else
         if (jch_locw_kspace_supported(g)) {
             // pivot check of the neighbour-space kernel: queries far from their neighbours in p-space are flagged and refitted below
-            JCH_TRY(jch_reserve(ctx, ctx->lw_flags, sizeof(int) * (size_t)m + 256));
+            JCH_TRY(jch_reserve(ctx, ctx->lw_flags, sizeof(int) * 2 * (size_t)m + 256));
             g.flags = (int *)ctx->lw_flags.ptr;
             JCH_HIP(ctx, hipMemsetAsync(g.flags, 0, sizeof(int) * (size_t)m, ctx->stream));
             JCH_TRY(jch_launch_locw_kspace(ctx, g));
@@ -1004,8 +946,17 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         hf.resize((size_t)m);
         JCH_HIP(ctx, hipMemcpyAsync(hf.data(), kflags, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     }
+    std::vector<int> hsf;
+    if (sflags) {
+        hsf.resize((size_t)m);
+        JCH_HIP(ctx, hipMemcpyAsync(hsf.data(), sflags, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    }
     JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
     JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sflags) {
+        ctx->knn_screened += (long long)m;
+        for (int i = 0; i < (int)m; ++i) ctx->knn_screen_redone += hsf[(size_t)i] ? 1 : 0;
+    }
     if (kflags) {   // flagged queries (the exception): refitted by the per-query path, their predictions fetched again
         std::vector<int> only;
         for (int i = 0; i < (int)m; ++i) if (hf[(size_t)i]) only.push_back(i);
@@ -1078,7 +1029,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     hipEvent_t ev0 = jch_ev(ctx);
     lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, Xrm, ldr);
     return lw_run(ctx, Xrm, ldr, n, p, dY, q, ldyd, dZt, ldztd, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol, scal, nlv_lo, nlv_hi, pred,
-                  ind_out, dist_out, w_out, ev0);
+                  ind_out, dist_out, w_out, ev0, nullptr);
 }
 
 extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
@@ -1095,7 +1046,7 @@ extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *X
     jch_lwplsr_model *mo = new (std::nothrow) jch_lwplsr_model();
     if (!mo) return jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_prepare: host allocation failed");
     mo->device = ctx->device; mo->n = n; mo->p = p; mo->q = q; mo->dd = dd; mo->ldr = ((int)p + 1) & ~1;
-    auto fail = [&](int32_t st) { (void)hipFree(mo->Xrm); (void)hipFree(mo->Y); (void)hipFree(mo->Zt); delete mo; return st; };
+    auto fail = [&](int32_t st) { (void)hipFree(mo->Xrm); (void)hipFree(mo->Y); (void)hipFree(mo->Zt); (void)hipFree(mo->screen_mem); delete mo; return st; };
     if (hipMalloc((void **)&mo->Xrm, sizeof(double) * (size_t)n * mo->ldr) != hipSuccess || hipMalloc((void **)&mo->Y, sizeof(double) * (size_t)n * q) != hipSuccess ||
         hipMalloc((void **)&mo->Zt, sizeof(double) * (size_t)n * dd) != hipSuccess)
         return fail(jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_prepare: device allocation failed (%lld x %lld training rows)", (long long)n, (long long)p));
@@ -1115,6 +1066,13 @@ extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *X
         dX = (const double *)ctx->xstage.ptr; ldxd = n;
     }
     lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, mo->Xrm, mo->ldr);
+    if (dd <= 62 && n < ((int64_t)1 << 26)) {   // (whether a call is screened also depends on its k: jch_knn_screen_shape_ok)
+        if (hipMalloc(&mo->screen_mem, jch_knn_screen_model_bytes(n, (int)dd)) != hipSuccess)
+            return fail(jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_prepare: device allocation failed (screened kNN operand)"));
+        const int32_t st = jch_knn_screen_build(ctx, mo->Zt, n, n, (int)dd, mo->screen_mem, &mo->screen);
+        if (st != JCH_OK) return fail(st);
+        mo->has_screen = true;
+    }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(jch_fail(ctx, JCH_EHIP, "jch_lwplsr_prepare: row-major copy failed"));
     *model_out = mo;
@@ -1128,7 +1086,7 @@ extern "C" int32_t jch_lwplsr_release(jch_ctx *ctx, jch_lwplsr_model *model)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    (void)hipFree(model->Xrm); (void)hipFree(model->Y); (void)hipFree(model->Zt);
+    (void)hipFree(model->Xrm); (void)hipFree(model->Y); (void)hipFree(model->Zt); (void)hipFree(model->screen_mem);
     for (auto &qm : model->qmaps) (void)hipFree(qm.dB);
     delete model;
     return JCH_OK;
@@ -1209,7 +1167,7 @@ extern "C" int32_t jch_lwplsr_predict_prepared(jch_ctx *ctx, const jch_lwplsr_mo
         dZq = src; ldzqd = m;
     }
     return lw_run(ctx, model->Xrm, model->ldr, model->n, p, model->Y, model->q, model->n, model->Zt, model->n, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol,
-                  scal, nlv_lo, nlv_hi, pred, ind_out, dist_out, w_out, ev0);
+                  scal, nlv_lo, nlv_hi, pred, ind_out, dist_out, w_out, ev0, model->has_screen ? &model->screen : nullptr);
 }
 
 // Weighted (uncorrected) covariance of the columns of A (n x d, d <= 64): S = (A - 1 mu')' D (A - 1 mu'), the

@@ -36,7 +36,26 @@ struct knn_args {
     double *ckey;  // [m][nseg][k] squared distances of every segment's k best (ascending; +inf beyond the segment's rows)
     int *cidx;     // [m][nseg][k]
     int dbg;       // measurement switch (JCH_KNN_DBG; results then wrong by design): 1 = the bar starts at -inf (no candidate is ever kept: the bare scan)
+    const int *only_flags = nullptr;   // k_knn_generic: null, or [m] device flags — only the queries with a non-zero flag are done
 };
+
+// lwplsr_screen.hip: the screened kNN (round 4).  Squared distances of ALL (row, query) pairs in f32 on the matrix cores
+// (v_mfma_f32_32x32x2_f32 on norm-augmented operands), an error-bounded bar per query from the k-th smallest GROUP minimum, exact
+// f64 distances only for the survivors (k .. ~1.2 k rows per query); queries the screen cannot settle (non-finite scores, more
+// survivors than the candidate list holds) are flagged and done by k_knn_generic.  Results identical to k_knn_scan's.
+struct knn_screen {          // the model-constant part: built once per prepared model, or per call in the ctx workspace
+    float *Zs = nullptr;     // [ntiles][KG][64 lanes][4] operand-ordered f32 copy of the centred training scores (+ |z|^2 and 1 columns)
+    double *mu = nullptr;    // [dd] column means the copy is centred on (distances do not depend on them)
+    unsigned *hdr = nullptr; // [0] bits of max |z|^2 (f32) over the rows, [1] non-zero: a training score is not finite
+    int KG = 0;              // groups of 8 operand columns: 8 KG >= dd + 2
+    int64_t ntiles = 0;      // 32-row tiles
+};
+bool jch_knn_screen_shape_ok(int64_t n, int dd, int k);
+size_t jch_knn_screen_model_bytes(int64_t n, int dd);
+// mem: jch_knn_screen_model_bytes(n, dd) bytes of device memory (256-B aligned) that `out` is carved from
+int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int64_t n, int dd, void *mem, knn_screen *out);
+// flags: [m] device ints, set to 1 for the queries handed to the exact selection (0 otherwise)
+int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen &sc, int *flags);
 
 // lwplsr_generic.hip: the paths WITHOUT shape limits (any k <= n, any p, q, nlv) behind the batched kernels' envelope.
 // kNN + weights of all m queries: exact selection of the k smallest distances per query, (distance, index) order, wdist weights
@@ -45,3 +64,97 @@ int32_t jch_launch_knn_generic(jch_ctx *ctx, const knn_args &a);
 // reference's own schedule, src/locwlv.jl:18-39); dpred [m][le][q] device
 int32_t jch_lw_generic_fits(jch_ctx *ctx, const locw_args &g, int64_t n, const int *only = nullptr /*host: query indices to fit (null: all)*/, int n_only = 0);
 
+#ifdef __HIPCC__
+#define KNN_CAP 1024   // candidate buffer per query (LDS) of the scan; the finishing kernels order at most this many (distance, index) pairs
+
+// bitonic sort of `cap` (a power of two <= KNN_CAP) (key, idx) pairs in LDS, ascending by (key, idx); NT threads
+template <int NT>
+__device__ static void bitonic_sort_n(double *key, int *idx, int cap)
+{
+    const int tid = threadIdx.x;
+    for (int size = 2; size <= cap; size <<= 1) {
+        for (int stride = size >> 1, ls = 31 - __builtin_clz(size >> 1); stride > 0; stride >>= 1, --ls) {
+            __syncthreads();
+            for (int t = tid; t < cap / 2; t += NT) {
+                // (shifts, not t / stride and t % stride: a runtime integer division is ~40 instructions on this ISA and was
+                // 3/4 of the sort's time)
+                const int lo = ((t >> ls) << (ls + 1)) | (t & (stride - 1)), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double a = key[lo], b = key[hi];
+                const int ia = idx[lo], ib = idx[hi];
+                const bool gt = (a > b) || (a == b && ia > ib) || (a != a && b == b);   // NaN sorts last
+                if (gt == up) { key[lo] = b; key[hi] = a; idx[lo] = ib; idx[hi] = ia; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The tail shared by the finishing kernels (k_knn_finish, k_knn_finish_screen): okey / oidx [kk] hold the query's nearest squared
+// distances and rows in (distance, index) order (sentinels +inf / 0x7fffffff where fewer than kk were found); writes the neighbour
+// list, the distances and the wdist weights (src/wdist.jl:64-75).  256 threads; key: scratch of >= kk doubles; every thread calls.
+__device__ static void knn_finish_tail(const knn_args &g, int qi, int kk, double *key, double *okey, int *oidx, double *sred, double *smed, int *snn)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k = g.k;
+    int *oi = g.ind + (size_t)qi * k;
+    double *od = g.dist + (size_t)qi * k, *ow = g.w + (size_t)qi * k;
+    // fewer than k candidates with a finite distance (NaN / Inf in the query's or the training scores: no comparison
+    // against the bar ever holds): the empty places keep the sentinel index.  They are given the in-range row `e` and a
+    // NaN distance — wdist then yields weights 1 for the query exactly as the reference's arithmetic does (every
+    // comparison with NaN is false, 0 / 0 -> NaN -> 1, src/wdist.jl:64-75) and nothing downstream reads out of bounds.
+    for (int e = tid; e < kk; e += 256) {
+        const bool hole = oidx[e] < 0 || (int64_t)oidx[e] >= g.n;
+        oi[e] = hole ? e : oidx[e];
+        const double dv = hole ? __builtin_nan("") : sqrt(okey[e]);
+        okey[e] = dv;
+        od[e] = dv;
+    }
+    __syncthreads();
+    // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
+    const double med = (kk & 1) ? okey[kk / 2] : 0.5 * (okey[kk / 2 - 1] + okey[kk / 2]);
+    // the median of |d - med| by RANK COUNTING (was a second sort): entry e's rank among the kk deviations in the order of the
+    // sort it replaces — by value, then by position, NaN last — is the number of entries that come before it
+    int nn = 0;
+    for (int e = tid; e < kk; e += 256) { const double v = fabs(okey[e] - med); key[e] = v; nn += v == v ? 1 : 0; }
+    for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
+    if (lane == 0) snn[wv] = nn;
+    if (tid < 2) smed[tid] = __builtin_nan("");                // (a target place among the NaNs stays NaN)
+    __syncthreads();
+    nn = snn[0] + snn[1] + snn[2] + snn[3];
+    const int t1 = kk / 2, t0 = (kk & 1) ? -1 : kk / 2 - 1;
+    for (int e = tid; e < kk; e += 256) {
+        const double v = key[e];
+        if (v != v) continue;
+        int r = 0;
+        for (int f = 0; f < kk; ++f) { const double u = key[f]; r += (u < v || (u == v && f < e)) ? 1 : 0; }
+        if (r == t1) smed[1] = v;
+        if (r == t0) smed[0] = v;
+    }
+    __syncthreads();
+    const double zmad = 1.4826 * ((kk & 1) ? smed[1] : 0.5 * (smed[0] + smed[1]));
+    const double cutoff = med + g.cri * zmad;
+    // weights; max with NaN propagation (Julia's `maximum` returns NaN if any NaN is present)
+    double wmax = -__builtin_inf();
+    int anynan = 0;
+    __syncthreads();                                           // (key: the deviations are done with, the weights go there)
+    for (int e = tid; e < kk; e += 256) {
+        const double dv = okey[e];
+        const double wv_ = dv <= cutoff ? exp(-dv / (g.h * zmad)) : 0.0;
+        key[e] = wv_;
+        if (wv_ != wv_) anynan = 1;
+        else if (wv_ > wmax) wmax = wv_;
+    }
+    for (int o = 32; o > 0; o >>= 1) { wmax = fmax(wmax, __shfl_xor(wmax, o, 64)); anynan |= __shfl_xor(anynan, o, 64); }
+    if (lane == 0) { sred[wv] = wmax; sred[4 + wv] = (double)anynan; }
+    __syncthreads();
+    wmax = fmax(fmax(sred[0], sred[1]), fmax(sred[2], sred[3]));
+    if (sred[4] + sred[5] + sred[6] + sred[7] > 0.0) wmax = __builtin_nan("");
+    for (int e = tid; e < kk; e += 256) {
+        double wv_ = key[e] / wmax;
+        if (wv_ != wv_) wv_ = 1.0;
+        if (wv_ < g.tol) wv_ = g.tol;
+        ow[e] = wv_;
+    }
+}
+#endif

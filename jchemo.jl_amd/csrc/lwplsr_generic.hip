@@ -68,6 +68,7 @@ __global__ __launch_bounds__(KG_NT) void k_knn_generic(knn_args g, kg_scratch sc
     double *skey = sc.skey + (size_t)blockIdx.x * K2, *dkey = sc.dkey + (size_t)blockIdx.x * K2;
     int *sidx = sc.sidx + (size_t)blockIdx.x * K2, *didx = sc.didx + (size_t)blockIdx.x * K2;
     for (int qi = blockIdx.x; qi < g.m; qi += gridDim.x) {
+        if (g.only_flags && !g.only_flags[qi]) continue;       // (block-uniform)
         __syncthreads();
         for (int c = tid; c < g.dd; c += KG_NT) zq[c] = g.Zq[(size_t)qi + (size_t)c * (size_t)g.ldzq];
         __syncthreads();
@@ -135,9 +136,15 @@ __global__ __launch_bounds__(KG_NT) void k_knn_generic(knn_args g, kg_scratch sc
         // ---- neighbours, distances; wdist weights (the arithmetic of k_knn_finish)
         int *oi = g.ind + (size_t)qi * k;
         double *od = g.dist + (size_t)qi * k, *ow = g.w + (size_t)qi * k;
+        // a NaN distance (NaN in the query's or in a selected row's scores) sorts BEHIND the padding of the sort buffer, so either
+        // may sit among the first k entries: such a place is a hole and gets what k_knn_finish gives its holes — the in-range row
+        // `e` and a NaN distance (knn_finish_tail, lwplsr_dev.h); nothing downstream gathers from the sentinel index
         for (int e = tid; e < k; e += KG_NT) {
-            const double dv = sqrt(skey[e]);
-            oi[e] = sidx[e];
+            const int si = sidx[e];
+            const double kv = skey[e];
+            const bool hole = si < 0 || (int64_t)si >= n || kv != kv;
+            const double dv = hole ? __builtin_nan("") : sqrt(kv);
+            oi[e] = hole ? e : si;
             od[e] = dv;
             skey[e] = dv;
         }
@@ -182,7 +189,9 @@ int32_t jch_launch_knn_generic(jch_ctx *ctx, const knn_args &a)
     while (K2 < a.k) K2 <<= 1;
     const size_t per = sizeof(double) * ((size_t)a.n + 2 * (size_t)K2) + sizeof(int) * 2 * (size_t)K2;
     const size_t budget = (size_t)4 << 30;
-    int nblk = (int)std::min<size_t>(std::min<size_t>((size_t)a.m, (size_t)ctx->cus * 2), std::max<size_t>(1, budget / per));
+    // (behind the screened kNN only the flagged queries — the exception — are done: a small grid, a small scratch)
+    const size_t want = a.only_flags ? 64 : (size_t)ctx->cus * 2;
+    int nblk = (int)std::min<size_t>(std::min<size_t>((size_t)a.m, want), std::max<size_t>(1, budget / per));
     JCH_TRY(jch_reserve(ctx, ctx->lw_work, per * nblk + 1024));
     kg_scratch sc;
     char *b = (char *)ctx->lw_work.ptr;

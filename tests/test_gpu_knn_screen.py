@@ -1,0 +1,171 @@
+"""Screened kNN (jchemo.jl_amd/csrc/lwplsr_screen.hip) against the exact scan (JCH_KNN_SCREEN=0) and the oracle: the screen only
+decides which rows get an exact distance, so neighbours, their order, distances and weights must be IDENTICAL — on generic data,
+with ties, with uncentred / badly scaled scores, with outliers, with non-finite queries, at the envelope's edges.
+Reference: /root/reference/src/getknn.jl:29-57, wdist.jl:64-75 (through the oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle.plsr_oracle as O
+import jchemo_hip as J_
+from jchemo_hip import plsr as P
+
+pytestmark = pytest.mark.gpu
+
+SCREENED, REDONE = 2, 3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = J_.Context(0)
+    yield c
+    c.close()
+
+
+def _both(ctx, X, y, Xq, monkeypatch, **kw):
+    """predict with the screen (default) and with the exact scan; returns (screened result, scan result, #screened, #redone)"""
+    fm = P.lwplsr(X, y, ctx=ctx, **kw)
+    s0, r0 = ctx.counter(SCREENED), ctx.counter(REDONE)
+    a = P.lwplsr_predict(fm, Xq, nlv=range(0, kw["nlv"] + 1), ctx=ctx)
+    s1, r1 = ctx.counter(SCREENED), ctx.counter(REDONE)
+    monkeypatch.setenv("JCH_KNN_SCREEN", "0")
+    fm2 = P.lwplsr(X, y, ctx=ctx, **kw)
+    b = P.lwplsr_predict(fm2, Xq, nlv=range(0, kw["nlv"] + 1), ctx=ctx)
+    assert ctx.counter(SCREENED) == s1                              # the switch works
+    monkeypatch.delenv("JCH_KNN_SCREEN")
+    return a, b, s1 - s0, r1 - r0
+
+
+def _same(a, b):
+    assert np.array_equal(a.listnn, b.listnn)
+    assert np.array_equal(a.listd, b.listd, equal_nan=True)         # the same expression on the same rows: the same bits
+    assert np.array_equal(a.listw, b.listw, equal_nan=True)
+    for pa, pb in zip(a.pred, b.pred):
+        assert np.array_equal(pa, pb, equal_nan=True)
+
+
+CASES = [
+    dict(n=30000, p=30, m=77, k=200, nlvdis=20, metric="mahal"),       # cfg5-like, ragged query tile and row tile
+    dict(n=30001, p=12, m=1, k=5, nlvdis=0, metric="eucl"),            # one query, tiny k, raw columns as the space
+    dict(n=5000, p=8, m=40, k=64, nlvdis=1, metric="eucl"),            # a one-dimensional score space
+    dict(n=20000, p=64, m=33, k=768, nlvdis=0, metric="mahal"),        # largest k, 62 < 64 columns: NOT screened (dd = 64)
+    dict(n=20000, p=62, m=33, k=768, nlvdis=0, metric="eucl"),         # largest k and widest screened space (dd = 62)
+    dict(n=700, p=10, m=9, k=20, nlvdis=4, metric="mahal"),            # few rows: T = 1, 22 tiles
+]
+
+
+@pytest.mark.parametrize("c", CASES)
+def test_screen_matches_the_exact_scan_and_the_oracle(c, ctx, monkeypatch):
+    rng = np.random.default_rng(c["n"] + c["k"])
+    n, p, m = c["n"], c["p"], c["m"]
+    L = rng.standard_normal((p, p)) / np.sqrt(p)
+    X = rng.standard_normal((n, p)) @ L + 0.3 * rng.standard_normal((n, 1))
+    Xq = rng.standard_normal((m, p)) @ L
+    y = X[:, : min(p, 5)].sum(axis=1) + 0.1 * rng.standard_normal(n)
+    kw = dict(nlvdis=c["nlvdis"], metric=c["metric"], h=2.0, k=c["k"], nlv=3)
+    a, b, ns, nr = _both(ctx, X, y, Xq, monkeypatch, **kw)
+    dd = c["nlvdis"] if c["nlvdis"] > 0 else p
+    assert ns == (m if dd <= 62 else 0)
+    assert nr == 0                                                  # nothing here needs the exact selection behind the screen
+    _same(a, b)
+    if n <= 30001 and m <= 80:
+        with np.errstate(all="ignore"):
+            ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, 4))
+        assert np.array_equal(a.listnn, ref["listnn"])
+        assert np.allclose(a.listd, ref["listd"], rtol=1e-9, atol=1e-12)
+
+
+def test_screen_with_uncentred_and_badly_scaled_scores(ctx, monkeypatch):
+    """Scores far from the origin (the operand copy is centred on the column means), columns of very different scale, a handful of
+    far outliers (they set the error bound: a wider bar, more survivors, the same answer) and duplicated rows (exact ties)."""
+    rng = np.random.default_rng(99)
+    n, p, m = 40000, 16, 50
+    scale = 10.0 ** rng.uniform(-3, 3, size=p)
+    X = rng.standard_normal((n, p)) * scale + 1.0e4 * scale
+    X[:40] += 300.0 * scale                                          # outliers
+    X[1000:1200] = X[2000:2200]                                      # duplicates
+    Xq = np.vstack([X[2000:2025] + 1e-9 * scale, rng.standard_normal((m - 25, p)) * scale + 1.0e4 * scale])
+    y = (X / scale).sum(axis=1)
+    kw = dict(nlvdis=0, metric="eucl", h=1.5, k=100, nlv=2)
+    a, b, ns, nr = _both(ctx, X, y, Xq, monkeypatch, **kw)
+    assert ns == m
+    _same(a, b)
+    with np.errstate(all="ignore"):
+        ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, 3))
+    assert np.array_equal(a.listnn, ref["listnn"])
+
+
+@pytest.mark.parametrize("c", [dict(n=50000, levels=3, redone=False), dict(n=200000, levels=2, redone=True)])
+def test_screen_on_a_lattice(c, ctx, monkeypatch):
+    """Integer lattice: hundreds (levels = 3: the screen's candidate lists hold them) or thousands (levels = 2: 3125 copies of every
+    point — the lists overflow, the queries are flagged and the exact selection behind the screen does them) of rows at exactly the
+    k-th distance.  Either way: the first k rows in (distance, index) order, as the oracle."""
+    rng = np.random.default_rng(5)
+    n, p, m = c["n"], 6, 14
+    X = rng.integers(0, c["levels"], size=(n, p)).astype(np.float64)
+    Xq = rng.integers(0, c["levels"], size=(m, p)).astype(np.float64)
+    y = X @ np.arange(1.0, p + 1.0) + rng.standard_normal(n)
+    kw = dict(nlvdis=0, metric="eucl", h=2.0, k=150, nlv=2)
+    a, b, ns, nr = _both(ctx, X, y, Xq, monkeypatch, **kw)
+    assert ns == m and nr == (m if c["redone"] else 0)
+    _same(a, b)
+    with np.errstate(all="ignore"):
+        ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, 3))
+    assert np.array_equal(a.listnn, ref["listnn"])
+    assert np.array_equal(a.listd, ref["listd"])
+
+
+def test_screen_with_non_finite_queries_and_scores(ctx, monkeypatch):
+    rng = np.random.default_rng(17)
+    n, p, m = 8000, 10, 37
+    X = rng.standard_normal((n, p))
+    Xq = rng.standard_normal((m, p))
+    y = X[:, 0] - X[:, 1] + 0.1 * rng.standard_normal(n)
+    Xq[3, 2] = np.nan
+    Xq[20, :] = np.inf
+    kw = dict(nlvdis=0, metric="eucl", h=2.0, k=30, nlv=2)
+    a, b, ns, nr = _both(ctx, X, y, Xq, monkeypatch, **kw)
+    assert ns == m and nr == 2
+    assert a.listnn.min() >= 0 and a.listnn.max() < n
+    assert np.all(np.isnan(a.listd[3]))
+    _same(a, b)
+    # a NaN among the training scores: the whole model is done by the exact selection
+    X2 = X.copy(); X2[77, 4] = np.nan
+    Xq2 = rng.standard_normal((5, p))
+    a2, b2, ns2, nr2 = _both(ctx, X2, y, Xq2, monkeypatch, **kw)
+    assert ns2 == 5 and nr2 == 5
+    assert np.array_equal(a2.listnn, b2.listnn)
+
+
+def test_one_shot_call_is_screened_too(ctx):
+    """jch_lwplsr_predict (no prepared handle) builds the operand copy in the ctx workspace per call."""
+    from jchemo_hip import _lib
+    rng = np.random.default_rng(3)
+    n, p, m, k, dd = 9000, 12, 21, 40, 5
+    X = np.asfortranarray(rng.standard_normal((n, p)))
+    Y = np.asfortranarray(X[:, :1] + 0.1 * rng.standard_normal((n, 1)))
+    Zt = np.asfortranarray(rng.standard_normal((n, dd)))
+    Zq = np.asfortranarray(rng.standard_normal((m, dd)))
+    Xq = np.asfortranarray(rng.standard_normal((m, p)))
+    lib = _lib.load()
+    out = {}
+    for tag, env in (("screen", None), ("scan", "0")):
+        if env is not None:
+            os.environ["JCH_KNN_SCREEN"] = env
+        try:
+            pred = np.zeros((m, 3, 1)); ind = np.zeros((m, k), np.int32); dist = np.zeros((m, k)); w = np.zeros((m, k))
+            s0 = ctx.counter(SCREENED)
+            dp = lambda a: a.ctypes.data
+            ctx.check(lib.jch_lwplsr_predict(ctx._h, 0, dp(X), n, p, n, dp(Y), 1, n, dp(Zt), n, dp(Zq), m, dd, dp(Xq), m, m, k, 2.0, 1e-4, 0, 0, 2,
+                                             dp(pred), dp(ind), dp(dist), dp(w)))
+            out[tag] = (pred, ind, dist, w, ctx.counter(SCREENED) - s0)
+        finally:
+            os.environ.pop("JCH_KNN_SCREEN", None)
+    assert out["screen"][4] == m and out["scan"][4] == 0
+    for i in range(4):
+        assert np.array_equal(out["screen"][i], out["scan"][i])
+    d2 = ((Zt[:, None, :] - Zq[None, :, :]) ** 2).sum(axis=2)       # n x m
+    for j in range(m):
+        order = np.lexsort((np.arange(n), d2[:, j]))[:k]
+        assert np.array_equal(out["screen"][1][j], order)

@@ -362,10 +362,15 @@ def test_lwplsr_knn_on_a_lattice(case, J, ctx):
     assert np.array_equal(res.listd, ref["listd"])                 # (square roots of the same small integers)
 
 
-def test_lwplsr_nan_query_row(J, ctx):
-    """A missing value in ONE query row: its scores, hence all its distances, are NaN and no training row ever beats the
+@pytest.mark.parametrize("knn_path", ["default", "JCH_KNN_SCREEN=0", "JCH_KNN_GENERIC=1"])
+def test_lwplsr_nan_query_row(knn_path, J, ctx, monkeypatch):
+    """(Run through the three neighbour searches: the screened one — which hands the NaN query to the exact selection —, the exact
+    scan, and the exact selection for all queries; round 4: the latter gathered from the sentinel index.)
+    A missing value in ONE query row: its scores, hence all its distances, are NaN and no training row ever beats the
     bar.  The reference's arithmetic gives that query NaN predictions (predict on a NaN row) and leaves the others alone;
     the library must do the same and must not gather from the sentinel index (GPU memory fault)."""
+    if knn_path != "default":
+        monkeypatch.setenv(*knn_path.split("="))
     n, p, m = 3000, 40, 9
     X = CO.fill_uniform(20250112, n, p)
     Xq = CO.fill_uniform(20250115, m, p)
