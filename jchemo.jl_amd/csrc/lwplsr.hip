@@ -170,6 +170,11 @@ __global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
     const int seg = blockIdx.x % g.nseg;
     const int q0 = (blockIdx.x / g.nseg) * QB;
     const int nq = min(QB, g.m - q0);
+    if (g.only_flags) {   // behind the screened search: only the query groups with a flagged member are scanned (block-uniform)
+        int any = 0;
+        for (int qq = 0; qq < nq; ++qq) any |= g.only_flags[q0 + qq];
+        if (!any) return;
+    }
     for (int e = tid; e < QB * g.dd; e += NT) {
         const int qq = e / g.dd, c = e - qq * g.dd;
         zq[e] = qq < nq ? g.Zq[(size_t)(q0 + qq) + (size_t)c * (size_t)g.ldzq] : 0.0;
@@ -293,6 +298,12 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
     __shared__ int snn[4];
     const int tid = threadIdx.x;
     const int qi = blockIdx.x, k = g.k;
+    if (g.only_flags) {   // (the members of a scanned group are all finished again: the unflagged ones get the values they have)
+        const int q0 = qi / g.qb * g.qb;
+        int any = 0;
+        for (int qq = q0; qq < min(q0 + g.qb, g.m); ++qq) any |= g.only_flags[qq];
+        if (!any) return;
+    }
     const int ncand = g.nseg * k;
     const double *ck = g.ckey + (size_t)qi * ncand;
     const int *ci = g.cidx + (size_t)qi * ncand;
@@ -803,6 +814,7 @@ struct jch_lwplsr_model {
     std::vector<qmap> qmaps;
     // the operand-ordered f32 copy of the scores for the screened kNN (lwplsr_screen.hip); absent when the score space is too wide
     bool has_screen = false;
+    mutable bool screen_off = false;   // set when a call had a quarter of its queries redone by the exact scan
     knn_screen screen;
     void *screen_mem = nullptr;
 };
@@ -815,11 +827,65 @@ static void lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t
     hipLaunchKernelGGL(k_to_rowmajor, dim3(nbx, ptiles), dim3(256), 0, ctx->stream, dX, ldxd, n, p, Xrm, ldr);
 }
 
+// LDS bytes of the scan for this shape (its envelope: <= 150 KB); wide_out: the JCH_KNN_WIDE=1 measurement variant applies
+size_t jch_knn_scan_lds(int k, int dd, int m, bool *wide_out)
+{
+    // JCH_KNN_WIDE=1 (measurement knob, round 3): eight queries per 512-thread workgroup — half the L2 traffic, the same waves per
+    // CU.  Measured at cfg5: 1.62 ms with 3 row segments, 1.05 with 2, against 0.87 for four queries per 256-thread workgroup:
+    // the scan is not bound by the L2 bytes but by its dependent steps (threshold tests, LDS appends, barriers, sorts), which
+    // eight waves share one candidate bookkeeping for.  Default: off.
+    const char *e_w = getenv("JCH_KNN_WIDE");
+    const bool wide = k <= KNN_CAP - 512 && e_w && atoi(e_w) == 1 && m > 4;
+    if (wide_out) *wide_out = wide;
+    const int qb = wide ? 8 : KNN_QB;
+    return (sizeof(double) + sizeof(int)) * qb * KNN_CAP + sizeof(double) * (qb * (size_t)dd + qb) + sizeof(int) * qb + 64;
+}
+
+// The exact scan + finish (K9 / K9b) for a.m queries; a.only_flags: null, or device flags — only the groups of KNN_QB queries with a
+// flagged member are done (the queries the screened search could not settle).  cbuf: the buffer the segments' candidates go to.
+int32_t jch_launch_knn_scan(jch_ctx *ctx, knn_args a, jch_buf &cbuf)
+{
+    const int64_t n = a.n;
+    const int m = a.m, k = a.k;
+    bool wide = false;
+    const size_t lds = jch_knn_scan_lds(k, a.dd, m, &wide);
+    if (a.only_flags) wide = false;
+    const int nt = wide ? 512 : 256;
+    a.qb = wide ? 8 : KNN_QB;
+    {
+        // row segments: as many as keep every segment at >= 4 trips and the merged candidate lists inside one sort (nseg * k <= KNN_CAP)
+        // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
+        // its own compaction sorts)
+        // (round 3, with the sort-free compactions: 2 segments 0.60 ms, 3: 0.51, 4: 0.59, 5: 0.57, 6: 0.56, 8: 0.59)
+        int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_FCAP / k), n / (4 * nt * KNN_RB)));
+        if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_FCAP / k));
+        a.nseg = nseg;
+        JCH_TRY(jch_reserve(ctx, cbuf, (sizeof(double) + sizeof(int)) * (size_t)m * nseg * k + 256));
+        a.ckey = (double *)cbuf.ptr; a.cidx = (int *)(a.ckey + (size_t)m * nseg * k);
+        static jch_per_device_once attr;
+        if (!attr.done(ctx->device)) {
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<256, KNN_QB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr.mark(ctx->device);
+        }
+        // (round 4, measured and removed: eight queries per 256-thread workgroup with 512-entry candidate buffers — half the score
+        // traffic per query — took 1.1 ms for the scan at cfg5 with half as many workgroups, i.e. the same time per workgroup-query:
+        // the scan is NOT bound by its L2 / Infinity Cache traffic; with a dot-product screen |z|^2 + |zq|^2 - 2 z.zq in front of the
+        // exact distance — half the arithmetic per pair — 1.78 ms: the ~1000 survivors per query and segment each pay a divergent
+        // 20-load recomputation.  Results were identical in both.  What bounds the scan is the dependent chain of a wave's trip.)
+        if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8) * nseg), dim3(512), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB) * nseg), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
+    }
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
 // kNN + weights + batched local fits on device-resident pieces; results to the host.  Xrm / dY / dZt: the model; dZq, dXq: the queries.
 static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64_t p, const double *dY, int64_t q, int64_t ldyd,
                       const double *dZt, int64_t ldztd, const double *dZq, int64_t ldzqd, int64_t dd, const double *dXq, int64_t m,
                       int64_t ldxqd, int32_t k, double h, double tol, int32_t scal, int32_t nlv_lo, int32_t nlv_hi, double *pred,
-                      int32_t *ind_out, double *dist_out, double *w_out, hipEvent_t ev0, const knn_screen *scr)
+                      int32_t *ind_out, double *dist_out, double *w_out, hipEvent_t ev0, const knn_screen *scr, bool *screen_off)
 {
     const int le = nlv_hi - nlv_lo + 1;
     JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * ((size_t)m * k * 2 + (size_t)m * le * q) + sizeof(int) * (size_t)m * k + 256));
@@ -839,17 +905,14 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         // CU.  Measured at cfg5: 1.62 ms with 3 row segments, 1.05 with 2, against 0.87 for four queries per 256-thread workgroup:
         // the scan is not bound by the L2 bytes but by its dependent steps (threshold tests, LDS appends, barriers, sorts), which
         // eight waves share one candidate bookkeeping for.  Default: off.
-        const char *e_w = getenv("JCH_KNN_WIDE");
-        const bool wide = k <= KNN_CAP - 512 && e_w && atoi(e_w) == 1 && m > 4;
-        const int qb = wide ? 8 : KNN_QB, nt = wide ? 512 : 256;
-        const size_t lds = (sizeof(double) + sizeof(int)) * qb * KNN_CAP + sizeof(double) * (qb * (size_t)dd + qb) + sizeof(int) * qb + 64;
+        const size_t lds = jch_knn_scan_lds(k, (int)dd, (int)m, nullptr);
         // outside the scan's envelope (k beyond the candidate buffers, a search space too wide for its LDS, 2^29 rows): the generic
         // selection, one workgroup per query (lwplsr_generic.hip); JCH_KNN_GENERIC=1 forces it (tests)
         const char *e_g = getenv("JCH_KNN_GENERIC");
         // the screened kNN (lwplsr_screen.hip: all pairs in f32 on the matrix cores, exact distances for the survivors only) when the
         // shape is inside its envelope; JCH_KNN_SCREEN=0 selects the exact scan below (A/B runs, tests)
         const char *e_s = getenv("JCH_KNN_SCREEN");
-        const bool screen = !(e_g && atoi(e_g) == 1) && !(e_s && atoi(e_s) == 0) && !a.dbg && jch_knn_screen_shape_ok(n, (int)dd, k);
+        const bool screen = !(e_g && atoi(e_g) == 1) && !(e_s && atoi(e_s) == 0) && !a.dbg && !(screen_off && *screen_off) && jch_knn_screen_shape_ok(n, (int)dd, k);
         if (screen) {
             knn_screen local;
             if (!scr) {   // one-shot call: the model-constant operand copy is rebuilt in the ctx workspace
@@ -865,29 +928,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         if (k > KNN_CAP - 256 || lds > 150 * 1024 || n >= ((int64_t)1 << 29) || (e_g && atoi(e_g) == 1)) {
             JCH_TRY(jch_launch_knn_generic(ctx, a));
         } else {
-        // row segments: as many as keep every segment at >= 4 trips and the merged candidate lists inside one sort (nseg * k <= KNN_CAP)
-        // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
-        // its own compaction sorts)
-        // (round 3, with the sort-free compactions: 2 segments 0.60 ms, 3: 0.51, 4: 0.59, 5: 0.57, 6: 0.56, 8: 0.59)
-        int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_FCAP / k), n / (4 * nt * KNN_RB)));
-        if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_FCAP / k));
-        a.nseg = nseg;
-        JCH_TRY(jch_reserve(ctx, ctx->gemm_b, (sizeof(double) + sizeof(int)) * (size_t)m * nseg * k + 256));
-        a.ckey = (double *)ctx->gemm_b.ptr; a.cidx = (int *)(a.ckey + (size_t)m * nseg * k);
-        static jch_per_device_once attr;
-        if (!attr.done(ctx->device)) {
-            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<256, KNN_QB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_knn_scan<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr.mark(ctx->device);
-        }
-        // (round 4, measured and removed: eight queries per 256-thread workgroup with 512-entry candidate buffers — half the score
-        // traffic per query — took 1.1 ms for the scan at cfg5 with half as many workgroups, i.e. the same time per workgroup-query:
-        // the scan is NOT bound by its L2 / Infinity Cache traffic; with a dot-product screen |z|^2 + |zq|^2 - 2 z.zq in front of the
-        // exact distance — half the arithmetic per pair — 1.78 ms: the ~1000 survivors per query and segment each pay a divergent
-        // 20-load recomputation.  Results were identical in both.  What bounds the scan is the dependent chain of a wave's trip.)
-        if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8) * nseg), dim3(512), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB) * nseg), dim3(256), lds, ctx->stream, a);
-        hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
+        JCH_TRY(jch_launch_knn_scan(ctx, a, ctx->gemm_b));
         }
     }
     ev2 = jch_ev(ctx);
@@ -954,8 +995,12 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
     JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (sflags) {
+        long long redone = 0;
+        for (int i = 0; i < (int)m; ++i) redone += hsf[(size_t)i] ? 1 : 0;
         ctx->knn_screened += (long long)m;
-        for (int i = 0; i < (int)m; ++i) ctx->knn_screen_redone += hsf[(size_t)i] ? 1 : 0;
+        ctx->knn_screen_redone += redone;
+        // a training set whose geometry defeats the screen's error bound (lwplsr_screen.hip): the model stops screening
+        if (screen_off && m >= 8 && redone * 4 > (long long)m) *screen_off = true;
     }
     if (kflags) {   // flagged queries (the exception): refitted by the per-query path, their predictions fetched again
         std::vector<int> only;
@@ -1029,7 +1074,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     hipEvent_t ev0 = jch_ev(ctx);
     lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, Xrm, ldr);
     return lw_run(ctx, Xrm, ldr, n, p, dY, q, ldyd, dZt, ldztd, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol, scal, nlv_lo, nlv_hi, pred,
-                  ind_out, dist_out, w_out, ev0, nullptr);
+                  ind_out, dist_out, w_out, ev0, nullptr, nullptr);
 }
 
 extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *Xtrain, int64_t n, int64_t p, int64_t ldx,
@@ -1167,7 +1212,7 @@ extern "C" int32_t jch_lwplsr_predict_prepared(jch_ctx *ctx, const jch_lwplsr_mo
         dZq = src; ldzqd = m;
     }
     return lw_run(ctx, model->Xrm, model->ldr, model->n, p, model->Y, model->q, model->n, model->Zt, model->n, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol,
-                  scal, nlv_lo, nlv_hi, pred, ind_out, dist_out, w_out, ev0, model->has_screen ? &model->screen : nullptr);
+                  scal, nlv_lo, nlv_hi, pred, ind_out, dist_out, w_out, ev0, model->has_screen ? &model->screen : nullptr, &model->screen_off);
 }
 
 // Weighted (uncorrected) covariance of the columns of A (n x d, d <= 64): S = (A - 1 mu')' D (A - 1 mu'), the

@@ -36,18 +36,21 @@ struct knn_args {
     double *ckey;  // [m][nseg][k] squared distances of every segment's k best (ascending; +inf beyond the segment's rows)
     int *cidx;     // [m][nseg][k]
     int dbg;       // measurement switch (JCH_KNN_DBG; results then wrong by design): 1 = the bar starts at -inf (no candidate is ever kept: the bare scan)
-    const int *only_flags = nullptr;   // k_knn_generic: null, or [m] device flags — only the queries with a non-zero flag are done
+    const int *only_flags = nullptr;   // null, or [m] device flags — only the queries with a non-zero flag are done (k_knn_scan: only their groups of qb)
+    int qb = 4;                        // queries per workgroup of the scan that filled ckey / cidx (k_knn_finish, only_flags)
 };
 
-// lwplsr_screen.hip: the screened kNN (round 4).  Squared distances of ALL (row, query) pairs in f32 on the matrix cores
-// (v_mfma_f32_32x32x2_f32 on norm-augmented operands), an error-bounded bar per query from the k-th smallest GROUP minimum, exact
+// lwplsr_screen.hip: the screened kNN (round 4).  Squared distances of ALL (row, query) pairs on the matrix cores
+// (v_mfma_f32_32x32x16_bf16 on two-piece bf16, norm-augmented operands), an error-bounded bar per query from the k-th smallest GROUP minimum, exact
 // f64 distances only for the survivors (k .. ~1.2 k rows per query); queries the screen cannot settle (non-finite scores, more
 // survivors than the candidate list holds) are flagged and done by k_knn_generic.  Results identical to k_knn_scan's.
 struct knn_screen {          // the model-constant part: built once per prepared model, or per call in the ctx workspace
-    float *Zs = nullptr;     // [ntiles][KG][64 lanes][4] operand-ordered f32 copy of the centred training scores (+ |z|^2 and 1 columns)
+    uint4 *Zs = nullptr;     // [ntiles][KS][64 lanes] operand-ordered two-piece bf16 copy of the centred training scores (+ the |z|^2 and 1 slots)
+    double *Zr = nullptr;    // [n][ldzr] row-major f64 copy of the scores (uncentred, the caller's values): one 8 dd-byte read per exact distance
+    int ldzr = 0;
     double *mu = nullptr;    // [dd] column means the copy is centred on (distances do not depend on them)
     unsigned *hdr = nullptr; // [0] bits of max |z|^2 (f32) over the rows, [1] non-zero: a training score is not finite
-    int KG = 0;              // groups of 8 operand columns: 8 KG >= dd + 2
+    int KS = 0;              // k-steps of 16 operand slots: 16 KS >= 3 dd + 4
     int64_t ntiles = 0;      // 32-row tiles
 };
 bool jch_knn_screen_shape_ok(int64_t n, int dd, int k);
@@ -56,6 +59,10 @@ size_t jch_knn_screen_model_bytes(int64_t n, int dd);
 int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int64_t n, int dd, void *mem, knn_screen *out);
 // flags: [m] device ints, set to 1 for the queries handed to the exact selection (0 otherwise)
 int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen &sc, int *flags);
+
+// lwplsr.hip: the exact scan (k <= 768, LDS for the score space: jch_knn_scan_lds <= 150 KB)
+size_t jch_knn_scan_lds(int k, int dd, int m, bool *wide_out);
+int32_t jch_launch_knn_scan(jch_ctx *ctx, knn_args a, jch_buf &cbuf);
 
 // lwplsr_generic.hip: the paths WITHOUT shape limits (any k <= n, any p, q, nlv) behind the batched kernels' envelope.
 // kNN + weights of all m queries: exact selection of the k smallest distances per query, (distance, index) order, wdist weights

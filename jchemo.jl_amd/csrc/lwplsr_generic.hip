@@ -67,6 +67,11 @@ __global__ __launch_bounds__(KG_NT) void k_knn_generic(knn_args g, kg_scratch sc
     double *d2 = sc.d2 + (size_t)blockIdx.x * (size_t)n;
     double *skey = sc.skey + (size_t)blockIdx.x * K2, *dkey = sc.dkey + (size_t)blockIdx.x * K2;
     int *sidx = sc.sidx + (size_t)blockIdx.x * K2, *didx = sc.didx + (size_t)blockIdx.x * K2;
+    if (g.only_flags) {   // behind the screened search: nothing flagged among this block's queries (the rule) -> one round trip and out
+        int any = 0;
+        for (int qi = blockIdx.x + tid * (int)gridDim.x; qi < g.m; qi += KG_NT * (int)gridDim.x) any |= g.only_flags[qi];
+        if (!__syncthreads_or(any)) return;
+    }
     for (int qi = blockIdx.x; qi < g.m; qi += gridDim.x) {
         if (g.only_flags && !g.only_flags[qi]) continue;       // (block-uniform)
         __syncthreads();

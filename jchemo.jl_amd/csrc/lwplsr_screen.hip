@@ -3,26 +3,35 @@
 //
 // k_knn_scan (lwplsr.hip) evaluates the exact f64 distance of every (row, query) pair on the vector pipe — 40 instructions per
 // pair — and keeps a running bar per query; it is bound by the dependent chain of its trips (0.51 ms per 1000 queries at cfg5,
-// 1e8 pairs).  The f64 matrix pipe runs at the vector rate on this chip, so it cannot screen; the f32 one runs at twice that and
-// takes the whole inner product off the vector pipe.  This path:
+// 1e8 pairs).  The f64 matrix pipe runs at the vector rate on this chip, so it cannot screen; the bf16 one is 32 x faster.  This
+// path:
 //
-//   pack      (once per model)  the training scores, centred on their column means, rounded to f32 and laid out in the operand
-//             order of v_mfma_f32_32x32x2_f32, with two extra operand columns: |z|^2 and 1.  The queries get the matching columns
-//             -2 zq ... , 1, |zq|^2, so that ONE chain of matrix instructions delivers  a_ij ~ |z_i - zq_j|^2  for a 32 x 32 tile of
-//             pairs.
+//   pack      (once per model)  the training scores, centred on their column means, SPLIT into two bf16 pieces z ~ zh + zl
+//             (16 significant bits) and laid out in the operand order of v_mfma_f32_32x32x16_bf16; the queries likewise,
+//             -2 zq ~ qh + ql.  Three operand slots per score column — (zh, qh), (zh, ql), (zl, qh): everything of z.zq but the
+//             zl.ql term — and four more for |z|^2 and |zq|^2 (two bf16 pieces each, against 1), so that ONE chain of matrix
+//             instructions (4 of them for 20 score columns) delivers  a_ij ~ |z_i - zq_j|^2  for a 32 x 32 tile of pairs, in f32.
+//             (First version of the round: f32 operands on v_mfma_f32_32x32x2_f32 — 12 instructions of twice the length per
+//             tile; both passes ran at 0.57 of that pipe's peak: 54 and 86 us at cfg5.)
 //   k_knn_gmin    pass 1 over all pairs: every lane keeps the minimum of a_ij over the rows of a GROUP (16 rows of each of T
-//             tiles).  The k-th smallest of a query's G group minima is an upper bound of its k-th smallest a_ij (k groups hold
-//             k different rows at or below it), and a tight one: with G = 4.5 k it is the ~1.13 k-th smallest.
-//   k_knn_bar     that k-th smallest per query (radix descent on the bit patterns, one wave per query), widened by the error
-//             bound: |a_ij - d_ij^2| <= eps_j = c (max_i |z_i|^2 + |zq_j|^2) for every row, c = (4 K + 16) 2^-23, K = dd + 2
-//             operand columns — twice what K truncating f32 accumulations + the f32 rounding of the operands can lose.  A row
-//             among the exact k nearest (ties included) has a_ij <= tau_j + 2 eps_j.
-//   k_knn_survive pass 2: the same products, every a_ij against the bar; survivors (1.13 k + the ties + the few within 2 eps) go
+//             tiles).  A value with k group minima at or below it is an upper bound of the k-th smallest a_ij (k groups hold k
+//             different rows at or below it), and the k-th smallest group minimum is a tight one: with G = 4.5 k groups it is the
+//             ~1.13 k-th smallest a_ij.
+//   k_knn_bar     that value per query (one wave per query: sampled pivot, value bisection), widened by the error bound:
+//             |a_ij - d_ij^2| <= eps_j = c (max_i |z_i|^2 + |zq_j|^2) for every row (ks_cfac: the 2^-16 of the two-piece operands
+//             against the worst-case distance |z| + |zq|, the dropped zl.ql terms, the two-piece norms, K truncating f32
+//             accumulations; x 1.25).  A row among the exact k nearest (ties included) has a_ij <= tau_j + 2 eps_j.
+//   k_knn_survive pass 2: the same products, every a_ij against the bar; survivors (~1.15 k + the ties + the few within 2 eps) go
 //             through a wave-private LDS list to the query's candidate list.
 //   k_knn_finish_screen  one workgroup per query: EXACT distances of the candidates (the expression and column order of
-//             k_knn_scan: the same bits), (distance, index) order, the k nearest, the weights (the tail shared with k_knn_finish).
-//             A query whose list overflowed or came up short (non-finite scores) is flagged ...
-//   k_knn_generic ... and done by the exact selection of lwplsr_generic.hip (flagged queries only).
+//             k_knn_scan: the same bits) from a row-major f64 copy of the scores, (distance, index) order, the k nearest, the
+//             weights (the tail shared with k_knn_finish).  A query whose list overflowed or came up short (non-finite scores)
+//             is flagged ...
+//   k_knn_scan    ... and done by the exact scan (lwplsr.hip; the groups of four queries with a flagged member only).  The bound
+//             scales with the NORMS of the centred scores, the bar with neighbour DISTANCES: where the k-th distance^2 is below
+//             ~1e-4 of the squared norms (score spaces of low intrinsic dimension and wide range) the bar admits thousands of
+//             rows and most queries end up here; a prepared model that sees a quarter of a call's queries flagged stops
+//             screening (lw_run).
 //
 // Neighbours, their order, distances and weights are identical to k_knn_scan's: the screen only decides WHICH rows get an exact
 // distance, and it never drops a row at or below the exact k-th distance.
@@ -30,27 +39,32 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
+#include <stdio.h>
 
 #include "jch_internal.h"
 #include "lv_device.h"
 #include "lwplsr_dev.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 ks_bf16x8 __attribute__((ext_vector_type(8)));
 
 #define KS_CCAP 2048        // candidate rows per query (global); more survivors: the query is flagged for the generic selection
-#define KS_LCAP 256         // wave-private LDS list of survivors (row << 5 | query column)
+#define KS_S 8              // survivors a (row chunk, query) pair keeps in its own slots of the candidate array; more: the query's overflow list
 #define KS_PAD 1.0e30f      // |z|^2 of the pad rows of the last tile: never below a bar, never a group minimum that counts
 #define KS_MAXSLOTS 1024    // group slots per query tile: G = 2 x slots <= 2048 values per query in k_knn_bar (32 per lane)
 
 struct ks_args {
     knn_args a;
     knn_screen sc;
-    float *Qs;          // [nqt][KG][64][4] query operand
+    uint4 *Qs;          // [nqt][KS][64] query operand (8 bf16 per lane and k-step)
     double *nq;         // [nqt * 32] |zq - mu|^2 of the f32-rounded query (f64 sum of the rounded values)
     float *gmin;        // [nqt][nslots][64]
     float *bar;         // [nqt * 32]
-    int *cnt;           // [nqt * 32]
-    int *cand;          // [m][KS_CCAP]
+    int *cnt;           // [nqt * 32] entries of the query's overflow list
+    int *cand;          // [m][KS_CCAP] overflow list (global atomics: only where one row chunk holds more than KS_S survivors of a query)
+    int *scnt;          // [m][nchunks] survivors of (query, row chunk), at most KS_S
+    int *scand;         // [m][nchunks][KS_S] their rows
     int *flags;         // [m]
     int nqt, nslots, T, gpw, nchunks;
     double cfac;
@@ -76,46 +90,80 @@ __global__ __launch_bounds__(1024) void k_ks_colmean(const double *__restrict__ 
     }
 }
 
-// one thread per (tile, lane): A operand of v_mfma_f32_32x32x2_f32 for k-step j is A[lane % 32][2 j + lane / 32]; four steps per 16-B load
-template <int KG>
+// f32 -> bf16, round to nearest even (Inf stays Inf, NaN stays NaN)
+__device__ __forceinline__ unsigned ks_bf16(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float ks_bf16_f(unsigned b) { return __uint_as_float(b << 16); }
+// the two bf16 pieces of f (hi + lo carries 16 significant bits of f)
+__device__ __forceinline__ void ks_split(float f, unsigned &hi, unsigned &lo)
+{
+    hi = ks_bf16(f);
+    lo = ks_bf16(f - ks_bf16_f(hi));
+}
+
+// Row order of the operand copy (ks_row): tile t holds the rows t, t + ntiles, t + 2 ntiles, ... (local row i <-> row i ntiles + t), and
+// group slot s the tiles s, s + nslots, ...: CONSECUTIVE training rows sit in different tiles and different groups.  Training sets
+// are often ordered (by time, by sample, by class): a query's neighbours are then runs of consecutive rows, and with rows grouped
+// as they come the k-th smallest group minimum would be the distance of the k-th nearest RUN, not row — a useless bar.
+// Operand slots (the K dimension of the products), dd score columns: slot 3 c + t, t = 0, 1, 2 -> A (zh, zh, zl), B (qh, ql, qh);
+// slots 3 dd, 3 dd + 1 -> A the two pieces of |z|^2, B 1; slots 3 dd + 2, 3 dd + 3 -> A 1, B the two pieces of |zq|^2; zero beyond.
+// v_mfma_f32_32x32x16_bf16, k-step s: lane l holds slots 16 s + 8 (l / 32) + 0 .. 7 of row (A) / query (B) l % 32.
+// one thread per (tile, lane)
+template <int KS>
 __global__ __launch_bounds__(256) void k_ks_pack_rows(const double *__restrict__ Zt, int64_t ldzt, int64_t n, int dd, const double *__restrict__ mu,
-                                                      float *__restrict__ Zs, int64_t ntiles, unsigned *__restrict__ hdr)
+                                                      uint4 *__restrict__ Zs, int64_t ntiles, unsigned *__restrict__ hdr, double *__restrict__ Zr, int ldzr)
 {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t tile = gid >> 6;
     const int lane = (int)(gid & 63);
     if (tile >= ntiles) return;
-    const int64_t row = tile * 32 + (lane & 31);
+    const int64_t row = (int64_t)(lane & 31) * ntiles + tile;      // (ks_row: consecutive rows sit in different tiles)
     const int h = lane >> 5;
     const bool live = row < n;
-    float v[KG * 4];
     double nz = 0.0;
     for (int c = 0; c < dd; ++c) {
-        const float f = live ? (float)(Zt[(size_t)row + (size_t)c * (size_t)ldzt] - mu[c]) : 0.0f;
-        nz += (double)f * (double)f;
-#pragma unroll
-        for (int s = 0; s < KG * 4; ++s)
-            if (c == 2 * s + h) v[s] = f;
+        const double zv = live ? Zt[(size_t)row + (size_t)c * (size_t)ldzt] : 0.0;
+        if (live && (c & 1) == h) Zr[(size_t)row * ldzr + c] = zv;      // (the two lanes of a row share the copy)
+        unsigned hi, lo;
+        ks_split((float)(zv - mu[c]), hi, lo);
+        const double zz = (double)ks_bf16_f(hi) + (double)ks_bf16_f(lo);
+        nz += zz * zz;
     }
-    const float nzf = live ? (float)nz : KS_PAD;
+    if (live && h == 1 && ldzr > dd) Zr[(size_t)row * ldzr + dd] = 0.0;
+    float nzf = (float)nz;
+    if ((double)nzf < nz) nzf = __uint_as_float(__float_as_uint(nzf) + 1u);   // (rounded UP: it enters the error bound through hdr[0])
+    unsigned n1, n2;
+    ks_split(live ? (float)nz : KS_PAD, n1, n2);
+    unsigned short v[KS * 8];
 #pragma unroll
-    for (int s = 0; s < KG * 4; ++s) {
-        const int c = 2 * s + h;
-        if (c == dd) v[s] = nzf;
-        else if (c == dd + 1) v[s] = 1.0f;
-        else if (c > dd + 1) v[s] = 0.0f;
+    for (int sl = 0; sl < KS * 8; ++sl) {
+        const int kk = 16 * (sl >> 3) + 8 * h + (sl & 7);
+        const int c = kk / 3, t = kk - 3 * c;
+        unsigned val = 0u;
+        if (c < dd) {
+            unsigned hi, lo;
+            ks_split(live ? (float)(Zt[(size_t)row + (size_t)c * (size_t)ldzt] - mu[c]) : 0.0f, hi, lo);
+            val = t == 2 ? lo : hi;
+        } else if (kk == 3 * dd) val = n1;
+        else if (kk == 3 * dd + 1) val = n2;
+        else if (kk == 3 * dd + 2 || kk == 3 * dd + 3) val = 0x3f80u;          // 1.0
+        v[sl] = (unsigned short)val;
     }
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg)
-        reinterpret_cast<float4 *>(Zs)[((size_t)tile * KG + kg) * 64 + lane] = make_float4(v[4 * kg], v[4 * kg + 1], v[4 * kg + 2], v[4 * kg + 3]);
+    for (int ks = 0; ks < KS; ++ks)
+        Zs[((size_t)tile * KS + ks) * 64 + lane] = make_uint4(v[8 * ks] | ((unsigned)v[8 * ks + 1] << 16), v[8 * ks + 2] | ((unsigned)v[8 * ks + 3] << 16),
+                                                            v[8 * ks + 4] | ((unsigned)v[8 * ks + 5] << 16), v[8 * ks + 6] | ((unsigned)v[8 * ks + 7] << 16));
     if (live && h == 0) {
         if (!(nzf < 1.0e29f)) atomicOr(hdr + 1, 1u);              // NaN / Inf / beyond the pad value: no screen for this model
         else atomicMax(hdr, __float_as_uint(nzf));                // (non-negative floats order like their bits)
     }
 }
 
-// B operand: B[2 j + lane / 32][lane % 32]; one thread per (query tile, lane)
-template <int KG>
+// one thread per (query tile, lane)
+template <int KS>
 __global__ __launch_bounds__(256) void k_ks_pack_queries(ks_args g)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -123,84 +171,102 @@ __global__ __launch_bounds__(256) void k_ks_pack_queries(ks_args g)
     if (qt >= g.nqt) return;
     const int j = qt * 32 + (lane & 31), h = lane >> 5, dd = g.a.dd;
     const bool live = j < g.a.m;
-    float v[KG * 4];
+    const double *zqp = g.a.Zq + (size_t)min(j, g.a.m - 1);
+    unsigned short v[KS * 8];
+    // (this lane's slots first — their loads go out together —, then the norm over all columns)
+    float fv[KS * 8];
+#pragma unroll
+    for (int sl = 0; sl < KS * 8; ++sl) {
+        const int kk = 16 * (sl >> 3) + 8 * h + (sl & 7);
+        const int c = min(kk / 3, dd - 1);
+        fv[sl] = -2.0f * (float)(zqp[(size_t)c * (size_t)g.a.ldzq] - g.sc.mu[c]);
+    }
     double nq = 0.0;
-    for (int c = 0; c < dd; ++c) {
-        const float f = live ? (float)(g.a.Zq[(size_t)j + (size_t)c * (size_t)g.a.ldzq] - g.sc.mu[c]) : 0.0f;
-        nq += (double)f * (double)f;
+    for (int c0 = 0; c0 < dd; c0 += 8) {
+        double x[8], m8[8];
 #pragma unroll
-        for (int s = 0; s < KG * 4; ++s)
-            if (c == 2 * s + h) v[s] = -2.0f * f;
+        for (int cc = 0; cc < 8; ++cc) { const int c = min(c0 + cc, dd - 1); x[cc] = zqp[(size_t)c * (size_t)g.a.ldzq]; m8[cc] = g.sc.mu[c]; }
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+            if (c0 + cc < dd && live) {
+                unsigned hi, lo;
+                ks_split(-2.0f * (float)(x[cc] - m8[cc]), hi, lo);
+                const double qq = 0.5 * ((double)ks_bf16_f(hi) + (double)ks_bf16_f(lo));
+                nq += qq * qq;
+            }
     }
-    const float nqf = (float)nq;
+    float nqf = (float)nq;
+    if ((double)nqf < nq) nqf = __uint_as_float(__float_as_uint(nqf) + 1u);
+    unsigned m1, m2;
+    ks_split((float)nq, m1, m2);
 #pragma unroll
-    for (int s = 0; s < KG * 4; ++s) {
-        const int c = 2 * s + h;
-        if (c == dd) v[s] = 1.0f;
-        else if (c == dd + 1) v[s] = nqf;
-        else if (c > dd + 1) v[s] = 0.0f;
+    for (int sl = 0; sl < KS * 8; ++sl) {
+        const int kk = 16 * (sl >> 3) + 8 * h + (sl & 7);
+        const int c = kk / 3, t = kk - 3 * c;
+        unsigned val = 0u;
+        if (c < dd) {
+            unsigned hi, lo;
+            ks_split(live ? fv[sl] : 0.0f, hi, lo);
+            val = t == 1 ? lo : hi;
+        } else if (kk == 3 * dd || kk == 3 * dd + 1) val = 0x3f80u;
+        else if (kk == 3 * dd + 2) val = m1;
+        else if (kk == 3 * dd + 3) val = m2;
+        v[sl] = (unsigned short)val;
     }
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg)
-        reinterpret_cast<float4 *>(g.Qs)[((size_t)qt * KG + kg) * 64 + lane] = make_float4(v[4 * kg], v[4 * kg + 1], v[4 * kg + 2], v[4 * kg + 3]);
+    for (int ks = 0; ks < KS; ++ks)
+        g.Qs[((size_t)qt * KS + ks) * 64 + lane] = make_uint4(v[8 * ks] | ((unsigned)v[8 * ks + 1] << 16), v[8 * ks + 2] | ((unsigned)v[8 * ks + 3] << 16),
+                                                              v[8 * ks + 4] | ((unsigned)v[8 * ks + 5] << 16), v[8 * ks + 6] | ((unsigned)v[8 * ks + 7] << 16));
     if (h == 0) g.nq[j] = (double)nqf;
 }
 
 // ---------------------------------------------------------------- the two passes over all pairs
-template <int KG>
-__device__ __forceinline__ void ks_load_b(const ks_args &g, int qt, int lane, float (&b)[KG * 4])
+template <int KS>
+__device__ __forceinline__ void ks_load_b(const ks_args &g, int qt, int lane, uint4 (&b)[KS])
 {
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-        const float4 t = reinterpret_cast<const float4 *>(g.Qs)[((size_t)qt * KG + kg) * 64 + lane];
-        b[4 * kg] = t.x; b[4 * kg + 1] = t.y; b[4 * kg + 2] = t.z; b[4 * kg + 3] = t.w;
-    }
+    for (int ks = 0; ks < KS; ++ks) b[ks] = g.Qs[((size_t)qt * KS + ks) * 64 + lane];
 }
-template <int KG>
-__device__ __forceinline__ void ks_load_a(const float *__restrict__ Zs, int64_t tile, int lane, float4 (&a)[KG])
+template <int KS>
+__device__ __forceinline__ void ks_load_a(const uint4 *__restrict__ Zs, int64_t tile, int lane, uint4 (&a)[KS])
 {
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) a[kg] = reinterpret_cast<const float4 *>(Zs)[((size_t)tile * KG + kg) * 64 + lane];
+    for (int ks = 0; ks < KS; ++ks) a[ks] = Zs[((size_t)tile * KS + ks) * 64 + lane];
 }
 // a_ij of one 32 x 32 tile of pairs: acc[r] of lane l <-> row 8 (r / 4) + 4 (l / 32) + r % 4, query column l % 32
-template <int KG>
-__device__ __forceinline__ f32x16 ks_tile(const float4 (&a)[KG], const float (&b)[KG * 4])
+template <int KS>
+__device__ __forceinline__ f32x16 ks_tile(const uint4 (&a)[KS], const uint4 (&b)[KS])
 {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg].x, b[4 * kg], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg].y, b[4 * kg + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg].z, b[4 * kg + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg].w, b[4 * kg + 3], acc, 0, 0, 0);
-    }
+    for (int ks = 0; ks < KS; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ks_bf16x8, a[ks]), __builtin_bit_cast(ks_bf16x8, b[ks]), acc, 0, 0, 0);
     return acc;
 }
 
 // wave item w: query tile w % nqt, row chunk w / nqt (gpw groups of T tiles); the four waves of a workgroup share the chunk
-template <int KG>
+template <int KS>
 __global__ __launch_bounds__(256) void k_knn_gmin(ks_args g)
 {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (int64_t)g.nqt * g.nchunks) return;
     const int qt = (int)(w % g.nqt), chunk = (int)(w / g.nqt);
-    float b[KG * 4];
-    ks_load_b<KG>(g, qt, lane, b);
+    uint4 b[KS];
+    ks_load_b<KS>(g, qt, lane, b);
     for (int gi = 0; gi < g.gpw; ++gi) {
         const int slot = chunk * g.gpw + gi;
         if (slot >= g.nslots) break;
-        const int64_t t0 = (int64_t)slot * g.T, t1 = min(g.sc.ntiles, t0 + g.T);
         float mn = __builtin_inff();
-        float4 a[KG], an[KG];
-        ks_load_a<KG>(g.sc.Zs, t0, lane, a);
-        for (int64_t t = t0; t < t1; ++t) {
-            ks_load_a<KG>(g.sc.Zs, min(t + 1, t1 - 1), lane, an);           // next tile's operands behind this tile's products
-            const f32x16 acc = ks_tile<KG>(a, b);
+        uint4 a[KS], an[KS];
+        ks_load_a<KS>(g.sc.Zs, slot, lane, a);
+        for (int64_t t = slot; t < g.sc.ntiles; t += g.nslots) {            // (the slot's tiles: slot, slot + nslots, ...)
+            ks_load_a<KS>(g.sc.Zs, t + g.nslots < g.sc.ntiles ? t + g.nslots : t, lane, an);   // next tile's operands behind this tile's products
+            const f32x16 acc = ks_tile<KS>(a, b);
 #pragma unroll
             for (int r = 0; r < 16; ++r) mn = fminf(mn, acc[r]);            // (a NaN never replaces a number)
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) a[kg] = an[kg];
+            for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
         }
         g.gmin[((size_t)qt * g.nslots + slot) * 64 + lane] = mn;
     }
@@ -223,14 +289,52 @@ __global__ __launch_bounds__(256) void k_knn_bar(ks_args g)
         const unsigned bits = __float_as_uint(f);
         u[i] = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);         // unsigned order = float order (a_ij may round below zero)
     }
+    // ANY value with at least k group minima at or below it is a valid bar, so the wave first sorts 64 SAMPLES (each lane's first
+    // value) across its lanes and bisects for the smallest sample with >= k values at or below it: 6 counting steps instead of
+    // the 32 of the exact radix descent, for a bar ~G / 128 ranks above the k-th smallest (+3 % survivors at cfg5).  No sample
+    // with k values below it (k close to G): the exact k-th smallest.
     unsigned prefix = 0u;
-    int need = g.a.k;
-    for (int bit = 31; bit >= 0; --bit) {                                   // (wave-uniform)
-        const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
-        int cnt0 = 0;
+    {
+        unsigned sv = u[0];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) cnt0 += __popcll(__ballot((u[i] & (hi | (1u << bit))) == prefix));
-        if (need > cnt0) { need -= cnt0; prefix |= 1u << bit; }
+        for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const unsigned pv = (unsigned)__shfl_xor((int)sv, stride, 64);
+                const bool keepmin = ((lane & stride) == 0) == ((lane & size) == 0);
+                sv = keepmin ? min(pv, sv) : max(pv, sv);
+            }
+        auto count = [&](unsigned pv) {
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) n += __popcll(__ballot(u[i] <= pv));
+            return n;
+        };
+        if (count((unsigned)__shfl((int)sv, 63, 64)) >= g.a.k) {
+            int lo = 0, hi = 63;
+            while (lo < hi) {                                               // (wave-uniform)
+                const int mid = (lo + hi) >> 1;
+                if (count((unsigned)__shfl((int)sv, mid, 64)) >= g.a.k) hi = mid; else lo = mid + 1;
+            }
+            // (lo_v, hi_v]: the sample below the pivot (fewer than k values at or below it) and the pivot; five steps of value
+            // bisection on the keys bring the bar within 1 / 32 of a sample gap of the k-th smallest
+            unsigned hi_v = (unsigned)__shfl((int)sv, hi, 64);
+            unsigned lo_v = hi > 0 ? (unsigned)__shfl((int)sv, hi - 1, 64) : 0u;
+            for (int it = 0; it < 5 && hi_v - lo_v > 1u; ++it) {
+                const unsigned mid_v = lo_v + ((hi_v - lo_v) >> 1);
+                if (count(mid_v) >= g.a.k) hi_v = mid_v; else lo_v = mid_v;
+            }
+            prefix = hi_v;
+        } else {
+            int need = g.a.k;
+            for (int bit = 31; bit >= 0; --bit) {                           // (wave-uniform)
+                const unsigned hi = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+                int cnt0 = 0;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) cnt0 += __popcll(__ballot((u[i] & (hi | (1u << bit))) == prefix));
+                if (need > cnt0) { need -= cnt0; prefix |= 1u << bit; }
+            }
+        }
     }
     if (lane == 0) {
         const unsigned bits = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
@@ -248,53 +352,68 @@ __global__ __launch_bounds__(256) void k_knn_bar(ks_args g)
     }
 }
 
-template <int KG>
+// Survivors: a (row chunk, query) pair has its OWN slots in the candidate array — one writer, no counter to share.  (First version:
+// every survivor took its place in the query's list by a global atomic with return; 245 k of them per call at cfg5, on 1000
+// addresses, across 8 L2s: 50 of the kernel's 70 us.)
+template <int KS>
 __global__ __launch_bounds__(256) void k_knn_survive(ks_args g)
 {
-    __shared__ unsigned list[4][KS_LCAP];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int wcnt[4][32];
+    __shared__ int wlist[4][32 * KS_S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31;
     const int64_t w = (int64_t)blockIdx.x * 4 + wv;
     if (w >= (int64_t)g.nqt * g.nchunks) return;
     const int qt = (int)(w % g.nqt), chunk = (int)(w / g.nqt);
-    float b[KG * 4];
-    ks_load_b<KG>(g, qt, lane, b);
-    const float barv = g.bar[qt * 32 + (lane & 31)];
-    unsigned *mine = list[wv];
-    int nl = 0;                                                             // (wave-uniform)
-    const unsigned long long below = (1ull << lane) - 1ull;
-    auto flush = [&]() {
-        wavesync();
-        for (int e = lane; e < nl; e += 64) {
-            const unsigned ent = mine[e];
-            const int j = qt * 32 + (int)(ent & 31u);
-            const int pos = atomicAdd(&g.cnt[j], 1);
-            if (pos < KS_CCAP && j < g.a.m) g.cand[(size_t)j * KS_CCAP + pos] = (int)(ent >> 5);
-        }
-        wavesync();
-        nl = 0;
+    const int j = qt * 32 + col;
+    uint4 b[KS];
+    ks_load_b<KS>(g, qt, lane, b);
+    const float barv = g.bar[j];
+    int *mycnt = wcnt[wv], *mylist = wlist[wv];
+    if (lane < 32) mycnt[lane] = 0;
+    wavesync();
+    // the chunk's tiles: slots s0 .. s1 - 1 of every stride of nslots tiles
+    const int s0 = chunk * g.gpw, s1 = min(g.nslots, s0 + g.gpw);
+    const int64_t nt = g.sc.ntiles;
+    auto next_tile = [&](int64_t t) {                                       // the tile after t in this chunk's order, or -1
+        int64_t base = t / g.nslots * g.nslots;
+        int64_t tn = t + 1;
+        if (tn - base >= s1) { base += g.nslots; tn = base + s0; }
+        return tn < nt ? tn : (int64_t)-1;
     };
-    const int64_t t0 = (int64_t)chunk * g.gpw * g.T, t1 = min(g.sc.ntiles, t0 + (int64_t)g.gpw * g.T);
-    if (t0 >= t1) return;
-    float4 a[KG], an[KG];
-    ks_load_a<KG>(g.sc.Zs, t0, lane, a);
-    for (int64_t t = t0; t < t1; ++t) {
-        ks_load_a<KG>(g.sc.Zs, min(t + 1, t1 - 1), lane, an);
-        const f32x16 acc = ks_tile<KG>(a, b);
-        const unsigned rowbase = (unsigned)(t * 32) + 4u * (unsigned)(lane >> 5);
+    uint4 a[KS], an[KS];
+    int64_t t = s0 < nt ? (int64_t)s0 : (int64_t)-1;
+    if (t >= 0) ks_load_a<KS>(g.sc.Zs, t, lane, a);
+    while (t >= 0) {
+        const int64_t tn = next_tile(t);
+        ks_load_a<KS>(g.sc.Zs, tn >= 0 ? tn : t, lane, an);
+        const f32x16 acc = ks_tile<KS>(a, b);
+        const int lrow = 4 * (lane >> 5);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool pass = acc[r] <= barv;
-            const unsigned long long m = __ballot(pass);
-            if (m) {                                                        // (wave-uniform; 1 register in 7 at cfg5)
-                if (nl + 64 > KS_LCAP) flush();
-                if (pass) mine[nl + __popcll(m & below)] = ((rowbase + 8u * (r >> 2) + (r & 3)) << 5) | (unsigned)(lane & 31);
-                nl += __popcll(m);
+            if (__ballot(pass)) {                                           // (wave-uniform; 1 register in 7 at cfg5)
+                if (pass) {
+                    const int row = (lrow + 8 * (r >> 2) + (r & 3)) * (int)nt + (int)t;   // (ks_row)
+                    const int pos = atomicAdd(&mycnt[col], 1);              // (LDS)
+                    if (pos < KS_S) mylist[col * KS_S + pos] = row;
+                    else if (j < g.a.m) {                                   // the chunk's slots are full: the query's overflow list
+                        const int op = atomicAdd(&g.cnt[j], 1);
+                        if (op < KS_CCAP) g.cand[(size_t)j * KS_CCAP + op] = row;
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) a[kg] = an[kg];
+        for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
+        t = tn;
     }
-    if (nl) flush();
+    wavesync();
+    // every (query, chunk) count is written (zero included): nothing to clear between calls
+    if (lane < 32 && j < g.a.m) g.scnt[(size_t)j * g.nchunks + chunk] = min(mycnt[lane], KS_S);
+    for (int e = lane; e < 32 * KS_S; e += 64) {
+        const int c2 = e / KS_S, pos = e - c2 * KS_S, j2 = qt * 32 + c2;
+        if (j2 < g.a.m && pos < min(mycnt[c2], KS_S)) g.scand[((size_t)j2 * g.nchunks + chunk) * KS_S + pos] = mylist[e];
+    }
 }
 
 // one workgroup per query: exact distances of the candidates, order, weights — or the flag for the generic selection
@@ -308,45 +427,82 @@ __global__ __launch_bounds__(256) void k_knn_finish_screen(ks_args g)
     __shared__ double sred[8];
     __shared__ double smed[2];
     __shared__ int snn[4];
+    __shared__ int tot;
     const int tid = threadIdx.x;
     const int qi = blockIdx.x, k = g.a.k, dd = g.a.dd;
-    const int c = g.cnt[qi];
-    if (c > KS_CCAP || c < k) {                                   // (block-uniform) overflow, or a query / model with non-finite scores
+    if (tid == 0) tot = 0;
+    for (int e = tid; e < dd; e += 256) zq[e] = g.a.Zq[(size_t)qi + (size_t)e * (size_t)g.a.ldzq];
+    __syncthreads();
+    // gather: the chunks' own slots, then the overflow list (any order: the sort below is by (distance, index))
+    const int oc = g.cnt[qi];
+    const int *sc_ = g.scnt + (size_t)qi * g.nchunks;
+    for (int ch = tid; ch < g.nchunks; ch += 256) {
+        const int cc = sc_[ch];
+        if (cc > 0) {
+            const int pos = atomicAdd(&tot, cc);
+            const int *src = g.scand + ((size_t)qi * g.nchunks + ch) * KS_S;
+            for (int i = 0; i < cc; ++i)
+                if (pos + i < KS_CCAP) idx[pos + i] = src[i];
+        }
+    }
+    for (int e = tid; e < min(oc, KS_CCAP); e += 256) {
+        const int pos = atomicAdd(&tot, 1);
+        if (pos < KS_CCAP) idx[pos] = g.cand[(size_t)qi * KS_CCAP + e];
+    }
+    __syncthreads();
+    const int c = tot;
+    if (oc > KS_CCAP || c > KS_CCAP || c < k) {                   // (block-uniform) overflow, or a query / model with non-finite scores
         if (tid == 0) g.flags[qi] = 1;
         return;
     }
     if (tid == 0) g.flags[qi] = 0;
-    for (int e = tid; e < dd; e += 256) zq[e] = g.a.Zq[(size_t)qi + (size_t)e * (size_t)g.a.ldzq];
-    __syncthreads();
     int cap = 64;
     while (cap < c) cap <<= 1;
-    const int *cd = g.cand + (size_t)qi * KS_CCAP;
+    const int dbg = g.a.dbg;                                      // JCH_KNN_SCREEN_DBG (measurement; results wrong by design): 2 no distances, 4 no sort, 8 no tail
     for (int e = tid; e < cap; e += 256) {
         double acc = __builtin_inf();
         int row = 0x7fffffff;
         if (e < c) {
-            row = cd[e];
+            row = idx[e];
             acc = 0.0;
-            // (the expression and column order of k_knn_scan: the same bits)
-            for (int c0 = 0; c0 < dd; c0 += 8) {
-                double x[8];
+            if (dbg & 2) acc = (double)row;
+            else {
+                // (the expression and column order of k_knn_scan: the same bits; the row from the row-major copy: 8 dd contiguous
+                // bytes instead of dd sectors 8 n bytes apart — those were 40 of this kernel's 66 us at cfg5)
+                const double2 *zr = reinterpret_cast<const double2 *>(g.sc.Zr + (size_t)row * g.sc.ldzr);
+                for (int c0 = 0; c0 < dd; c0 += 16) {
+                    double2 x[8];
 #pragma unroll
-                for (int cc = 0; cc < 8; ++cc) x[cc] = g.a.Zt[(size_t)row + (size_t)min(c0 + cc, dd - 1) * (size_t)g.a.ldzt];
+                    for (int cc = 0; cc < 8; ++cc) x[cc] = zr[min(c0 / 2 + cc, (g.sc.ldzr >> 1) - 1)];
 #pragma unroll
-                for (int cc = 0; cc < 8; ++cc)
-                    if (c0 + cc < dd) { const double d = x[cc] - zq[c0 + cc]; acc += d * d; }
+                    for (int cc = 0; cc < 8; ++cc) {
+                        if (c0 + 2 * cc < dd) { const double d = x[cc].x - zq[c0 + 2 * cc]; acc += d * d; }
+                        if (c0 + 2 * cc + 1 < dd) { const double d = x[cc].y - zq[c0 + 2 * cc + 1]; acc += d * d; }
+                    }
+                }
             }
         }
         key[e] = acc; idx[e] = row;
     }
-    bitonic_sort_n<256>(key, idx, cap);
+    if (!(dbg & 4)) bitonic_sort_n<256>(key, idx, cap);
+    else __syncthreads();
     for (int e = tid; e < k; e += 256) { okey[e] = key[e]; oidx[e] = idx[e]; }
     __syncthreads();
+    if (dbg & 8) { for (int e = tid; e < k; e += 256) { g.a.ind[(size_t)qi * k + e] = oidx[e]; g.a.dist[(size_t)qi * k + e] = okey[e]; g.a.w[(size_t)qi * k + e] = 1.0; } return; }
     knn_finish_tail(g.a, qi, k, key, okey, oidx, sred, smed, snn);
 }
 
 // ---------------------------------------------------------------- host
-static int ks_kg(int dd) { return (dd + 2 + 7) / 8; }
+// |a_ij - d_ij^2| <= ks_cfac (|z_i|^2 + |zq_j|^2): two-piece operands (each within 2^-16 of its value) against the worst-case
+// distance |z| + |zq|: 2^-14; the dropped zl.ql terms and the two-piece norms: 2 x 2^-16; K = 3 dd + 4 truncating f32 accumulations
+// of terms that sum to <= 2.02 (|z|^2 + |zq|^2) in absolute value: 2.02 K 2^-23; the f32 roundings of the centred values and the
+// f64 arithmetic of the exact distance: 2^-20.  x 1.25.
+static double ks_cfac(int dd)
+{
+    const double K = 3.0 * dd + 4.0;
+    return 1.25 * (6.103515625e-05 + 2.0 * 1.52587890625e-05 + 2.02 * K * 1.1920928955078125e-07 + 9.5367431640625e-07);
+}
+static int ks_ks(int dd) { return (3 * dd + 4 + 15) / 16; }   // k-steps of 16 operand slots
 
 // the shapes the screen takes: score space of at most 62 dimensions (8 operand-column groups), k inside the finishing kernel's
 // buffers, and enough rows for the groups to give a bar the candidate list can hold the survivors of
@@ -372,21 +528,24 @@ bool jch_knn_screen_shape_ok(int64_t n, int dd, int k)
 size_t jch_knn_screen_model_bytes(int64_t n, int dd)
 {
     const size_t ntiles = (size_t)((n + 31) / 32);
-    return ntiles * (size_t)ks_kg(dd) * 64 * 16 + (((size_t)dd * sizeof(double) + 255) & ~(size_t)255) + 256;
+    const size_t ldzr = ((size_t)dd + 1) & ~(size_t)1;
+    return ntiles * (size_t)ks_ks(dd) * 64 * 16 + (((size_t)n * ldzr * sizeof(double) + 255) & ~(size_t)255) + (((size_t)dd * sizeof(double) + 255) & ~(size_t)255) + 256;
 }
 int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int64_t n, int dd, void *mem, knn_screen *out)
 {
     knn_screen sc;
-    sc.KG = ks_kg(dd);
+    sc.KS = ks_ks(dd);
     sc.ntiles = (n + 31) / 32;
     char *b = (char *)mem;
-    sc.Zs = (float *)b; b += (size_t)sc.ntiles * sc.KG * 64 * 16;
+    sc.Zs = (uint4 *)b; b += (size_t)sc.ntiles * sc.KS * 64 * 16;
+    sc.ldzr = (dd + 1) & ~1;
+    sc.Zr = (double *)b; b += ((size_t)n * sc.ldzr * sizeof(double) + 255) & ~(size_t)255;
     sc.mu = (double *)b; b += ((size_t)dd * sizeof(double) + 255) & ~(size_t)255;
     sc.hdr = (unsigned *)b;
     hipLaunchKernelGGL(k_ks_colmean, dim3(dd), dim3(1024), 0, ctx->stream, dZt, ldzt, n, sc.mu, sc.hdr);
     const unsigned nb = (unsigned)((sc.ntiles * 64 + 255) / 256);
-#define KS_PACK(KGv) case KGv: hipLaunchKernelGGL((k_ks_pack_rows<KGv>), dim3(nb), dim3(256), 0, ctx->stream, dZt, ldzt, n, dd, sc.mu, sc.Zs, sc.ntiles, sc.hdr); break
-    switch (sc.KG) { KS_PACK(1); KS_PACK(2); KS_PACK(3); KS_PACK(4); KS_PACK(5); KS_PACK(6); KS_PACK(7); KS_PACK(8);
+#define KS_PACK(KSv) case KSv: hipLaunchKernelGGL((k_ks_pack_rows<KSv>), dim3(nb), dim3(256), 0, ctx->stream, dZt, ldzt, n, dd, sc.mu, sc.Zs, sc.ntiles, sc.hdr, sc.Zr, sc.ldzr); break
+    switch (sc.KS) { KS_PACK(1); KS_PACK(2); KS_PACK(3); KS_PACK(4); KS_PACK(5); KS_PACK(6); KS_PACK(7); KS_PACK(8); KS_PACK(9); KS_PACK(10); KS_PACK(11); KS_PACK(12);
     default: return jch_fail(ctx, JCH_EINVAL, "internal: screened kNN: %d score dimensions", dd); }
 #undef KS_PACK
     JCH_HIP(ctx, hipGetLastError());
@@ -394,25 +553,25 @@ int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int6
     return JCH_OK;
 }
 
-template <int KG>
+template <int KS>
 static void ks_launch_passes(jch_ctx *ctx, const ks_args &g)
 {
     const int64_t waves = (int64_t)g.nqt * g.nchunks;
     const unsigned nb = (unsigned)((waves + 3) / 4);
-    hipLaunchKernelGGL((k_ks_pack_queries<KG>), dim3((unsigned)((g.nqt * 64 + 255) / 256)), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL((k_ks_pack_queries<KS>), dim3((unsigned)((g.nqt * 64 + 255) / 256)), dim3(256), 0, ctx->stream, g);
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL((k_knn_gmin<KG>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL((k_knn_gmin<KS>), dim3(nb), dim3(256), 0, ctx->stream, g);
     const int G = 2 * g.nslots, nbq = (g.nqt * 32 + 3) / 4;
     if (G <= 256) hipLaunchKernelGGL((k_knn_bar<4>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else if (G <= 512) hipLaunchKernelGGL((k_knn_bar<8>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else if (G <= 1024) hipLaunchKernelGGL((k_knn_bar<16>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL((k_knn_bar<32>), dim3(nbq), dim3(256), 0, ctx->stream, g);
-    hipLaunchKernelGGL((k_knn_survive<KG>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL((k_knn_survive<KS>), dim3(nb), dim3(256), 0, ctx->stream, g);
 }
 
 int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen &sc, int *flags)
 {
-    if (!jch_knn_screen_shape_ok(a.n, a.dd, a.k) || sc.KG != ks_kg(a.dd)) return jch_fail(ctx, JCH_EINVAL, "internal: screened kNN: shape outside its envelope");
+    if (!jch_knn_screen_shape_ok(a.n, a.dd, a.k) || sc.KS != ks_ks(a.dd)) return jch_fail(ctx, JCH_EINVAL, "internal: screened kNN: shape outside its envelope");
     ks_args g;
     g.a = a; g.sc = sc;
     int64_t ntiles;
@@ -421,36 +580,51 @@ int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen 
     // groups per wave: ~6 wave items per SIMD of the chip
     g.gpw = (int)std::max<int64_t>(1, ((int64_t)g.nslots * g.nqt) / ((int64_t)ctx->cus * 4 * 6));
     if (const char *e = getenv("JCH_KNN_SCREEN_GPW")) g.gpw = std::max(1, atoi(e));
+    // (the chunks' own candidate slots: m x chunks x KS_S ints — at most 1 GB)
+    g.gpw = (int)std::max<int64_t>(g.gpw, ((int64_t)a.m * g.nslots * KS_S * 4 + ((int64_t)1 << 30) - 1) >> 30);
     g.nchunks = (g.nslots + g.gpw - 1) / g.gpw;
-    const int K = a.dd + 2;
-    g.cfac = (4.0 * K + 16.0) * 1.1920928955078125e-07;   // x 2^-23
+    g.cfac = ks_cfac(a.dd);
     const size_t mpad = (size_t)g.nqt * 32;
-    const size_t b_qs = (size_t)g.nqt * sc.KG * 64 * 16, b_nq = mpad * sizeof(double), b_gmin = (size_t)g.nqt * g.nslots * 64 * sizeof(float),
-                 b_bar = mpad * sizeof(float), b_cnt = mpad * sizeof(int), b_cand = (size_t)a.m * KS_CCAP * sizeof(int);
+    const size_t b_qs = (size_t)g.nqt * sc.KS * 64 * 16, b_nq = mpad * sizeof(double), b_gmin = (size_t)g.nqt * g.nslots * 64 * sizeof(float),
+                 b_bar = mpad * sizeof(float), b_cnt = mpad * sizeof(int), b_cand = (size_t)a.m * KS_CCAP * sizeof(int),
+                 b_scnt = (size_t)a.m * g.nchunks * sizeof(int), b_scand = b_scnt * KS_S;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, up(b_qs) + up(b_nq) + up(b_gmin) + up(b_bar) + up(b_cnt) + up(b_cand) + 256));
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, up(b_qs) + up(b_nq) + up(b_gmin) + up(b_bar) + up(b_cnt) + up(b_cand) + up(b_scnt) + up(b_scand) + 256));
     char *b = (char *)ctx->gemm_b.ptr;
-    g.Qs = (float *)b; b += up(b_qs);
+    g.Qs = (uint4 *)b; b += up(b_qs);
     g.nq = (double *)b; b += up(b_nq);
     g.gmin = (float *)b; b += up(b_gmin);
     g.bar = (float *)b; b += up(b_bar);
     g.cnt = (int *)b; b += up(b_cnt);
-    g.cand = (int *)b;
+    g.cand = (int *)b; b += up(b_cand);
+    g.scnt = (int *)b; b += up(b_scnt);
+    g.scand = (int *)b;
     g.flags = flags;
-    switch (sc.KG) {
-    case 1: ks_launch_passes<1>(ctx, g); break;
-    case 2: ks_launch_passes<2>(ctx, g); break;
-    case 3: ks_launch_passes<3>(ctx, g); break;
-    case 4: ks_launch_passes<4>(ctx, g); break;
-    case 5: ks_launch_passes<5>(ctx, g); break;
-    case 6: ks_launch_passes<6>(ctx, g); break;
-    case 7: ks_launch_passes<7>(ctx, g); break;
-    default: ks_launch_passes<8>(ctx, g); break;
+#define KS_PASSES(KSv) case KSv: ks_launch_passes<KSv>(ctx, g); break
+    switch (sc.KS) { KS_PASSES(1); KS_PASSES(2); KS_PASSES(3); KS_PASSES(4); KS_PASSES(5); KS_PASSES(6); KS_PASSES(7); KS_PASSES(8); KS_PASSES(9);
+    KS_PASSES(10); KS_PASSES(11); default: ks_launch_passes<12>(ctx, g); break; }
+#undef KS_PASSES
+    if (const char *e = getenv("JCH_KNN_SCREEN_DBG")) {
+        g.a.dbg = atoi(e);
+        if (g.a.dbg & 1) {   // survivors per query (host sync; measurement only)
+            std::vector<int> hc(mpad), hs((size_t)a.m * g.nchunks);
+            JCH_HIP(ctx, hipMemcpyAsync(hc.data(), g.cnt, sizeof(int) * mpad, hipMemcpyDeviceToHost, ctx->stream));
+            JCH_HIP(ctx, hipMemcpyAsync(hs.data(), g.scnt, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+            JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            long long tot = 0, ovf = 0; int mx = 0, over256 = 0;
+            for (int i = 0; i < a.m; ++i) {
+                int c = hc[i];
+                for (int ch = 0; ch < g.nchunks; ++ch) c += hs[(size_t)i * g.nchunks + ch];
+                tot += c; ovf += hc[i]; mx = std::max(mx, c); over256 += c > 256;
+            }
+            fprintf(stderr, "[jch] screened kNN: m=%d k=%d T=%d slots=%d gpw=%d chunks=%d survivors mean %.1f max %d, %d lists > 256, %lld through the overflow lists\n", a.m, a.k,
+                    g.T, g.nslots, g.gpw, g.nchunks, (double)tot / a.m, mx, over256, ovf);
+        }
     }
     hipLaunchKernelGGL(k_knn_finish_screen, dim3((unsigned)a.m), dim3(256), sizeof(double) * (size_t)a.dd, ctx->stream, g);
     JCH_HIP(ctx, hipGetLastError());
-    // the flagged queries (the exception; every workgroup of a 64-block grid looks at its queries' flags and leaves)
+    // the flagged queries (the exception): the exact scan, for the groups of four queries with a flagged member
     knn_args ag = a;
     ag.only_flags = g.flags;
-    return jch_launch_knn_generic(ctx, ag);
+    return jch_launch_knn_scan(ctx, ag, ctx->lw_work);
 }

@@ -116,6 +116,35 @@ def test_screen_on_a_lattice(c, ctx, monkeypatch):
     assert np.array_equal(a.listd, ref["listd"])
 
 
+def test_screen_with_sorted_rows_and_a_wide_range(ctx, monkeypatch):
+    """Training rows SORTED along a dominant score of wide range: (1) a query's neighbours are runs of consecutive rows — the operand
+    copy deals consecutive rows to different tiles and groups, or the group minima would say nothing; (2) the k-th distance^2 is
+    ~1e-6 of the squared norms, far below the screen's error bound: most queries are flagged and redone by the exact scan, and the
+    prepared model stops screening after such a call.  The answers do not change."""
+    rng = np.random.default_rng(23)
+    n, p, m = 60000, 3, 45
+    X = rng.standard_normal((n, p)) * np.array([50.0, 0.1, 0.1])
+    X = X[np.argsort(X[:, 0])]
+    Xq = rng.standard_normal((m, p)) * np.array([50.0, 0.1, 0.1])
+    y = X[:, 0] + rng.standard_normal(n)
+    kw = dict(nlvdis=0, metric="eucl", h=2.0, k=200, nlv=2)
+    fm = P.lwplsr(X, y, ctx=ctx, **kw)
+    s0, r0 = ctx.counter(SCREENED), ctx.counter(REDONE)
+    a = P.lwplsr_predict(fm, Xq, nlv=range(0, 3), ctx=ctx)
+    assert ctx.counter(SCREENED) - s0 == m and ctx.counter(REDONE) - r0 > m // 4
+    a2 = P.lwplsr_predict(fm, Xq, nlv=range(0, 3), ctx=ctx)          # the model has stopped screening
+    assert ctx.counter(SCREENED) - s0 == m
+    _same(a, a2)
+    with np.errstate(all="ignore"):
+        ref = O.lwplsr_predict(O.lwplsr(X, y, **kw), Xq, nlv=range(0, 3))
+    assert np.array_equal(a.listnn, ref["listnn"])
+    # the same rows in the same order with a narrow range (every score of unit scale): the screen settles every query
+    X1 = X / np.array([50.0, 0.1, 0.1]); Xq1 = Xq / np.array([50.0, 0.1, 0.1])
+    a3, b3, ns, nr = _both(ctx, X1, y, Xq1, monkeypatch, **kw)
+    assert ns == m and nr == 0
+    _same(a3, b3)
+
+
 def test_screen_with_non_finite_queries_and_scores(ctx, monkeypatch):
     rng = np.random.default_rng(17)
     n, p, m = 8000, 10, 37
