@@ -57,42 +57,7 @@ __global__ __launch_bounds__(256) void k_to_rowmajor(const double *__restrict__ 
 #define KNN_CB 8        // score columns loaded together
 
 // (bitonic_sort_n, knn_finish_tail: lwplsr_dev.h — shared with lwplsr_screen.hip)
-// The same network run by ONE wave (no workgroup barrier between the passes: a wave's LDS operations complete in order): the four
-// waves of a scan workgroup sort the four queries' buffers side by side — 7 us per 1024 entries against 14 us x 4 queries with
-// the workgroup-wide sort, which was half of the scan's time (JCH_KNN_DBG=1 measures the scan without any candidate kept).
-template <int PP>   // PP = pairs per lane and pass = cap / 128 (1 for cap <= 128): all of a pass's loads go out together
-__device__ __forceinline__ void bitonic_sort_wave_pp(double *key, int *idx, int cap)
-{
-    const int lane = threadIdx.x & 63;
-    for (int size = 2; size <= cap; size <<= 1) {
-        for (int stride = size >> 1, ls = 31 - __builtin_clz(size >> 1); stride > 0; stride >>= 1, --ls) {
-            wavesync();
-            double a[PP], b[PP];
-            int ia[PP], ib[PP], lo[PP];
-#pragma unroll
-            for (int u = 0; u < PP; ++u) {
-                const int t = lane + 64 * u;
-                lo[u] = ((t >> ls) << (ls + 1)) | (t & (stride - 1));
-                const int l = t < cap / 2 ? lo[u] : 0;
-                a[u] = key[l]; b[u] = key[l + stride]; ia[u] = idx[l]; ib[u] = idx[l + stride];
-            }
-#pragma unroll
-            for (int u = 0; u < PP; ++u) {
-                const bool up = ((lo[u] & size) == 0);
-                const bool gt = (a[u] > b[u]) || (a[u] == b[u] && ia[u] > ib[u]) || (a[u] != a[u] && b[u] == b[u]);   // NaN sorts last
-                if (lane + 64 * u < cap / 2 && gt == up) { key[lo[u]] = b[u]; key[lo[u] + stride] = a[u]; idx[lo[u]] = ib[u]; idx[lo[u] + stride] = ia[u]; }
-            }
-        }
-    }
-    wavesync();
-}
-__device__ static void bitonic_sort_wave(double *key, int *idx, int cap)
-{
-    if (cap <= 128) bitonic_sort_wave_pp<1>(key, idx, cap);
-    else if (cap == 256) bitonic_sort_wave_pp<2>(key, idx, cap);
-    else if (cap == 512) bitonic_sort_wave_pp<4>(key, idx, cap);
-    else bitonic_sort_wave_pp<8>(key, idx, cap);
-}
+// (bitonic_sort_wave: lwplsr_dev.h)
 // Compaction WITHOUT a sort (one wave, a query's candidate buffer of c0 <= KNN_CAP unordered entries): any bar tau' that leaves
 // at least k entries <= tau' is a valid bar, so the wave sorts 64 SAMPLES of the keys across its lanes (21 shuffle passes),
 // bisects for the smallest sample with >= k keys at or below it (6 counting steps: 16 compares + ballots per lane), and moves

@@ -97,6 +97,68 @@ __device__ static void bitonic_sort_n(double *key, int *idx, int cap)
     __syncthreads();
 }
 
+__device__ __forceinline__ void knn_wavesync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// The same network run by ONE wave (no workgroup barrier between the passes: a wave's LDS operations complete in order): the four
+// waves of a scan workgroup sort the four queries' buffers side by side — 7 us per 1024 entries against 14 us x 4 queries with
+// the workgroup-wide sort, which was half of the scan's time (JCH_KNN_DBG=1 measures the scan without any candidate kept).
+template <int PP>   // PP = pairs per lane and pass = cap / 128 (1 for cap <= 128): all of a pass's loads go out together
+__device__ __forceinline__ void bitonic_sort_wave_pp(double *key, int *idx, int cap)
+{
+    const int lane = threadIdx.x & 63;
+    for (int size = 2; size <= cap; size <<= 1) {
+        for (int stride = size >> 1, ls = 31 - __builtin_clz(size >> 1); stride > 0; stride >>= 1, --ls) {
+            knn_wavesync();
+            double a[PP], b[PP];
+            int ia[PP], ib[PP], lo[PP];
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const int t = lane + 64 * u;
+                lo[u] = ((t >> ls) << (ls + 1)) | (t & (stride - 1));
+                const int l = t < cap / 2 ? lo[u] : 0;
+                a[u] = key[l]; b[u] = key[l + stride]; ia[u] = idx[l]; ib[u] = idx[l + stride];
+            }
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const bool up = ((lo[u] & size) == 0);
+                const bool gt = (a[u] > b[u]) || (a[u] == b[u] && ia[u] > ib[u]) || (a[u] != a[u] && b[u] == b[u]);   // NaN sorts last
+                if (lane + 64 * u < cap / 2 && gt == up) { key[lo[u]] = b[u]; key[lo[u] + stride] = a[u]; idx[lo[u]] = ib[u]; idx[lo[u] + stride] = ia[u]; }
+            }
+        }
+    }
+    knn_wavesync();
+}
+__device__ static void bitonic_sort_wave(double *key, int *idx, int cap)
+{
+    if (cap <= 128) bitonic_sort_wave_pp<1>(key, idx, cap);
+    else if (cap == 256) bitonic_sort_wave_pp<2>(key, idx, cap);
+    else if (cap == 512) bitonic_sort_wave_pp<4>(key, idx, cap);
+    else bitonic_sort_wave_pp<8>(key, idx, cap);
+}
+
+// 64 (key, idx) pairs, one per lane, into ascending (key, idx) order across the lanes of a wave: the bitonic network on registers
+// (21 exchange steps through the lanes, no LDS, no barrier)
+__device__ __forceinline__ void knn_sort64_lanes(double &kv, int &iv)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const double pk = __shfl_xor(kv, stride, 64);
+            const int pi = __shfl_xor(iv, stride, 64);
+            const bool keepmin = ((lane & stride) == 0) == ((lane & size) == 0);
+            const bool p_first = (pk < kv) || (pk == kv && pi < iv);      // the partner's pair comes before mine
+            const bool m_first = (kv < pk) || (kv == pk && iv < pi);
+            const bool take = keepmin ? p_first : m_first;
+            kv = take ? pk : kv;
+            iv = take ? pi : iv;
+        }
+}
+
 // The tail shared by the finishing kernels (k_knn_finish, k_knn_finish_screen): okey / oidx [kk] hold the query's nearest squared
 // distances and rows in (distance, index) order (sentinels +inf / 0x7fffffff where fewer than kk were found); writes the neighbour
 // list, the distances and the wdist weights (src/wdist.jl:64-75).  256 threads; key: scratch of >= kk doubles; every thread calls.
@@ -120,23 +182,56 @@ __device__ static void knn_finish_tail(const knn_args &g, int qi, int kk, double
     __syncthreads();
     // wdist (src/wdist.jl:64-75): median, MAD, cutoff, exp weights, / max, NaN -> 1, then the tol clamp
     const double med = (kk & 1) ? okey[kk / 2] : 0.5 * (okey[kk / 2 - 1] + okey[kk / 2]);
-    // the median of |d - med| by RANK COUNTING (was a second sort): entry e's rank among the kk deviations in the order of the
-    // sort it replaces — by value, then by position, NaN last — is the number of entries that come before it
-    int nn = 0;
-    for (int e = tid; e < kk; e += 256) { const double v = fabs(okey[e] - med); key[e] = v; nn += v == v ? 1 : 0; }
-    for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
-    if (lane == 0) snn[wv] = nn;
-    if (tid < 2) smed[tid] = __builtin_nan("");                // (a target place among the NaNs stays NaN)
-    __syncthreads();
-    nn = snn[0] + snn[1] + snn[2] + snn[3];
+    // the median of |d - med|: the values at the places t0, t1 of the kk deviations in ascending order, NaN last.
     const int t1 = kk / 2, t0 = (kk & 1) ? -1 : kk / 2 - 1;
-    for (int e = tid; e < kk; e += 256) {
-        const double v = key[e];
-        if (v != v) continue;
-        int r = 0;
-        for (int f = 0; f < kk; ++f) { const double u = key[f]; r += (u < v || (u == v && f < e)) ? 1 : 0; }
-        if (r == t1) smed[1] = v;
-        if (r == t0) smed[0] = v;
+    const double dlast = okey[kk - 1];
+    if (med == med && fabs(med) < __builtin_inf() && dlast == dlast && fabs(dlast) < __builtin_inf()) {   // (block-uniform)
+        // All distances finite (they ascend; holes, NaN, would be last).  The deviations are then two monotone runs — descending up
+        // to the first distance >= med, ascending from there — and an entry's place in their merged order is its place in its own
+        // run plus a binary search of the other (round 4; was a count over all kk entries per entry: kk^2 steps, 10 of the
+        // finishing kernel's 55 us at cfg5).  Ties: the descending run's entries first — any order of equal values puts the same
+        // VALUE at a place.
+        for (int e = tid; e < kk; e += 256) key[e] = fabs(okey[e] - med);
+        if (tid == 0) snn[0] = kk;
+        if (tid < 2) smed[tid] = __builtin_nan("");
+        __syncthreads();
+        for (int e = tid; e < kk; e += 256)
+            if (okey[e] >= med && (e == 0 || okey[e - 1] < med)) snn[0] = e;
+        __syncthreads();
+        const int p = snn[0];
+        for (int e = tid; e < kk; e += 256) {
+            const double v = key[e];
+            int r;
+            if (e < p) {            // descending run, read backwards: ascending; entries of the other run strictly below v come first
+                int lo = 0, hi = kk - p;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[p + mid] < v) lo = mid + 1; else hi = mid; }
+                r = (p - 1 - e) + lo;
+            } else {                // ascending run; entries of the other run at or below v come first
+                int lo = 0, hi = p;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[p - 1 - mid] <= v) lo = mid + 1; else hi = mid; }
+                r = (e - p) + lo;
+            }
+            if (r == t1) smed[1] = v;
+            if (r == t0) smed[0] = v;
+        }
+    } else {
+        // (non-finite distances) by RANK COUNTING: entry e's place — by value, then by position, NaN last — is the number of entries
+        // that come before it
+        int nn = 0;
+        for (int e = tid; e < kk; e += 256) { const double v = fabs(okey[e] - med); key[e] = v; nn += v == v ? 1 : 0; }
+        for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
+        if (lane == 0) snn[wv] = nn;
+        if (tid < 2) smed[tid] = __builtin_nan("");                // (a target place among the NaNs stays NaN)
+        __syncthreads();
+        nn = snn[0] + snn[1] + snn[2] + snn[3];
+        for (int e = tid; e < kk; e += 256) {
+            const double v = key[e];
+            if (v != v) continue;
+            int r = 0;
+            for (int f = 0; f < kk; ++f) { const double u = key[f]; r += (u < v || (u == v && f < e)) ? 1 : 0; }
+            if (r == t1) smed[1] = v;
+            if (r == t0) smed[0] = v;
+        }
     }
     __syncthreads();
     const double zmad = 1.4826 * ((kk & 1) ? smed[1] : 0.5 * (smed[0] + smed[1]));

@@ -63,10 +63,10 @@ struct ks_args {
     float *bar;         // [nqt * 32]
     int *cnt;           // [nqt * 32] entries of the query's overflow list
     int *cand;          // [m][KS_CCAP] overflow list (global atomics: only where one row chunk holds more than KS_S survivors of a query)
-    int *scnt;          // [m][nchunks] survivors of (query, row chunk), at most KS_S
-    int *scand;         // [m][nchunks][KS_S] their rows
+    int *scand;         // [m][nchunks][KS_S] rows of the survivors of (query, row chunk), -1 in the unused places: every place is
+                        // written by the pair's one wave on every call (32 contiguous bytes), nothing to clear, no count to read
     int *flags;         // [m]
-    int nqt, nslots, T, gpw, nchunks;
+    int nqt, nslots, T, gpw, nchunks, qw;   // qw: tiles of 32 queries per wave item (1, 2)
     double cfac;
 };
 
@@ -244,31 +244,70 @@ __device__ __forceinline__ f32x16 ks_tile(const uint4 (&a)[KS], const uint4 (&b)
     return acc;
 }
 
-// wave item w: query tile w % nqt, row chunk w / nqt (gpw groups of T tiles); the four waves of a workgroup share the chunk
-template <int KS>
+// Workgroup -> (row chunk, four query groups), XCD-aware: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+// workgroup b runs on XCD b % 8; all the workgroups of a row chunk are given the same residue — the chunk's operand tiles cross the
+// fabric once, into ONE L2, and every other wave that needs them hits there (the operand copy, 12.8 MB at cfg5, does not fit one L2:
+// with chunks dealt to all XCDs every XCD pulled all of it from the Infinity Cache, one tile ahead of its use).
+__device__ __forceinline__ bool ks_item(const ks_args &g, int nqg, int &qg, int &chunk)
+{
+    const int nqb = (nqg + 3) >> 2;
+    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+    chunk = (i / nqb) * 8 + xcd;
+    qg = (i % nqb) * 4 + (int)(threadIdx.x >> 6);
+    return chunk < g.nchunks && qg < nqg;
+}
+
+// wave item: query group qg (QW tiles of 32 queries: every loaded row operand serves 32 QW queries — with QW = 1 both passes
+// ran into the L2 bandwidth: 4 KB of operand per 1024 pairs, 17 TB/s at cfg5), row chunk w / nqg (gpw group slots); the four waves of
+// a workgroup share the chunk
+template <int KS, int QW>
 __global__ __launch_bounds__(256) void k_knn_gmin(ks_args g)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= (int64_t)g.nqt * g.nchunks) return;
-    const int qt = (int)(w % g.nqt), chunk = (int)(w / g.nqt);
-    uint4 b[KS];
-    ks_load_b<KS>(g, qt, lane, b);
+    const int nqg = (g.nqt + QW - 1) / QW;
+    int qg, chunk;
+    if (!ks_item(g, nqg, qg, chunk)) return;
+    uint4 b[QW][KS];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) ks_load_b<KS>(g, min(qg * QW + u, g.nqt - 1), lane, b[u]);
     for (int gi = 0; gi < g.gpw; ++gi) {
         const int slot = chunk * g.gpw + gi;
         if (slot >= g.nslots) break;
-        float mn = __builtin_inff();
-        uint4 a[KS], an[KS];
-        ks_load_a<KS>(g.sc.Zs, slot, lane, a);
-        for (int64_t t = slot; t < g.sc.ntiles; t += g.nslots) {            // (the slot's tiles: slot, slot + nslots, ...)
-            ks_load_a<KS>(g.sc.Zs, t + g.nslots < g.sc.ntiles ? t + g.nslots : t, lane, an);   // next tile's operands behind this tile's products
-            const f32x16 acc = ks_tile<KS>(a, b);
+        float mn[QW];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mn = fminf(mn, acc[r]);            // (a NaN never replaces a number)
+        for (int u = 0; u < QW; ++u) mn[u] = __builtin_inff();
+        // the slot's tiles (slot, slot + nslots, ...) through two operand buffers, the next tile's loads behind this tile's products.
+        // (Written as one buffer + a copy at the end of the iteration the compiler waited for the loads at the copies, and without the
+        // scheduling barriers it sank them to their use: every tile then waited for its own operands — 25 us instead of 12.)
+        uint4 a0[KS], a1[KS];
+        auto tile_min = [&](const uint4 (&a)[KS]) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
+            for (int u = 0; u < QW; ++u) {
+                const f32x16 acc = ks_tile<KS>(a, b[u]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mn[u] = fminf(mn[u], acc[r]);  // (a NaN never replaces a number)
+            }
+        };
+        int64_t t = slot;
+        ks_load_a<KS>(g.sc.Zs, t, lane, a0);
+        for (;;) {
+            const int64_t t1 = t + g.nslots;
+            const bool has1 = t1 < g.sc.ntiles;
+            ks_load_a<KS>(g.sc.Zs, has1 ? t1 : t, lane, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            tile_min(a0);
+            if (!has1) break;
+            const int64_t t2 = t1 + g.nslots;
+            const bool has2 = t2 < g.sc.ntiles;
+            ks_load_a<KS>(g.sc.Zs, has2 ? t2 : t1, lane, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            tile_min(a1);
+            if (!has2) break;
+            t = t2;
         }
-        g.gmin[((size_t)qt * g.nslots + slot) * 64 + lane] = mn;
+#pragma unroll
+        for (int u = 0; u < QW; ++u)
+            if (qg * QW + u < g.nqt) g.gmin[((size_t)(qg * QW + u) * g.nslots + slot) * 64 + lane] = mn[u];
     }
 }
 
@@ -354,22 +393,52 @@ __global__ __launch_bounds__(256) void k_knn_bar(ks_args g)
 
 // Survivors: a (row chunk, query) pair has its OWN slots in the candidate array — one writer, no counter to share.  (First version:
 // every survivor took its place in the query's list by a global atomic with return; 245 k of them per call at cfg5, on 1000
-// addresses, across 8 L2s: 50 of the kernel's 70 us.)
-template <int KS>
+// addresses, across 8 L2s: 50 of the kernel's 70 us.)  Inside the tile loop a survivor only goes to a wave-private list (its place
+// from the ballot: no atomic, no wait); ks_place hands the list's entries to their queries' slots when the wave is done, or the
+// list full.
+#define KS_LCAP 512         // wave-private list of survivors: row << 6 | query column (0 .. 63)
+// (Measured and dropped: the exact distance of every entry computed here, as it is placed — the ~230 k random 160-byte reads per call
+// overlapping the other waves' products instead of standing in the finishing kernel: survive 36 -> 77 us at three waves per SIMD,
+// the finishing kernel unchanged at 45: what costs there is the NUMBER of scattered sectors it reads, the rows' and the
+// candidates'.)  (The fields by value: a reference to the kernel's argument block would put a copy of the block on the stack.)
+__device__ __noinline__ void ks_place(int *cand, int *cnt, int m, const unsigned *list, int nl, int *mycnt, int *myslots, int qbase)
+{
+    const int lane = threadIdx.x & 63;
+    wavesync();
+    for (int e = lane; e < nl; e += 64) {
+        const unsigned ent = list[e];
+        const int c2 = (int)(ent & 63u), row = (int)(ent >> 6), j = qbase + c2;
+        const int pos = atomicAdd(&mycnt[c2], 1);                           // (LDS)
+        if (pos < KS_S) myslots[c2 * KS_S + pos] = row;
+        else if (j < m) {                                                   // the chunk's slots are full: the query's overflow list
+            const int op = atomicAdd(&cnt[j], 1);
+            if (op < KS_CCAP) cand[(size_t)j * KS_CCAP + op] = row;
+        }
+    }
+    wavesync();
+}
+
+template <int KS, int QW>
 __global__ __launch_bounds__(256) void k_knn_survive(ks_args g)
 {
-    __shared__ int wcnt[4][32];
-    __shared__ int wlist[4][32 * KS_S];
+    __shared__ int wcnt[4][32 * QW];
+    __shared__ int wslots[4][32 * QW * KS_S];
+    __shared__ unsigned wlist[4][KS_LCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31;
-    const int64_t w = (int64_t)blockIdx.x * 4 + wv;
-    if (w >= (int64_t)g.nqt * g.nchunks) return;
-    const int qt = (int)(w % g.nqt), chunk = (int)(w / g.nqt);
-    const int j = qt * 32 + col;
-    uint4 b[KS];
-    ks_load_b<KS>(g, qt, lane, b);
-    const float barv = g.bar[j];
-    int *mycnt = wcnt[wv], *mylist = wlist[wv];
-    if (lane < 32) mycnt[lane] = 0;
+    const int nqg = (g.nqt + QW - 1) / QW;
+    int qg, chunk;
+    if (!ks_item(g, nqg, qg, chunk)) return;
+    uint4 b[QW][KS];
+    float barv[QW];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+        const int qt = min(qg * QW + u, g.nqt - 1);
+        ks_load_b<KS>(g, qt, lane, b[u]);
+        barv[u] = qg * QW + u < g.nqt ? g.bar[qt * 32 + col] : -__builtin_inff();
+    }
+    int *mycnt = wcnt[wv], *myslots = wslots[wv];
+    unsigned *mylist = wlist[wv];
+    for (int e = lane; e < 32 * QW; e += 64) mycnt[e] = 0;
     wavesync();
     // the chunk's tiles: slots s0 .. s1 - 1 of every stride of nslots tiles
     const int s0 = chunk * g.gpw, s1 = min(g.nslots, s0 + g.gpw);
@@ -380,39 +449,61 @@ __global__ __launch_bounds__(256) void k_knn_survive(ks_args g)
         if (tn - base >= s1) { base += g.nslots; tn = base + s0; }
         return tn < nt ? tn : (int64_t)-1;
     };
-    uint4 a[KS], an[KS];
-    int64_t t = s0 < nt ? (int64_t)s0 : (int64_t)-1;
-    if (t >= 0) ks_load_a<KS>(g.sc.Zs, t, lane, a);
-    while (t >= 0) {
-        const int64_t tn = next_tile(t);
-        ks_load_a<KS>(g.sc.Zs, tn >= 0 ? tn : t, lane, an);
-        const f32x16 acc = ks_tile<KS>(a, b);
-        const int lrow = 4 * (lane >> 5);
+    const int lrow = 4 * (lane >> 5);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int nl = 0;                                                             // (wave-uniform)
+    auto tile_test = [&](const uint4 (&a)[KS], int64_t t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool pass = acc[r] <= barv;
-            if (__ballot(pass)) {                                           // (wave-uniform; 1 register in 7 at cfg5)
-                if (pass) {
-                    const int row = (lrow + 8 * (r >> 2) + (r & 3)) * (int)nt + (int)t;   // (ks_row)
-                    const int pos = atomicAdd(&mycnt[col], 1);              // (LDS)
-                    if (pos < KS_S) mylist[col * KS_S + pos] = row;
-                    else if (j < g.a.m) {                                   // the chunk's slots are full: the query's overflow list
-                        const int op = atomicAdd(&g.cnt[j], 1);
-                        if (op < KS_CCAP) g.cand[(size_t)j * KS_CCAP + op] = row;
+        for (int u = 0; u < QW; ++u) {
+            const f32x16 acc = ks_tile<KS>(a, b[u]);
+            // all 16 comparisons first (their masks in scalar registers), then the branches: written as compare-and-branch per
+            // register every branch waited for its own comparison — 25 of the kernel's 40 us
+            unsigned long long m[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = __ballot(acc[r] <= barv[u]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (m[r]) {                                                 // (wave-uniform; 1 register in 7 at cfg5)
+                    if (nl > KS_LCAP - 64) { ks_place(g.cand, g.cnt, g.a.m, mylist, nl, mycnt, myslots, qg * QW * 32); nl = 0; }
+                    if ((m[r] >> lane) & 1ull) {
+                        const unsigned row = (unsigned)((lrow + 8 * (r >> 2) + (r & 3)) * (int)nt + (int)t);   // (ks_row)
+                        mylist[nl + __popcll(m[r] & below)] = (row << 6) | (unsigned)(32 * u + col);
                     }
+                    nl += __popcll(m[r]);
                 }
             }
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
-        t = tn;
+    };
+    // (two operand buffers, as in k_knn_gmin)
+    uint4 a0[KS], a1[KS];
+    int64_t t = s0 < nt ? (int64_t)s0 : (int64_t)-1;
+    if (t >= 0) ks_load_a<KS>(g.sc.Zs, t, lane, a0);
+    while (t >= 0) {
+        const int64_t t1 = next_tile(t);
+        ks_load_a<KS>(g.sc.Zs, t1 >= 0 ? t1 : t, lane, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_test(a0, t);
+        if (t1 < 0) break;
+        const int64_t t2 = next_tile(t1);
+        ks_load_a<KS>(g.sc.Zs, t2 >= 0 ? t2 : t1, lane, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_test(a1, t1);
+        t = t2;
     }
+    if (nl) ks_place(g.cand, g.cnt, g.a.m, mylist, nl, mycnt, myslots, qg * QW * 32);
     wavesync();
-    // every (query, chunk) count is written (zero included): nothing to clear between calls
-    if (lane < 32 && j < g.a.m) g.scnt[(size_t)j * g.nchunks + chunk] = min(mycnt[lane], KS_S);
-    for (int e = lane; e < 32 * KS_S; e += 64) {
-        const int c2 = e / KS_S, pos = e - c2 * KS_S, j2 = qt * 32 + c2;
-        if (j2 < g.a.m && pos < min(mycnt[c2], KS_S)) g.scand[((size_t)j2 * g.nchunks + chunk) * KS_S + pos] = mylist[e];
+    // this chunk's slots of every query of the group: all KS_S places (-1 beyond the count), 32 contiguous bytes per query
+    for (int e = lane; e < 32 * QW; e += 64) {
+        const int j = qg * QW * 32 + e;
+        if (j < g.a.m) {
+            const int cc = min(mycnt[e], KS_S);
+            int v[KS_S];
+#pragma unroll
+            for (int i = 0; i < KS_S; ++i) v[i] = i < cc ? myslots[e * KS_S + i] : -1;
+            int4 *dst = reinterpret_cast<int4 *>(g.scand + ((size_t)j * g.nchunks + chunk) * KS_S);
+#pragma unroll
+            for (int i = 0; i < KS_S / 4; ++i) dst[i] = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        }
     }
 }
 
@@ -432,17 +523,27 @@ __global__ __launch_bounds__(256) void k_knn_finish_screen(ks_args g)
     const int qi = blockIdx.x, k = g.a.k, dd = g.a.dd;
     if (tid == 0) tot = 0;
     for (int e = tid; e < dd; e += 256) zq[e] = g.a.Zq[(size_t)qi + (size_t)e * (size_t)g.a.ldzq];
+    for (int e = tid; e < k; e += 256) { okey[e] = __builtin_inf(); oidx[e] = 0x7fffffff; }
     __syncthreads();
-    // gather: the chunks' own slots, then the overflow list (any order: the sort below is by (distance, index))
+    // gather: the chunks' own slots (one contiguous read of the query's nchunks x 32 bytes), then the overflow list (any order: the
+    // entries are put in (distance, index) order below)
+    const int dbg = g.a.dbg;   // JCH_KNN_SCREEN_DBG (measurement; results then wrong by design): 2 no distances, 4 no ordering, 8 no tail, 16 no gather
     const int oc = g.cnt[qi];
-    const int *sc_ = g.scnt + (size_t)qi * g.nchunks;
+    const int4 *sl = reinterpret_cast<const int4 *>(g.scand + (size_t)qi * g.nchunks * KS_S);
+    if (dbg & 16) { for (int e = tid; e < k + 20; e += 256) idx[e] = e * 37; if (tid == 0) tot = k + 20; }
+    else
     for (int ch = tid; ch < g.nchunks; ch += 256) {
-        const int cc = sc_[ch];
+        int v[KS_S];
+#pragma unroll
+        for (int i = 0; i < KS_S / 4; ++i) { const int4 t4 = sl[ch * (KS_S / 4) + i]; v[4 * i] = t4.x; v[4 * i + 1] = t4.y; v[4 * i + 2] = t4.z; v[4 * i + 3] = t4.w; }
+        int cc = 0;
+#pragma unroll
+        for (int i = 0; i < KS_S; ++i) cc += v[i] >= 0 ? 1 : 0;
         if (cc > 0) {
             const int pos = atomicAdd(&tot, cc);
-            const int *src = g.scand + ((size_t)qi * g.nchunks + ch) * KS_S;
-            for (int i = 0; i < cc; ++i)
-                if (pos + i < KS_CCAP) idx[pos + i] = src[i];
+#pragma unroll
+            for (int i = 0; i < KS_S; ++i)
+                if (i < cc && pos + i < KS_CCAP) idx[pos + i] = v[i];
         }
     }
     for (int e = tid; e < min(oc, KS_CCAP); e += 256) {
@@ -456,39 +557,66 @@ __global__ __launch_bounds__(256) void k_knn_finish_screen(ks_args g)
         return;
     }
     if (tid == 0) g.flags[qi] = 0;
-    int cap = 64;
+    int cap = 256;
     while (cap < c) cap <<= 1;
-    const int dbg = g.a.dbg;                                      // JCH_KNN_SCREEN_DBG (measurement; results wrong by design): 2 no distances, 4 no sort, 8 no tail
     for (int e = tid; e < cap; e += 256) {
         double acc = __builtin_inf();
         int row = 0x7fffffff;
         if (e < c) {
             row = idx[e];
             acc = 0.0;
-            if (dbg & 2) acc = (double)row;
-            else {
-                // (the expression and column order of k_knn_scan: the same bits; the row from the row-major copy: 8 dd contiguous
-                // bytes instead of dd sectors 8 n bytes apart — those were 40 of this kernel's 66 us at cfg5)
-                const double2 *zr = reinterpret_cast<const double2 *>(g.sc.Zr + (size_t)row * g.sc.ldzr);
-                for (int c0 = 0; c0 < dd; c0 += 16) {
-                    double2 x[8];
+            if (dbg & 2) { acc = (double)((row * 2654435761u) >> 8); key[e] = acc; continue; }
+            // (the expression and column order of k_knn_scan: the same bits; the row from the row-major copy: 8 dd contiguous bytes
+            // in whole 64-byte sectors instead of dd sectors 8 n bytes apart — those were 40 of this kernel's 66 us at cfg5)
+            const double2 *zr = reinterpret_cast<const double2 *>(g.sc.Zr + (size_t)row * g.sc.ldzr);
+            for (int c0 = 0; c0 < dd; c0 += 16) {
+                double2 x[8];
 #pragma unroll
-                    for (int cc = 0; cc < 8; ++cc) x[cc] = zr[min(c0 / 2 + cc, (g.sc.ldzr >> 1) - 1)];
+                for (int cc = 0; cc < 8; ++cc) x[cc] = zr[min(c0 / 2 + cc, (g.sc.ldzr >> 1) - 1)];
 #pragma unroll
-                    for (int cc = 0; cc < 8; ++cc) {
-                        if (c0 + 2 * cc < dd) { const double d = x[cc].x - zq[c0 + 2 * cc]; acc += d * d; }
-                        if (c0 + 2 * cc + 1 < dd) { const double d = x[cc].y - zq[c0 + 2 * cc + 1]; acc += d * d; }
-                    }
+                for (int cc = 0; cc < 8; ++cc) {
+                    if (c0 + 2 * cc < dd) { const double d = x[cc].x - zq[c0 + 2 * cc]; acc += d * d; }
+                    if (c0 + 2 * cc + 1 < dd) { const double d = x[cc].y - zq[c0 + 2 * cc + 1]; acc += d * d; }
                 }
             }
         }
         key[e] = acc; idx[e] = row;
     }
-    if (!(dbg & 4)) bitonic_sort_n<256>(key, idx, cap);
-    else __syncthreads();
-    for (int e = tid; e < k; e += 256) { okey[e] = key[e]; oidx[e] = idx[e]; }
     __syncthreads();
-    if (dbg & 8) { for (int e = tid; e < k; e += 256) { g.a.ind[(size_t)qi * k + e] = oidx[e]; g.a.dist[(size_t)qi * k + e] = okey[e]; g.a.w[(size_t)qi * k + e] = 1.0; } return; }
+    if (dbg & 4) { for (int e = tid; e < k; e += 256) { okey[e] = key[e]; oidx[e] = idx[e]; } }
+    else
+    if (c <= 256) {
+        // four segments of 64 entries, each put in order by one wave on its registers, then MERGED BY RANK: an entry's place is its place
+        // in its own segment plus, for every other segment, the number of entries there that come before it — a binary search each
+        // (two barriers; the workgroup-wide bitonic sort has 36, and ordering by rank over ALL entries — c steps per entry — was
+        // measured at 24 us of this kernel's 55)
+        double kv = key[tid];
+        int iv = idx[tid];
+        knn_sort64_lanes(kv, iv);
+        __syncthreads();
+        key[tid] = kv; idx[tid] = iv;
+        __syncthreads();
+        const int s_ = tid >> 6;
+        int rank = tid & 63;
+        for (int s2 = 0; s2 < 4; ++s2) {
+            if (s2 == s_) continue;
+            const double *kl = key + 64 * s2;
+            const int *il = idx + 64 * s2;
+            int lo = 0, hi = 64;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const double kb = kl[mid];
+                if ((kb < kv) || (kb == kv && il[mid] < iv)) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k && iv != 0x7fffffff) { okey[rank] = kv; oidx[rank] = iv; }
+    } else {
+        bitonic_sort_n<256>(key, idx, cap);
+        for (int e = tid; e < k; e += 256) { okey[e] = key[e]; oidx[e] = idx[e]; }
+    }
+    __syncthreads();
+    if (dbg & 8) { for (int e = tid; e < k; e += 256) { g.a.ind[(size_t)qi * k + e] = oidx[e] < 0 || oidx[e] >= g.a.n ? e : oidx[e]; g.a.dist[(size_t)qi * k + e] = okey[e]; g.a.w[(size_t)qi * k + e] = 1.0; } return; }
     knn_finish_tail(g.a, qi, k, key, okey, oidx, sred, smed, snn);
 }
 
@@ -513,22 +641,28 @@ static void ks_plan(int64_t n, int k, int64_t &ntiles, int &T, int &nslots)
     T = (int)std::max<int64_t>(1, (ntiles + target - 1) / target);
     nslots = (int)((ntiles + T - 1) / T);
 }
+// the bar is the k-th smallest of G group minima, i.e. about the (-G ln(1 - k / G))-th smallest distance: the expected number of
+// survivors per query (0: too few groups for this k).  (+ 15 % and the ties) they must fit the candidate list.
+static double ks_survivors(int64_t n, int k)
+{
+    int64_t ntiles; int T, nslots;
+    ks_plan(n, k, ntiles, T, nslots);
+    const double G = 2.0 * (double)(n / (32 * (int64_t)T));
+    if (G < 1.25 * k) return 0.0;
+    return -G * log(1.0 - (double)k / G);
+}
 bool jch_knn_screen_shape_ok(int64_t n, int dd, int k)
 {
     if (dd < 1 || dd > 62 || k < 1 || k > KNN_CAP - 256 || n >= ((int64_t)1 << 26)) return false;
     int64_t ntiles; int T, nslots;
     ks_plan(n, k, ntiles, T, nslots);
-    // the bar is the k-th smallest of G group minima, i.e. about the (-G ln(1 - k / G))-th smallest distance: that many survivors
-    // (+ 15 % and the ties) must fit the candidate list
-    const double G = 2.0 * (double)(n / (32 * (int64_t)T));
-    if (G < 1.25 * k) return false;
-    const double est = -G * log(1.0 - (double)k / G);
-    return 1.15 * est + 32.0 <= 0.9 * KS_CCAP;
+    const double est = ks_survivors(n, k);
+    return est > 0.0 && 1.15 * est + 32.0 <= 0.9 * KS_CCAP;
 }
 size_t jch_knn_screen_model_bytes(int64_t n, int dd)
 {
     const size_t ntiles = (size_t)((n + 31) / 32);
-    const size_t ldzr = ((size_t)dd + 1) & ~(size_t)1;
+    const size_t ldzr = ((size_t)dd + 7) & ~(size_t)7;   // (rows in whole 64-byte sectors)
     return ntiles * (size_t)ks_ks(dd) * 64 * 16 + (((size_t)n * ldzr * sizeof(double) + 255) & ~(size_t)255) + (((size_t)dd * sizeof(double) + 255) & ~(size_t)255) + 256;
 }
 int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int64_t n, int dd, void *mem, knn_screen *out)
@@ -538,7 +672,7 @@ int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int6
     sc.ntiles = (n + 31) / 32;
     char *b = (char *)mem;
     sc.Zs = (uint4 *)b; b += (size_t)sc.ntiles * sc.KS * 64 * 16;
-    sc.ldzr = (dd + 1) & ~1;
+    sc.ldzr = (dd + 7) & ~7;
     sc.Zr = (double *)b; b += ((size_t)n * sc.ldzr * sizeof(double) + 255) & ~(size_t)255;
     sc.mu = (double *)b; b += ((size_t)dd * sizeof(double) + 255) & ~(size_t)255;
     sc.hdr = (unsigned *)b;
@@ -556,17 +690,21 @@ int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int6
 template <int KS>
 static void ks_launch_passes(jch_ctx *ctx, const ks_args &g)
 {
-    const int64_t waves = (int64_t)g.nqt * g.nchunks;
-    const unsigned nb = (unsigned)((waves + 3) / 4);
     hipLaunchKernelGGL((k_ks_pack_queries<KS>), dim3((unsigned)((g.nqt * 64 + 255) / 256)), dim3(256), 0, ctx->stream, g);
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL((k_knn_gmin<KS>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    constexpr int QWmax = KS <= 6 ? 2 : 1;                       // (registers: 4 KS per 32 queries for their operand)
+    const int qw = g.qw <= QWmax ? g.qw : QWmax;
+    const int nqg = (g.nqt + qw - 1) / qw;
+    const unsigned nb = (unsigned)(((g.nchunks + 7) / 8) * ((nqg + 3) / 4) * 8);   // (ks_item)
+    if (qw == 2) hipLaunchKernelGGL((k_knn_gmin<KS, QWmax>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((k_knn_gmin<KS, 1>), dim3(nb), dim3(256), 0, ctx->stream, g);
     const int G = 2 * g.nslots, nbq = (g.nqt * 32 + 3) / 4;
     if (G <= 256) hipLaunchKernelGGL((k_knn_bar<4>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else if (G <= 512) hipLaunchKernelGGL((k_knn_bar<8>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else if (G <= 1024) hipLaunchKernelGGL((k_knn_bar<16>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL((k_knn_bar<32>), dim3(nbq), dim3(256), 0, ctx->stream, g);
-    hipLaunchKernelGGL((k_knn_survive<KS>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    if (qw == 2) hipLaunchKernelGGL((k_knn_survive<KS, QWmax>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((k_knn_survive<KS, 1>), dim3(nb), dim3(256), 0, ctx->stream, g);
 }
 
 int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen &sc, int *flags)
@@ -577,8 +715,12 @@ int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen 
     int64_t ntiles;
     ks_plan(a.n, a.k, ntiles, g.T, g.nslots);
     g.nqt = (a.m + 31) / 32;
+    g.qw = (g.nqt >= 2 && sc.KS <= 6) ? 2 : 1;
+    if (const char *e = getenv("JCH_KNN_SCREEN_QW")) g.qw = atoi(e) == 1 ? 1 : g.qw;
     // groups per wave: ~6 wave items per SIMD of the chip
-    g.gpw = (int)std::max<int64_t>(1, ((int64_t)g.nslots * g.nqt) / ((int64_t)ctx->cus * 4 * 6));
+    g.gpw = (int)std::max<int64_t>(1, ((int64_t)g.nslots * ((g.nqt + g.qw - 1) / g.qw)) / ((int64_t)ctx->cus * 4 * 6));
+    // (at most 256 chunks: a query's slots, chunks x 32 bytes, are read in one trip by its finishing workgroup)
+    g.gpw = std::max(g.gpw, (g.nslots + 255) / 256);
     if (const char *e = getenv("JCH_KNN_SCREEN_GPW")) g.gpw = std::max(1, atoi(e));
     // (the chunks' own candidate slots: m x chunks x KS_S ints — at most 1 GB)
     g.gpw = (int)std::max<int64_t>(g.gpw, ((int64_t)a.m * g.nslots * KS_S * 4 + ((int64_t)1 << 30) - 1) >> 30);
@@ -587,9 +729,9 @@ int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen 
     const size_t mpad = (size_t)g.nqt * 32;
     const size_t b_qs = (size_t)g.nqt * sc.KS * 64 * 16, b_nq = mpad * sizeof(double), b_gmin = (size_t)g.nqt * g.nslots * 64 * sizeof(float),
                  b_bar = mpad * sizeof(float), b_cnt = mpad * sizeof(int), b_cand = (size_t)a.m * KS_CCAP * sizeof(int),
-                 b_scnt = (size_t)a.m * g.nchunks * sizeof(int), b_scand = b_scnt * KS_S;
+                 b_scand = (size_t)a.m * g.nchunks * KS_S * sizeof(int);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, up(b_qs) + up(b_nq) + up(b_gmin) + up(b_bar) + up(b_cnt) + up(b_cand) + up(b_scnt) + up(b_scand) + 256));
+    JCH_TRY(jch_reserve(ctx, ctx->gemm_b, up(b_qs) + up(b_nq) + up(b_gmin) + up(b_bar) + up(b_cnt) + up(b_cand) + up(b_scand) + 256));
     char *b = (char *)ctx->gemm_b.ptr;
     g.Qs = (uint4 *)b; b += up(b_qs);
     g.nq = (double *)b; b += up(b_nq);
@@ -597,7 +739,6 @@ int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen 
     g.bar = (float *)b; b += up(b_bar);
     g.cnt = (int *)b; b += up(b_cnt);
     g.cand = (int *)b; b += up(b_cand);
-    g.scnt = (int *)b; b += up(b_scnt);
     g.scand = (int *)b;
     g.flags = flags;
 #define KS_PASSES(KSv) case KSv: ks_launch_passes<KSv>(ctx, g); break
@@ -607,14 +748,14 @@ int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen 
     if (const char *e = getenv("JCH_KNN_SCREEN_DBG")) {
         g.a.dbg = atoi(e);
         if (g.a.dbg & 1) {   // survivors per query (host sync; measurement only)
-            std::vector<int> hc(mpad), hs((size_t)a.m * g.nchunks);
+            std::vector<int> hc(mpad), hs((size_t)a.m * g.nchunks * KS_S);
             JCH_HIP(ctx, hipMemcpyAsync(hc.data(), g.cnt, sizeof(int) * mpad, hipMemcpyDeviceToHost, ctx->stream));
-            JCH_HIP(ctx, hipMemcpyAsync(hs.data(), g.scnt, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
+            JCH_HIP(ctx, hipMemcpyAsync(hs.data(), g.scand, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, ctx->stream));
             JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
             long long tot = 0, ovf = 0; int mx = 0, over256 = 0;
             for (int i = 0; i < a.m; ++i) {
                 int c = hc[i];
-                for (int ch = 0; ch < g.nchunks; ++ch) c += hs[(size_t)i * g.nchunks + ch];
+                for (size_t e = 0; e < (size_t)g.nchunks * KS_S; ++e) c += hs[(size_t)i * g.nchunks * KS_S + e] >= 0 ? 1 : 0;
                 tot += c; ovf += hc[i]; mx = std::max(mx, c); over256 += c > 256;
             }
             fprintf(stderr, "[jch] screened kNN: m=%d k=%d T=%d slots=%d gpw=%d chunks=%d survivors mean %.1f max %d, %d lists > 256, %lld through the overflow lists\n", a.m, a.k,
