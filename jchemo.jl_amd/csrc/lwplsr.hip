@@ -233,6 +233,7 @@ __global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
     }
     // the segment's k best of every query, in (distance, index) order: wave w takes query w
     __syncthreads();
+    const bool fused = g.only_flags != nullptr;   // behind the screened search (one segment): the workgroup finishes its queries itself
     if (wv < nq) {
         int c0 = cnt[wv];
         double *key = bkey + wv * KNN_CAP;
@@ -245,9 +246,23 @@ __global__ __launch_bounds__(NT) void k_knn_scan(knn_args g)
         const int cap = knn_pow2_at_least(c0);
         for (int e = c0 + lane; e < cap; e += 64) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
         bitonic_sort_wave(key, idx, cap);
-        double *ok = g.ckey + ((size_t)(q0 + wv) * g.nseg + seg) * k;
-        int *oi = g.cidx + ((size_t)(q0 + wv) * g.nseg + seg) * k;
-        for (int e = lane; e < k; e += 64) { ok[e] = e < c0 ? key[e] : __builtin_inf(); oi[e] = e < c0 ? idx[e] : 0x7fffffff; }
+        if (fused) {
+            for (int e = c0 + lane; e < k; e += 64) { key[e] = __builtin_inf(); idx[e] = 0x7fffffff; }
+        } else {
+            double *ok = g.ckey + ((size_t)(q0 + wv) * g.nseg + seg) * k;
+            int *oi = g.cidx + ((size_t)(q0 + wv) * g.nseg + seg) * k;
+            for (int e = lane; e < k; e += 64) { ok[e] = e < c0 ? key[e] : __builtin_inf(); oi[e] = e < c0 ? idx[e] : 0x7fffffff; }
+        }
+    }
+    if (fused) {   // (block-uniform) K9b on the lists where they lie: the members of a scanned group are all finished (the unflagged ones get the values they have)
+        double *scr = reinterpret_cast<double *>(cnt + QB + 2);     // [KNN_CAP] scratch | sred [8] | smed [2] | snn [4] (the launcher sizes the LDS for it)
+        double *sred = scr + KNN_CAP, *smed = sred + 8;
+        int *snn = reinterpret_cast<int *>(smed + 2);
+        const int kk = (int)min<int64_t>(k, g.n);
+        for (int qq = 0; qq < nq; ++qq) {
+            __syncthreads();
+            knn_finish_tail(g, q0 + qq, kk, scr, bkey + qq * KNN_CAP, bidx + qq * KNN_CAP, sred, smed, snn);
+        }
     }
 }
 
@@ -263,12 +278,6 @@ __global__ __launch_bounds__(256) void k_knn_finish(knn_args g)
     __shared__ int snn[4];
     const int tid = threadIdx.x;
     const int qi = blockIdx.x, k = g.k;
-    if (g.only_flags) {   // (the members of a scanned group are all finished again: the unflagged ones get the values they have)
-        const int q0 = qi / g.qb * g.qb;
-        int any = 0;
-        for (int qq = q0; qq < min(q0 + g.qb, g.m); ++qq) any |= g.only_flags[qq];
-        if (!any) return;
-    }
     const int ncand = g.nseg * k;
     const double *ck = g.ckey + (size_t)qi * ncand;
     const int *ci = g.cidx + (size_t)qi * ncand;
@@ -816,7 +825,6 @@ int32_t jch_launch_knn_scan(jch_ctx *ctx, knn_args a, jch_buf &cbuf)
     const size_t lds = jch_knn_scan_lds(k, a.dd, m, &wide);
     if (a.only_flags) wide = false;
     const int nt = wide ? 512 : 256;
-    a.qb = wide ? 8 : KNN_QB;
     {
         // row segments: as many as keep every segment at >= 4 trips and the merged candidate lists inside one sort (nseg * k <= KNN_CAP)
         // (measured at cfg5, 1000 queries: 1 segment 1.38 ms, 2: 1.00, 3: 0.88, 5: 1.21 — every (query group, segment) block pays
@@ -824,6 +832,9 @@ int32_t jch_launch_knn_scan(jch_ctx *ctx, knn_args a, jch_buf &cbuf)
         // (round 3, with the sort-free compactions: 2 segments 0.60 ms, 3: 0.51, 4: 0.59, 5: 0.57, 6: 0.56, 8: 0.59)
         int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(3, KNN_FCAP / k), n / (4 * nt * KNN_RB)));
         if (const char *e = getenv("JCH_KNN_SEGMENTS")) nseg = std::max(1, std::min(atoi(e), KNN_FCAP / k));
+        // behind the screened search: ONE segment and no separate finishing kernel — two launches whose workgroups find nothing
+        // flagged and leave cost 9.8 us per call at cfg5, one launch of a third as many workgroups 3
+        if (a.only_flags) nseg = 1;
         a.nseg = nseg;
         JCH_TRY(jch_reserve(ctx, cbuf, (sizeof(double) + sizeof(int)) * (size_t)m * nseg * k + 256));
         a.ckey = (double *)cbuf.ptr; a.cidx = (int *)(a.ckey + (size_t)m * nseg * k);
@@ -839,8 +850,8 @@ int32_t jch_launch_knn_scan(jch_ctx *ctx, knn_args a, jch_buf &cbuf)
         // exact distance — half the arithmetic per pair — 1.78 ms: the ~1000 survivors per query and segment each pay a divergent
         // 20-load recomputation.  Results were identical in both.  What bounds the scan is the dependent chain of a wave's trip.)
         if (wide) hipLaunchKernelGGL((k_knn_scan<512, 8>), dim3((unsigned)((m + 7) / 8) * nseg), dim3(512), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB) * nseg), dim3(256), lds, ctx->stream, a);
-        hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_knn_scan<256, KNN_QB>), dim3((unsigned)((m + KNN_QB - 1) / KNN_QB) * nseg), dim3(256), lds + (a.only_flags ? sizeof(double) * (KNN_CAP + 16) : 0), ctx->stream, a);
+        if (!a.only_flags) hipLaunchKernelGGL(k_knn_finish, dim3((unsigned)m), dim3(256), 0, ctx->stream, a);
     }
     JCH_HIP(ctx, hipGetLastError());
     return JCH_OK;

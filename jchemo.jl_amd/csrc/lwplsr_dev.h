@@ -37,7 +37,6 @@ struct knn_args {
     int *cidx;     // [m][nseg][k]
     int dbg;       // measurement switch (JCH_KNN_DBG; results then wrong by design): 1 = the bar starts at -inf (no candidate is ever kept: the bare scan)
     const int *only_flags = nullptr;   // null, or [m] device flags — only the queries with a non-zero flag are done (k_knn_scan: only their groups of qb)
-    int qb = 4;                        // queries per workgroup of the scan that filled ckey / cidx (k_knn_finish, only_flags)
 };
 
 // lwplsr_screen.hip: the screened kNN (round 4).  Squared distances of ALL (row, query) pairs on the matrix cores

@@ -66,7 +66,9 @@ struct ks_args {
     int *scand;         // [m][nchunks][KS_S] rows of the survivors of (query, row chunk), -1 in the unused places: every place is
                         // written by the pair's one wave on every call (32 contiguous bytes), nothing to clear, no count to read
     int *flags;         // [m]
-    int nqt, nslots, T, gpw, nchunks, qw;   // qw: tiles of 32 queries per wave item (1, 2)
+    int nqt, nslots, T;
+    int gpw, nchunks, qw;      // k_knn_survive: group slots per row chunk, chunks, tiles of 32 queries per wave item (1, 2)
+    int gpw_g, nchunks_g, qw_g;   // k_knn_gmin: the same (its own split of the work: it writes per group slot, not per chunk)
     double cfac;
 };
 
@@ -248,13 +250,13 @@ __device__ __forceinline__ f32x16 ks_tile(const uint4 (&a)[KS], const uint4 (&b)
 // workgroup b runs on XCD b % 8; all the workgroups of a row chunk are given the same residue — the chunk's operand tiles cross the
 // fabric once, into ONE L2, and every other wave that needs them hits there (the operand copy, 12.8 MB at cfg5, does not fit one L2:
 // with chunks dealt to all XCDs every XCD pulled all of it from the Infinity Cache, one tile ahead of its use).
-__device__ __forceinline__ bool ks_item(const ks_args &g, int nqg, int &qg, int &chunk)
+__device__ __forceinline__ bool ks_item(int nchunks, int nqg, int &qg, int &chunk)
 {
     const int nqb = (nqg + 3) >> 2;
     const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
     chunk = (i / nqb) * 8 + xcd;
     qg = (i % nqb) * 4 + (int)(threadIdx.x >> 6);
-    return chunk < g.nchunks && qg < nqg;
+    return chunk < nchunks && qg < nqg;
 }
 
 // wave item: query group qg (QW tiles of 32 queries: every loaded row operand serves 32 QW queries — with QW = 1 both passes
@@ -266,12 +268,12 @@ __global__ __launch_bounds__(256) void k_knn_gmin(ks_args g)
     const int lane = threadIdx.x & 63;
     const int nqg = (g.nqt + QW - 1) / QW;
     int qg, chunk;
-    if (!ks_item(g, nqg, qg, chunk)) return;
+    if (!ks_item(g.nchunks_g, nqg, qg, chunk)) return;
     uint4 b[QW][KS];
 #pragma unroll
     for (int u = 0; u < QW; ++u) ks_load_b<KS>(g, min(qg * QW + u, g.nqt - 1), lane, b[u]);
-    for (int gi = 0; gi < g.gpw; ++gi) {
-        const int slot = chunk * g.gpw + gi;
+    for (int gi = 0; gi < g.gpw_g; ++gi) {
+        const int slot = chunk * g.gpw_g + gi;
         if (slot >= g.nslots) break;
         float mn[QW];
 #pragma unroll
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void k_knn_survive(ks_args g)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, col = lane & 31;
     const int nqg = (g.nqt + QW - 1) / QW;
     int qg, chunk;
-    if (!ks_item(g, nqg, qg, chunk)) return;
+    if (!ks_item(g.nchunks, nqg, qg, chunk)) return;
     uint4 b[QW][KS];
     float barv[QW];
 #pragma unroll
@@ -693,18 +695,16 @@ static void ks_launch_passes(jch_ctx *ctx, const ks_args &g)
     hipLaunchKernelGGL((k_ks_pack_queries<KS>), dim3((unsigned)((g.nqt * 64 + 255) / 256)), dim3(256), 0, ctx->stream, g);
     (void)jch_ev(ctx);
     constexpr int QWmax = KS <= 6 ? 2 : 1;                       // (registers: 4 KS per 32 queries for their operand)
-    const int qw = g.qw <= QWmax ? g.qw : QWmax;
-    const int nqg = (g.nqt + qw - 1) / qw;
-    const unsigned nb = (unsigned)(((g.nchunks + 7) / 8) * ((nqg + 3) / 4) * 8);   // (ks_item)
-    if (qw == 2) hipLaunchKernelGGL((k_knn_gmin<KS, QWmax>), dim3(nb), dim3(256), 0, ctx->stream, g);
-    else hipLaunchKernelGGL((k_knn_gmin<KS, 1>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    auto grid = [&](int qw, int nchunks) { return (unsigned)(((nchunks + 7) / 8) * (((g.nqt + qw - 1) / qw + 3) / 4) * 8); };   // (ks_item)
+    if (g.qw_g == 2 && QWmax == 2) hipLaunchKernelGGL((k_knn_gmin<KS, QWmax>), dim3(grid(2, g.nchunks_g)), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((k_knn_gmin<KS, 1>), dim3(grid(1, g.nchunks_g)), dim3(256), 0, ctx->stream, g);
     const int G = 2 * g.nslots, nbq = (g.nqt * 32 + 3) / 4;
     if (G <= 256) hipLaunchKernelGGL((k_knn_bar<4>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else if (G <= 512) hipLaunchKernelGGL((k_knn_bar<8>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else if (G <= 1024) hipLaunchKernelGGL((k_knn_bar<16>), dim3(nbq), dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL((k_knn_bar<32>), dim3(nbq), dim3(256), 0, ctx->stream, g);
-    if (qw == 2) hipLaunchKernelGGL((k_knn_survive<KS, QWmax>), dim3(nb), dim3(256), 0, ctx->stream, g);
-    else hipLaunchKernelGGL((k_knn_survive<KS, 1>), dim3(nb), dim3(256), 0, ctx->stream, g);
+    if (g.qw == 2 && QWmax == 2) hipLaunchKernelGGL((k_knn_survive<KS, QWmax>), dim3(grid(2, g.nchunks)), dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((k_knn_survive<KS, 1>), dim3(grid(1, g.nchunks)), dim3(256), 0, ctx->stream, g);
 }
 
 int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen &sc, int *flags)
@@ -715,14 +715,20 @@ int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen 
     int64_t ntiles;
     ks_plan(a.n, a.k, ntiles, g.T, g.nslots);
     g.nqt = (a.m + 31) / 32;
-    g.qw = (g.nqt >= 2 && sc.KS <= 6) ? 2 : 1;
-    if (const char *e = getenv("JCH_KNN_SCREEN_QW")) g.qw = atoi(e) == 1 ? 1 : g.qw;
-    // groups per wave: ~6 wave items per SIMD of the chip
+    // The two passes split the work their own ways (measured at cfg5, one box: the group-minima pass 16.9 us with two query tiles per
+    // wave item and one group slot per chunk, 21.8 with one tile; the survivor pass 31.2 us with one tile and two slots per chunk,
+    // 36.4-40.7 with two tiles — its survivor bookkeeping wants registers, not operand reuse).
+    // k_knn_gmin: ~6 wave items per SIMD of the chip
+    g.qw_g = (g.nqt >= 2 && sc.KS <= 6) ? 2 : 1;
+    g.gpw_g = (int)std::max<int64_t>(1, ((int64_t)g.nslots * ((g.nqt + g.qw_g - 1) / g.qw_g)) / ((int64_t)ctx->cus * 4 * 6));
+    g.nchunks_g = (g.nslots + g.gpw_g - 1) / g.gpw_g;
+    // k_knn_survive: at most 256 chunks (a query's slots, chunks x 32 bytes, are read in one trip by its finishing workgroup), and
+    // at most 1 GB of them (m x chunks x KS_S ints)
+    g.qw = 1;
+    if (const char *e = getenv("JCH_KNN_SCREEN_QW")) g.qw = (atoi(e) == 2 && g.nqt >= 2 && sc.KS <= 6) ? 2 : 1;
     g.gpw = (int)std::max<int64_t>(1, ((int64_t)g.nslots * ((g.nqt + g.qw - 1) / g.qw)) / ((int64_t)ctx->cus * 4 * 6));
-    // (at most 256 chunks: a query's slots, chunks x 32 bytes, are read in one trip by its finishing workgroup)
     g.gpw = std::max(g.gpw, (g.nslots + 255) / 256);
     if (const char *e = getenv("JCH_KNN_SCREEN_GPW")) g.gpw = std::max(1, atoi(e));
-    // (the chunks' own candidate slots: m x chunks x KS_S ints — at most 1 GB)
     g.gpw = (int)std::max<int64_t>(g.gpw, ((int64_t)a.m * g.nslots * KS_S * 4 + ((int64_t)1 << 30) - 1) >> 30);
     g.nchunks = (g.nslots + g.gpw - 1) / g.gpw;
     g.cfac = ks_cfac(a.dd);
