@@ -247,6 +247,7 @@ def secondary_lwplsr(J, lib, ctx, dev, calls):
     y = J.colmajor_empty(n, 1, dev); y.copy_((X @ beta + torch.sin(3 * X[:, 5])).reshape(-1, 1) + 0.05 * noise)
     fm = J.lwplsr(X, y, nlvdis=nlvdis, metric="mahal", h=1.0, k=k, nlv=nlv, ctx=ctx)
     J.predict(fm, Xq, nlv=range(0, nlv + 1), ctx=ctx)
+    scr0, red0 = ctx.counter(2), ctx.counter(3)          # JCH_COUNTER_KNN_SCREENED / _SCREEN_REDONE
     dev_ms = {"query_scores_or_copies": 0.0, "knn_and_weights": 0.0, "local_fits": 0.0}
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(calls):
@@ -272,6 +273,9 @@ def secondary_lwplsr(J, lib, ctx, dev, calls):
                              note="algorithmic bytes = the gathered neighbour rows m k p 8 (SURVEY §8d: the path is latency / occupancy bound, "
                                   "the HBM fraction is reported for completeness; profiles/ holds the counted traffic)"),
            "device_ms_per_step": {k_: v / calls for k_, v in dev_ms.items()}}
+    out["knn_search"] = {"screened_queries_per_call": (ctx.counter(2) - scr0) / (2 * calls), "redone_by_the_exact_scan_per_call": (ctx.counter(3) - red0) / (2 * calls),
+                         "note": "round 4: all (row, query) pairs on v_mfma_f32_32x32x16_bf16 (two-piece bf16 operands), error-bounded bar from group minima, exact f64 "
+                                 "distances for the survivors; neighbours / distances / weights identical to the exact scan (JCH_KNN_SCREEN=0), tests/test_gpu_knn_screen.py"}
     out["roofline"]["traffic"] = pmc_config_traffic("cfg5_lwplsr", m=m, k=k, p=p)
     out["roofline"]["traffic_source"] = PMC_FILE + ": committed rocprofv3 --pmc passes of k_locw_kspace at this shape; NOT measured in this run"
     # the local fits are a matrix-pipe + vector kernel since round 3 (k_locw_kspace: the k x k Gram matrix of the gathered rows on

@@ -793,7 +793,7 @@ struct jch_lwplsr_model {
     void *screen_mem = nullptr;
 };
 
-static void lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t n, int p, double *Xrm, int ldr)
+void jch_lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t n, int p, double *Xrm, int ldr)
 {
     const int ptiles = (ldr + 63) / 64;
     const int64_t nchunks = (n + 63) / 64;
@@ -1048,7 +1048,7 @@ extern "C" int32_t jch_lwplsr_predict(jch_ctx *ctx, int32_t loc, const double *X
     ctx->ev_used = 0;
     ctx->prof = jch_profile{};
     hipEvent_t ev0 = jch_ev(ctx);
-    lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, Xrm, ldr);
+    jch_lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, Xrm, ldr);
     return lw_run(ctx, Xrm, ldr, n, p, dY, q, ldyd, dZt, ldztd, dZq, ldzqd, dd, dXq, m, ldxqd, k, h, tol, scal, nlv_lo, nlv_hi, pred,
                   ind_out, dist_out, w_out, ev0, nullptr, nullptr);
 }
@@ -1086,7 +1086,7 @@ extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *X
             return fail(jch_fail(ctx, JCH_EHIP, "jch_lwplsr_prepare: copy of X failed"));
         dX = (const double *)ctx->xstage.ptr; ldxd = n;
     }
-    lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, mo->Xrm, mo->ldr);
+    jch_lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, mo->Xrm, mo->ldr);
     if (dd <= 62 && n < ((int64_t)1 << 26)) {   // (whether a call is screened also depends on its k: jch_knn_screen_shape_ok)
         if (hipMalloc(&mo->screen_mem, jch_knn_screen_model_bytes(n, (int)dd)) != hipSuccess)
             return fail(jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_prepare: device allocation failed (screened kNN operand)"));

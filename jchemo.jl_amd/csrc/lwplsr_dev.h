@@ -59,6 +59,8 @@ int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int6
 // flags: [m] device ints, set to 1 for the queries handed to the exact selection (0 otherwise)
 int32_t jch_launch_knn_screen(jch_ctx *ctx, const knn_args &a, const knn_screen &sc, int *flags);
 
+// lwplsr.hip: row-major copy Xrm [n][ldr] of a column-major n x p matrix (columns p .. ldr - 1 zero), on the ctx stream
+void jch_lw_to_rowmajor(jch_ctx *ctx, const double *dX, int64_t ldxd, int64_t n, int p, double *Xrm, int ldr);
 // lwplsr.hip: the exact scan (k <= 768, LDS for the score space: jch_knn_scan_lds <= 150 KB)
 size_t jch_knn_scan_lds(int k, int dd, int m, bool *wide_out);
 int32_t jch_launch_knn_scan(jch_ctx *ctx, knn_args a, jch_buf &cbuf);

@@ -73,23 +73,29 @@ struct ks_args {
 };
 
 // ---------------------------------------------------------------- model-constant part
-__global__ __launch_bounds__(1024) void k_ks_colmean(const double *__restrict__ Zt, int64_t ldzt, int64_t n, double *__restrict__ mu, unsigned *__restrict__ hdr)
+#define KS_MB 32   // row blocks of the column sums
+__global__ __launch_bounds__(256) void k_ks_colsum(const double *__restrict__ Zt, int64_t ldzt, int64_t n, double *__restrict__ part)
 {
-    __shared__ double red[16];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[4];
+    const int c = blockIdx.x, blk = blockIdx.y, tid = threadIdx.x;
     const double *col = Zt + (size_t)c * (size_t)ldzt;
+    const int64_t per = (n + KS_MB - 1) / KS_MB, lo = blk * per, hi = min(n, lo + per);
     double s = 0.0;
-    for (int64_t i = tid; i < n; i += 1024) s += col[i];
+    for (int64_t i = lo + tid; i < hi; i += 256) s += col[i];
     s = jch_wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) part[c * KS_MB + blk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void k_ks_colmean(const double *__restrict__ part, int dd, int64_t n, double *__restrict__ mu, unsigned *__restrict__ hdr)
+{
+    for (int c = threadIdx.x; c < dd; c += 64) {
         double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += red[w];
+        for (int b = 0; b < KS_MB; ++b) t += part[c * KS_MB + b];
         t /= (double)n;
-        mu[c] = (t == t && fabs(t) < 1e300) ? t : 0.0;       // (non-finite scores: the pack kernel raises hdr[1])
-        if (c == 0) { hdr[0] = 0u; hdr[1] = 0u; }
+        mu[c] = (t == t && fabs(t) < 1e300) ? t : 0.0;           // (non-finite scores: the pack kernel raises hdr[1])
     }
+    if (threadIdx.x == 0) { hdr[0] = 0u; hdr[1] = 0u; }
 }
 
 // f32 -> bf16, round to nearest even (Inf stays Inf, NaN stays NaN)
@@ -116,25 +122,26 @@ __device__ __forceinline__ void ks_split(float f, unsigned &hi, unsigned &lo)
 // one thread per (tile, lane)
 template <int KS>
 __global__ __launch_bounds__(256) void k_ks_pack_rows(const double *__restrict__ Zt, int64_t ldzt, int64_t n, int dd, const double *__restrict__ mu,
-                                                      uint4 *__restrict__ Zs, int64_t ntiles, unsigned *__restrict__ hdr, double *__restrict__ Zr, int ldzr)
+                                                      uint4 *__restrict__ Zs, int64_t ntiles, unsigned *__restrict__ hdr)
 {
+    // thread -> (operand lane, tile), consecutive threads on consecutive TILES: their rows (ks_row) are consecutive too, so the column
+    // reads coalesce; the 16-byte operand stores are 1 KB x KS apart instead (tile-major threads, coalesced stores and reads 8 n / 32
+    // bytes apart, took 84 us at cfg5)
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t tile = gid >> 6;
-    const int lane = (int)(gid & 63);
-    if (tile >= ntiles) return;
+    const int lane = (int)(gid / ntiles);
+    const int64_t tile = gid - (int64_t)lane * ntiles;
+    if (lane >= 64) return;
     const int64_t row = (int64_t)(lane & 31) * ntiles + tile;      // (ks_row: consecutive rows sit in different tiles)
     const int h = lane >> 5;
     const bool live = row < n;
     double nz = 0.0;
     for (int c = 0; c < dd; ++c) {
         const double zv = live ? Zt[(size_t)row + (size_t)c * (size_t)ldzt] : 0.0;
-        if (live && (c & 1) == h) Zr[(size_t)row * ldzr + c] = zv;      // (the two lanes of a row share the copy)
         unsigned hi, lo;
         ks_split((float)(zv - mu[c]), hi, lo);
         const double zz = (double)ks_bf16_f(hi) + (double)ks_bf16_f(lo);
         nz += zz * zz;
     }
-    if (live && h == 1 && ldzr > dd) Zr[(size_t)row * ldzr + dd] = 0.0;
     float nzf = (float)nz;
     if ((double)nzf < nz) nzf = __uint_as_float(__float_as_uint(nzf) + 1u);   // (rounded UP: it enters the error bound through hdr[0])
     unsigned n1, n2;
@@ -665,7 +672,7 @@ size_t jch_knn_screen_model_bytes(int64_t n, int dd)
 {
     const size_t ntiles = (size_t)((n + 31) / 32);
     const size_t ldzr = ((size_t)dd + 7) & ~(size_t)7;   // (rows in whole 64-byte sectors)
-    return ntiles * (size_t)ks_ks(dd) * 64 * 16 + (((size_t)n * ldzr * sizeof(double) + 255) & ~(size_t)255) + (((size_t)dd * sizeof(double) + 255) & ~(size_t)255) + 256;
+    return ntiles * (size_t)ks_ks(dd) * 64 * 16 + (((size_t)n * ldzr * sizeof(double) + 255) & ~(size_t)255) + (((size_t)dd * sizeof(double) + 255) & ~(size_t)255) + 256 + sizeof(double) * 64 * KS_MB;
 }
 int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int64_t n, int dd, void *mem, knn_screen *out)
 {
@@ -677,10 +684,14 @@ int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int6
     sc.ldzr = (dd + 7) & ~7;
     sc.Zr = (double *)b; b += ((size_t)n * sc.ldzr * sizeof(double) + 255) & ~(size_t)255;
     sc.mu = (double *)b; b += ((size_t)dd * sizeof(double) + 255) & ~(size_t)255;
-    sc.hdr = (unsigned *)b;
-    hipLaunchKernelGGL(k_ks_colmean, dim3(dd), dim3(1024), 0, ctx->stream, dZt, ldzt, n, sc.mu, sc.hdr);
+    sc.hdr = (unsigned *)b; b += 256;
+    double *part = reinterpret_cast<double *>(b);                 // [dd][KS_MB] partial column sums
+    // column means (two stages), the row-major copy (tiled transpose), the operand copy
+    hipLaunchKernelGGL(k_ks_colsum, dim3(dd, KS_MB), dim3(256), 0, ctx->stream, dZt, ldzt, n, part);
+    hipLaunchKernelGGL(k_ks_colmean, dim3(1), dim3(64), 0, ctx->stream, part, dd, n, sc.mu, sc.hdr);
+    jch_lw_to_rowmajor(ctx, dZt, ldzt, n, dd, sc.Zr, sc.ldzr);
     const unsigned nb = (unsigned)((sc.ntiles * 64 + 255) / 256);
-#define KS_PACK(KSv) case KSv: hipLaunchKernelGGL((k_ks_pack_rows<KSv>), dim3(nb), dim3(256), 0, ctx->stream, dZt, ldzt, n, dd, sc.mu, sc.Zs, sc.ntiles, sc.hdr, sc.Zr, sc.ldzr); break
+#define KS_PACK(KSv) case KSv: hipLaunchKernelGGL((k_ks_pack_rows<KSv>), dim3(nb), dim3(256), 0, ctx->stream, dZt, ldzt, n, dd, sc.mu, sc.Zs, sc.ntiles, sc.hdr); break
     switch (sc.KS) { KS_PACK(1); KS_PACK(2); KS_PACK(3); KS_PACK(4); KS_PACK(5); KS_PACK(6); KS_PACK(7); KS_PACK(8); KS_PACK(9); KS_PACK(10); KS_PACK(11); KS_PACK(12);
     default: return jch_fail(ctx, JCH_EINVAL, "internal: screened kNN: %d score dimensions", dd); }
 #undef KS_PACK
