@@ -347,11 +347,14 @@ JCH_API int32_t jch_ctx_allreduce_probe(jch_ctx *ctx, int32_t transport, double 
  * than 64 local standard deviations (along the offset) from the mean of their neighbours — possible because the neighbours are
  * chosen in the score space, not in p-space — and that were refitted by the per-query path (explicit centring). */
 #define JCH_COUNTER_LOCW_REFITS 1
-/* which = JCH_COUNTER_KNN_SCREENED: queries of jch_lwplsr_predict* whose neighbours were found by the screened search (all pairs in
- * f32 on the matrix cores, exact distances for the survivors; score spaces of <= 62 dimensions, k <= 768, n >= 24 k);
+/* which = JCH_COUNTER_KNN_SCREENED: queries of jch_lwplsr_predict* whose neighbours were found by the screened search (all (row, query)
+ * pairs on the bf16 matrix cores from two-piece operands, an error-bounded bar per query, exact Float64 distances for the survivors;
+ * score spaces of <= 62 dimensions, k <= 768, n < 2^26 and enough rows for the bar to be tight — otherwise, and with
+ * JCH_KNN_SCREEN=0 in the environment, the exact scan);
  * which = JCH_COUNTER_KNN_SCREEN_REDONE: those of them the screen could not settle (non-finite scores, or more rows within its
- * error bound of the k-th distance than a candidate list holds — ties on a lattice) and the exact selection redid.  Results do not
- * depend on which search ran. */
+ * error bound of the k-th distance than a candidate list holds: ties on a lattice, neighbour distances far below the scores' norms)
+ * and the exact scan redid.  Neighbours, their order, distances and weights do not depend on which search ran.  A prepared model
+ * (jch_lwplsr_prepare) that sees more than a quarter of a call's queries redone stops screening. */
 #define JCH_COUNTER_KNN_SCREENED 2
 #define JCH_COUNTER_KNN_SCREEN_REDONE 3
 JCH_API int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_t *out);
