@@ -9,6 +9,7 @@
 // The reference runs m independent small fits on CPU threads; here a query's whole fit lives in one workgroup:
 // its k x p block (0.8 MB at cfg5) is gathered once into an L2/MALL-resident scratch slab and swept once per LV.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -910,7 +911,46 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     ev2 = jch_ev(ctx);
     // neighbours, distances and weights are final here: their copies to the host (3.2 MB at cfg5, into pages of the caller's
     // fresh arrays that have never been touched) run on a second stream BESIDE the local fits instead of after them
-    bool side_copies = (ind_out || dist_out || w_out) && !getenv("JCH_LW_SIDE_COPY_OFF");
+    // JCH_LW_LISTS_STAGED=1 (round 4, measured, NOT the default): the neighbour lists go to pinned staging through copies queued on
+    // the main stream IN FRONT of the local fits, and the host moves them on to the caller's arrays while the local fits run.  Why
+    // it was tried: copies are CU kernels on this stack and the local-fit launch takes every CU, so of the three copies queued beside
+    // it on the second stream (the default below) one runs during the launch and two after it — 150 us of device tail per call at cfg5;
+    // in front of the launch they cost 75 us (device timeline: profiles/r04_lw_timeline.txt).  The device span of a call shrank
+    // (1168 -> 1131 us under the tracer) but the call as the host sees it got SLOWER on the same box, three A/B pairs: 1.20-1.25 ms
+    // against 1.17-1.18 — the host's own copy of 4 MB out of the staging is not free either.  Kept for hosts where it pays.
+    const size_t list_bytes = (ind_out ? sizeof(int) : 0) * (size_t)m * k + ((dist_out ? 1 : 0) + (w_out ? 1 : 0)) * sizeof(double) * (size_t)m * k;
+    const size_t pred_bytes_ = sizeof(double) * (size_t)m * le * q + sizeof(int) * 2 * (size_t)m + 64;
+    const char *e_ls = getenv("JCH_LW_LISTS_STAGED");
+    const bool lists_staged = e_ls && atoi(e_ls) == 1 && list_bytes > 0 && list_bytes + pred_bytes_ <= ((size_t)64 << 20);
+    char *hl_d = nullptr, *hl_w = nullptr, *hl_i = nullptr;   // pinned staging of dist / w / ind
+    if (lists_staged) {
+        JCH_TRY(jch_reserve_host(ctx, list_bytes + pred_bytes_ + 256));
+        char *hb = (char *)ctx->hstage + ((pred_bytes_ + 63) & ~(size_t)63);
+        if (dist_out) { hl_d = hb; hb += sizeof(double) * (size_t)m * k; }
+        if (w_out) { hl_w = hb; hb += sizeof(double) * (size_t)m * k; }
+        if (ind_out) { hl_i = hb; }
+        if (dist_out && w_out) JCH_HIP(ctx, hipMemcpyAsync(hl_d, ddist, 2 * sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));   // (adjacent on both sides)
+        else {
+            if (dist_out) JCH_HIP(ctx, hipMemcpyAsync(hl_d, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+            if (w_out) JCH_HIP(ctx, hipMemcpyAsync(hl_w, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (ind_out) JCH_HIP(ctx, hipMemcpyAsync(hl_i, dind, sizeof(int) * (size_t)m * k, hipMemcpyDeviceToHost, ctx->stream));
+        if (!ctx->aux_event && hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming) != hipSuccess) { ctx->aux_event = nullptr; return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_predict: event creation failed"); }
+        JCH_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream));
+    }
+    // the lists are on the host as soon as their event is: on to the caller's arrays (beside the batched local fits; BEFORE per-query
+    // fits, which use the pinned staging themselves)
+    bool lists_drained = !lists_staged;
+    auto drain_lists = [&]() -> int32_t {
+        if (lists_drained) return JCH_OK;
+        lists_drained = true;
+        JCH_HIP(ctx, hipEventSynchronize(ctx->aux_event));
+        if (dist_out) memcpy(dist_out, hl_d, sizeof(double) * (size_t)m * k);
+        if (w_out) memcpy(w_out, hl_w, sizeof(double) * (size_t)m * k);
+        if (ind_out) memcpy(ind_out, hl_i, sizeof(int) * (size_t)m * k);
+        return JCH_OK;
+    };
+    bool side_copies = !lists_staged && (ind_out || dist_out || w_out) && !getenv("JCH_LW_SIDE_COPY_OFF");
     if (side_copies) {
         if (!ctx->aux_stream && hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) { ctx->aux_stream = nullptr; side_copies = false; }
         if (side_copies && !ctx->aux_event && hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming) != hipSuccess) { ctx->aux_event = nullptr; side_copies = false; }
@@ -931,6 +971,7 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
         if (!locw_batched_fits(g) || (e_lg && atoi(e_lg) == 1)) {   // outside the batched kernels' envelope: one fit per query (lwplsr_generic.hip)
             const hipError_t pe = hipMemsetAsync(dpred, 0, sizeof(double) * (size_t)m * le * q, ctx->stream);
             if (pe != hipSuccess) return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_predict: %s", hipGetErrorString(pe));
+            JCH_TRY(drain_lists());
             JCH_TRY(jch_lw_generic_fits(ctx, g, n));
             generic_fits = true;
         } else
@@ -938,7 +979,6 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
             // pivot check of the neighbour-space kernel: queries far from their neighbours in p-space are flagged and refitted below
             JCH_TRY(jch_reserve(ctx, ctx->lw_flags, sizeof(int) * 2 * (size_t)m + 256));
             g.flags = (int *)ctx->lw_flags.ptr;
-            JCH_HIP(ctx, hipMemsetAsync(g.flags, 0, sizeof(int) * (size_t)m, ctx->stream));
             JCH_TRY(jch_launch_locw_kspace(ctx, g));
             kflags = g.flags; kargs = g;
         } else
@@ -951,25 +991,40 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     JCH_HIP(ctx, hipGetLastError());
     ev3 = generic_fits ? nullptr : jch_ev(ctx);
     // (the local fits are in the queue: whatever the host does from here on runs beside them)
+    // The small results — predictions, the two flag arrays — go to PINNED staging through copies queued right behind the local fits,
+    // before the host waits for anything (round 4; three copies into pageable memory issued after the wait for the neighbour lists
+    // left the device idle for 65 us and cost 30 + 18 + 34 us of turn-around: 0.15 of a 1.17 ms call at cfg5)
+    const size_t pred_bytes = sizeof(double) * (size_t)m * le * q, flag_bytes = (kflags || sflags) ? sizeof(int) * 2 * (size_t)m : 0;
+    const bool staged = lists_staged || pred_bytes + flag_bytes <= ((size_t)64 << 20);
+    char *hs = nullptr;
+    if (staged) {
+        if (lists_drained) JCH_TRY(jch_reserve_host(ctx, pred_bytes + flag_bytes + 64));   // (lists still in the staging: reserved above, they lie behind this part)
+        hs = (char *)ctx->hstage;
+        if (flag_bytes) JCH_HIP(ctx, hipMemcpyAsync(hs, ctx->lw_flags.ptr, flag_bytes, hipMemcpyDeviceToHost, ctx->stream));   // [pivot flags m][screen flags m]
+        JCH_HIP(ctx, hipMemcpyAsync(hs + flag_bytes, dpred, pred_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    JCH_TRY(drain_lists());
     hipStream_t cs = side_copies ? ctx->aux_stream : ctx->stream;
     hipError_t ce = hipSuccess;
+    if (lists_staged) { /* done */ } else
     if (ind_out && ce == hipSuccess) ce = hipMemcpyAsync(ind_out, dind, sizeof(int) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
-    if (dist_out && ce == hipSuccess) ce = hipMemcpyAsync(dist_out, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
-    if (w_out && ce == hipSuccess) ce = hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
+    if (!lists_staged && dist_out && ce == hipSuccess) ce = hipMemcpyAsync(dist_out, ddist, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
+    if (!lists_staged && w_out && ce == hipSuccess) ce = hipMemcpyAsync(w_out, dw, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost, cs);
     if (side_copies) { const hipError_t se = hipStreamSynchronize(cs); if (ce == hipSuccess) ce = se; }   // (before any return: the buffers are the caller's)
     if (ce != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_predict: copy of the neighbour lists failed: %s", hipGetErrorString(ce)); }
-    std::vector<int> hf;
-    if (kflags) {   // the pivot flags of the neighbour-space kernel travel with the predictions (one sync for both)
-        hf.resize((size_t)m);
-        JCH_HIP(ctx, hipMemcpyAsync(hf.data(), kflags, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int> hf, hsf;
+    if (staged) {
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(pred, hs + flag_bytes, pred_bytes);
+        const int *hfl = reinterpret_cast<const int *>(hs);
+        if (kflags) hf.assign(hfl, hfl + m);
+        if (sflags) hsf.assign(hfl + m, hfl + 2 * m);
+    } else {
+        if (kflags) { hf.resize((size_t)m); JCH_HIP(ctx, hipMemcpyAsync(hf.data(), kflags, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream)); }
+        if (sflags) { hsf.resize((size_t)m); JCH_HIP(ctx, hipMemcpyAsync(hsf.data(), sflags, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream)); }
+        JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, pred_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::vector<int> hsf;
-    if (sflags) {
-        hsf.resize((size_t)m);
-        JCH_HIP(ctx, hipMemcpyAsync(hsf.data(), sflags, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    JCH_HIP(ctx, hipMemcpyAsync(pred, dpred, sizeof(double) * (size_t)m * le * q, hipMemcpyDeviceToHost, ctx->stream));
-    JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (sflags) {
         long long redone = 0;
         for (int i = 0; i < (int)m; ++i) redone += hsf[(size_t)i] ? 1 : 0;

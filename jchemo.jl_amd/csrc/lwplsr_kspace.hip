@@ -250,6 +250,7 @@ __global__ __launch_bounds__(KS_NT, 1) void k_locw_kspace(locw_args g)
     for (int qi = blockIdx.x; qi < g.m; qi += gridDim.x) {
         __syncthreads();
         KS_STAMP(0);
+        if (tid == 0 && g.flags) g.flags[qi] = 0;   // (every query's flag is written by its workgroup: no memset in front of the launch; thread 0 also raises it)
         // ---- weights (mweight), neighbour ids, Y rows, Y means / stds; A = D Yc
         double s0 = 0.0;
         for (int e = tid; e < k; e += KS_NT) { idx[e] = (g.dbg & 1) ? e : g.ind[(size_t)qi * k + e]; s0 += g.w[(size_t)qi * k + e]; }
@@ -656,7 +657,11 @@ static int32_t launch_ks(jch_ctx *ctx, locw_args &g)
         JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_locw_kspace<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr.mark(ctx->device);
     }
-    const int nb = std::min(g.m, ctx->cus);
+    // as many workgroups as the queries need for the same number of rounds: 1000 queries on 256 CUs are 4 rounds with 250 workgroups as
+    // with 256, and the 6 CUs left free run the copy kernels of the neighbour lists, which travel to the host beside this launch
+    // (with every CU taken those copies waited for the end of the launch: 0.14 of a 1.17 ms call at cfg5)
+    const int rounds = (g.m + ctx->cus - 1) / ctx->cus;
+    const int nb = std::min(ctx->cus, (g.m + rounds - 1) / rounds);
     g.slab = ((size_t)std::max(g.ldr, 16 + KS_KP) + 31) & ~(size_t)31;
     JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
     g.scratch = (double *)ctx->xstage.ptr;
