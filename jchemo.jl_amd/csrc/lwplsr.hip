@@ -1143,11 +1143,13 @@ extern "C" int32_t jch_lwplsr_prepare(jch_ctx *ctx, int32_t loc, const double *X
     }
     jch_lw_to_rowmajor(ctx, dX, ldxd, n, (int)p, mo->Xrm, mo->ldr);
     if (dd <= 62 && n < ((int64_t)1 << 26)) {   // (whether a call is screened also depends on its k: jch_knn_screen_shape_ok)
-        if (hipMalloc(&mo->screen_mem, jch_knn_screen_model_bytes(n, (int)dd)) != hipSuccess)
-            return fail(jch_fail(ctx, JCH_ENOMEM, "jch_lwplsr_prepare: device allocation failed (screened kNN operand)"));
-        const int32_t st = jch_knn_screen_build(ctx, mo->Zt, n, n, (int)dd, mo->screen_mem, &mo->screen);
-        if (st != JCH_OK) return fail(st);
-        mo->has_screen = true;
+        // (no memory for the operand copy: the model works without it — every call then builds it in the ctx workspace, or scans)
+        if (hipMalloc(&mo->screen_mem, jch_knn_screen_model_bytes(n, (int)dd)) != hipSuccess) { mo->screen_mem = nullptr; (void)hipGetLastError(); }
+        else {
+            const int32_t st = jch_knn_screen_build(ctx, mo->Zt, n, n, (int)dd, mo->screen_mem, &mo->screen);
+            if (st != JCH_OK) return fail(st);
+            mo->has_screen = true;
+        }
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(jch_fail(ctx, JCH_EHIP, "jch_lwplsr_prepare: row-major copy failed"));

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_knn_gmin(ks_args g)
         }
 #pragma unroll
         for (int u = 0; u < QW; ++u)
-            if (qg * QW + u < g.nqt) g.gmin[((size_t)(qg * QW + u) * g.nslots + slot) * 64 + lane] = mn[u];
+            if (qg * QW + u < g.nqt) g.gmin[((size_t)(qg * QW + u) * g.nslots + slot) * 64 + lane] = mn[u];   // ([query tile][lane][slot] — contiguous reads for k_knn_bar — was measured: bar 10.5 -> 6.8 us, this kernel 17 -> 21.8 with its scattered stores)
     }
 }
 
@@ -364,13 +364,19 @@ __global__ __launch_bounds__(256) void k_knn_bar(ks_args g)
                 const int mid = (lo + hi) >> 1;
                 if (count((unsigned)__shfl((int)sv, mid, 64)) >= g.a.k) hi = mid; else lo = mid + 1;
             }
-            // (lo_v, hi_v]: the sample below the pivot (fewer than k values at or below it) and the pivot; five steps of value
-            // bisection on the keys bring the bar within 1 / 32 of a sample gap of the k-th smallest
+            // (lo_v, hi_v]: the sample below the pivot (fewer than k values at or below it) and the pivot.  Value bisection on the keys
+            // until at most k + k / 64 + 1 values lie at or below the bar — a few steps when the samples are representative, up to 32
+            // (the exact radix descent) when they are not: the samples are each lane's FIRST value, i.e. the first 64 group slots, and a
+            // query at the edge of an ordered training set has all its near groups elsewhere (2086 survivors instead of ~230, found by
+            // test_screen_with_sorted_rows_and_a_wide_range)
             unsigned hi_v = (unsigned)__shfl((int)sv, hi, 64);
             unsigned lo_v = hi > 0 ? (unsigned)__shfl((int)sv, hi - 1, 64) : 0u;
-            for (int it = 0; it < 5 && hi_v - lo_v > 1u; ++it) {
+            int c_hi = count(hi_v);
+            const int want = g.a.k + (g.a.k >> 6) + 1;
+            for (int it = 0; it < 32 && hi_v - lo_v > 1u && c_hi > want; ++it) {
                 const unsigned mid_v = lo_v + ((hi_v - lo_v) >> 1);
-                if (count(mid_v) >= g.a.k) hi_v = mid_v; else lo_v = mid_v;
+                const int cm = count(mid_v);
+                if (cm >= g.a.k) { hi_v = mid_v; c_hi = cm; } else lo_v = mid_v;
             }
             prefix = hi_v;
         } else {
@@ -594,32 +600,35 @@ __global__ __launch_bounds__(256) void k_knn_finish_screen(ks_args g)
     __syncthreads();
     if (dbg & 4) { for (int e = tid; e < k; e += 256) { okey[e] = key[e]; oidx[e] = idx[e]; } }
     else
-    if (c <= 256) {
-        // four segments of 64 entries, each put in order by one wave on its registers, then MERGED BY RANK: an entry's place is its place
-        // in its own segment plus, for every other segment, the number of entries there that come before it — a binary search each
-        // (two barriers; the workgroup-wide bitonic sort has 36, and ordering by rank over ALL entries — c steps per entry — was
-        // measured at 24 us of this kernel's 55)
-        double kv = key[tid];
-        int iv = idx[tid];
-        knn_sort64_lanes(kv, iv);
+    if (c <= 512) {
+        // segments of 64 entries (four, or eight: two per wave), each put in order by one wave on its registers, then MERGED BY RANK: an
+        // entry's place is its place in its own segment plus, for every other segment, the number of entries there that come before
+        // it — a binary search each (two barriers; the workgroup-wide bitonic sort has 36 and more, and ordering by rank over ALL
+        // entries — c steps per entry — was measured at 24 us of this kernel's 55)
+        const int nseg = cap >> 6, per = cap >> 8;                 // cap = 256 or 512: 1 or 2 entries per thread
+        double kv[2];
+        int iv[2];
+        for (int u = 0; u < per; ++u) { kv[u] = key[tid + 256 * u]; iv[u] = idx[tid + 256 * u]; knn_sort64_lanes(kv[u], iv[u]); }
         __syncthreads();
-        key[tid] = kv; idx[tid] = iv;
+        for (int u = 0; u < per; ++u) { key[tid + 256 * u] = kv[u]; idx[tid + 256 * u] = iv[u]; }
         __syncthreads();
-        const int s_ = tid >> 6;
-        int rank = tid & 63;
-        for (int s2 = 0; s2 < 4; ++s2) {
-            if (s2 == s_) continue;
-            const double *kl = key + 64 * s2;
-            const int *il = idx + 64 * s2;
-            int lo = 0, hi = 64;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const double kb = kl[mid];
-                if ((kb < kv) || (kb == kv && il[mid] < iv)) lo = mid + 1; else hi = mid;
+        for (int u = 0; u < per; ++u) {
+            const int s_ = (tid + 256 * u) >> 6;
+            int rank = tid & 63;
+            for (int s2 = 0; s2 < nseg; ++s2) {
+                if (s2 == s_) continue;
+                const double *kl = key + 64 * s2;
+                const int *il = idx + 64 * s2;
+                int lo = 0, hi = 64;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const double kb = kl[mid];
+                    if ((kb < kv[u]) || (kb == kv[u] && il[mid] < iv[u])) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
             }
-            rank += lo;
+            if (rank < k && iv[u] != 0x7fffffff) { okey[rank] = kv[u]; oidx[rank] = iv[u]; }
         }
-        if (rank < k && iv != 0x7fffffff) { okey[rank] = kv; oidx[rank] = iv; }
     } else {
         bitonic_sort_n<256>(key, idx, cap);
         for (int e = tid; e < k; e += 256) { okey[e] = key[e]; oidx[e] = idx[e]; }
