@@ -198,3 +198,45 @@ def test_one_shot_call_is_screened_too(ctx):
     for j in range(m):
         order = np.lexsort((np.arange(n), d2[:, j]))[:k]
         assert np.array_equal(out["screen"][1][j], order)
+
+
+def test_screen_fuzz_against_the_exact_scan(ctx):
+    """Seeded shapes and score distributions (Gaussian, sorted along a column, tight clusters, heavy tails, duplicated rows, queries
+    taken from the training set or far outside it) through the one-shot entry point with the screen and with the exact scan:
+    neighbours, distances, weights and predictions must be identical whatever the screen makes of the geometry."""
+    from jchemo_hip import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(int(os.environ.get("JCH_FUZZ_SEED", "20261005")))
+    screened = redone = 0
+    for case in range(24):
+        dd = int(rng.integers(1, 31)); k = int(rng.integers(1, 301)); m = int(rng.integers(1, 90))
+        n = int(rng.integers(max(40 * k, 2000), max(40 * k, 2000) + 40000)); p = 6
+        kind = case % 6
+        Z = rng.standard_normal((n, dd))
+        if kind == 1: Z = Z[np.argsort(Z[:, 0])]
+        if kind == 2: Z = rng.standard_normal((8, dd))[rng.integers(0, 8, n)] * 10.0 + 0.05 * Z
+        if kind == 3: Z = rng.standard_t(2.5, size=(n, dd))
+        if kind == 4: Z[n // 2:] = Z[: n - n // 2]
+        if kind == 5: Z = Z * 10.0 ** rng.uniform(-2, 2, size=dd) + 100.0
+        Zq = Z[rng.integers(0, n, m)] + 1e-3 * rng.standard_normal((m, dd)) if case % 2 else rng.standard_normal((m, dd)) * Z.std(axis=0) * 1.5 + Z.mean(axis=0)
+        X = np.asfortranarray(rng.standard_normal((n, p))); Y = np.asfortranarray(X[:, :1] + 0.1 * rng.standard_normal((n, 1)))
+        Xq = np.asfortranarray(rng.standard_normal((m, p)))
+        Zt = np.asfortranarray(Z); Zq = np.asfortranarray(Zq)
+        out = {}
+        for tag, env in (("screen", None), ("scan", "0")):
+            if env is not None:
+                os.environ["JCH_KNN_SCREEN"] = env
+            try:
+                pred = np.zeros((m, 2, 1)); ind = np.zeros((m, k), np.int32); dist = np.zeros((m, k)); w = np.zeros((m, k))
+                s0, r0 = ctx.counter(SCREENED), ctx.counter(REDONE)
+                dp = lambda a: a.ctypes.data
+                ctx.check(lib.jch_lwplsr_predict(ctx._h, 0, dp(X), n, p, n, dp(Y), 1, n, dp(Zt), n, dp(Zq), m, dd, dp(Xq), m, m, k, 2.0, 1e-4, 0, 0, 1,
+                                                 dp(pred), dp(ind), dp(dist), dp(w)))
+                out[tag] = (pred, ind, dist, w)
+                if env is None:
+                    screened += ctx.counter(SCREENED) - s0; redone += ctx.counter(REDONE) - r0
+            finally:
+                os.environ.pop("JCH_KNN_SCREEN", None)
+        for i in range(4):
+            assert np.array_equal(out["screen"][i], out["scan"][i], equal_nan=True), (case, kind, n, dd, k, m, i)
+    assert screened > 0                                               # (most of these shapes are inside the screen's envelope)
