@@ -171,62 +171,56 @@ __global__ __launch_bounds__(256) void k_ks_pack_rows(const double *__restrict__
     }
 }
 
-// one thread per (query tile, lane)
+// The query operand of one lane (query tile qt): its 8 KS slots of query j = 32 qt + lane % 32, and |zq|^2 of the two-piece query
+// (rounded up to f32).  Every score column is loaded once, all loads in flight together; the slots are picked with compile-time
+// indices for both halves of the wave and selected by the lane's half.  The waves of k_knn_gmin build their operand with this
+// themselves (round 4: a separate kernel in front of them cost 11 us per call at cfg5 for 2048 threads' worth of work) and the
+// first row chunk's waves store it for k_knn_survive.
 template <int KS>
-__global__ __launch_bounds__(256) void k_ks_pack_queries(ks_args g)
+__device__ __forceinline__ void ks_make_b(const ks_args &g, int qt, int lane, uint4 (&b)[KS], float &nqf)
 {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int qt = gid >> 6, lane = gid & 63;
-    if (qt >= g.nqt) return;
+    constexpr int DMAX = (16 * KS - 4) / 3;                        // score columns KS k-steps can hold: 3 dd + 4 <= 16 KS
     const int j = qt * 32 + (lane & 31), h = lane >> 5, dd = g.a.dd;
     const bool live = j < g.a.m;
     const double *zqp = g.a.Zq + (size_t)min(j, g.a.m - 1);
-    unsigned short v[KS * 8];
-    // (this lane's slots first — their loads go out together —, then the norm over all columns)
-    float fv[KS * 8];
+    float fv[DMAX];
 #pragma unroll
-    for (int sl = 0; sl < KS * 8; ++sl) {
-        const int kk = 16 * (sl >> 3) + 8 * h + (sl & 7);
-        const int c = min(kk / 3, dd - 1);
-        fv[sl] = -2.0f * (float)(zqp[(size_t)c * (size_t)g.a.ldzq] - g.sc.mu[c]);
-    }
+    for (int c = 0; c < DMAX; ++c) { const int cc = min(c, dd - 1); fv[c] = -2.0f * (float)(zqp[(size_t)cc * (size_t)g.a.ldzq] - g.sc.mu[cc]); }
+    unsigned short hi[DMAX], lo[DMAX];
     double nq = 0.0;
-    for (int c0 = 0; c0 < dd; c0 += 8) {
-        double x[8], m8[8];
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) { const int c = min(c0 + cc, dd - 1); x[cc] = zqp[(size_t)c * (size_t)g.a.ldzq]; m8[cc] = g.sc.mu[c]; }
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
-            if (c0 + cc < dd && live) {
-                unsigned hi, lo;
-                ks_split(-2.0f * (float)(x[cc] - m8[cc]), hi, lo);
-                const double qq = 0.5 * ((double)ks_bf16_f(hi) + (double)ks_bf16_f(lo));
-                nq += qq * qq;
-            }
+    for (int c = 0; c < DMAX; ++c) {
+        unsigned h_, l_;
+        ks_split((live && c < dd) ? fv[c] : 0.0f, h_, l_);
+        hi[c] = (unsigned short)h_; lo[c] = (unsigned short)l_;
+        const double qq = 0.5 * ((double)ks_bf16_f(h_) + (double)ks_bf16_f(l_));
+        nq += qq * qq;
     }
-    float nqf = (float)nq;
+    nqf = (float)nq;
     if ((double)nqf < nq) nqf = __uint_as_float(__float_as_uint(nqf) + 1u);
     unsigned m1, m2;
     ks_split((float)nq, m1, m2);
-#pragma unroll
-    for (int sl = 0; sl < KS * 8; ++sl) {
-        const int kk = 16 * (sl >> 3) + 8 * h + (sl & 7);
+    auto slot = [&](int kk) -> unsigned {                          // (kk is a compile-time constant at every call)
         const int c = kk / 3, t = kk - 3 * c;
         unsigned val = 0u;
-        if (c < dd) {
-            unsigned hi, lo;
-            ks_split(live ? fv[sl] : 0.0f, hi, lo);
-            val = t == 1 ? lo : hi;
-        } else if (kk == 3 * dd || kk == 3 * dd + 1) val = 0x3f80u;
+        if (c < DMAX) val = t == 1 ? lo[c] : hi[c];                  // (columns >= dd hold zeros: overwritten below where the norm slots sit)
+        if (kk == 3 * dd || kk == 3 * dd + 1) val = 0x3f80u;        // 1.0
         else if (kk == 3 * dd + 2) val = m1;
         else if (kk == 3 * dd + 3) val = m2;
-        v[sl] = (unsigned short)val;
+        else if (kk > 3 * dd + 3) val = 0u;
+        return val;
+    };
+    unsigned short v[KS * 8];
+#pragma unroll
+    for (int sl = 0; sl < KS * 8; ++sl) {
+        const int k0 = 16 * (sl >> 3) + (sl & 7);
+        const unsigned v0 = slot(k0), v1 = slot(k0 + 8);
+        v[sl] = (unsigned short)(h ? v1 : v0);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-        g.Qs[((size_t)qt * KS + ks) * 64 + lane] = make_uint4(v[8 * ks] | ((unsigned)v[8 * ks + 1] << 16), v[8 * ks + 2] | ((unsigned)v[8 * ks + 3] << 16),
-                                                              v[8 * ks + 4] | ((unsigned)v[8 * ks + 5] << 16), v[8 * ks + 6] | ((unsigned)v[8 * ks + 7] << 16));
-    if (h == 0) g.nq[j] = (double)nqf;
+        b[ks] = make_uint4(v[8 * ks] | ((unsigned)v[8 * ks + 1] << 16), v[8 * ks + 2] | ((unsigned)v[8 * ks + 3] << 16),
+                           v[8 * ks + 4] | ((unsigned)v[8 * ks + 5] << 16), v[8 * ks + 6] | ((unsigned)v[8 * ks + 7] << 16));
 }
 
 // ---------------------------------------------------------------- the two passes over all pairs
@@ -270,7 +264,7 @@ __device__ __forceinline__ bool ks_item(int nchunks, int nqg, int &qg, int &chun
 // ran into the L2 bandwidth: 4 KB of operand per 1024 pairs, 17 TB/s at cfg5), row chunk w / nqg (gpw group slots); the four waves of
 // a workgroup share the chunk
 template <int KS, int QW>
-__global__ __launch_bounds__(256) void k_knn_gmin(ks_args g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_knn_gmin(ks_args g)   // (four waves per SIMD: the operand builder at the top would take more registers than the tile loop if it were let)
 {
     const int lane = threadIdx.x & 63;
     const int nqg = (g.nqt + QW - 1) / QW;
@@ -278,7 +272,16 @@ __global__ __launch_bounds__(256) void k_knn_gmin(ks_args g)
     if (!ks_item(g.nchunks_g, nqg, qg, chunk)) return;
     uint4 b[QW][KS];
 #pragma unroll
-    for (int u = 0; u < QW; ++u) ks_load_b<KS>(g, min(qg * QW + u, g.nqt - 1), lane, b[u]);
+    for (int u = 0; u < QW; ++u) {
+        const int qt = min(qg * QW + u, g.nqt - 1);
+        float nqf;
+        ks_make_b<KS>(g, qt, lane, b[u], nqf);
+        if (chunk == 0 && qg * QW + u < g.nqt) {                  // for k_knn_bar (the norm) and k_knn_survive (the operand)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) g.Qs[((size_t)qt * KS + ks) * 64 + lane] = b[u][ks];
+            if (lane < 32) g.nq[qt * 32 + lane] = (double)nqf;
+        }
+    }
     for (int gi = 0; gi < g.gpw_g; ++gi) {
         const int slot = chunk * g.gpw_g + gi;
         if (slot >= g.nslots) break;
@@ -712,7 +715,6 @@ int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int6
 template <int KS>
 static void ks_launch_passes(jch_ctx *ctx, const ks_args &g)
 {
-    hipLaunchKernelGGL((k_ks_pack_queries<KS>), dim3((unsigned)((g.nqt * 64 + 255) / 256)), dim3(256), 0, ctx->stream, g);
     (void)jch_ev(ctx);
     constexpr int QWmax = KS <= 6 ? 2 : 1;                       // (registers: 4 KS per 32 queries for their operand)
     auto grid = [&](int qw, int nchunks) { return (unsigned)(((nchunks + 7) / 8) * (((g.nqt + qw - 1) / qw + 3) / 4) * 8); };   // (ks_item)
