@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256) void k_ks_pack_rows(const double *__restrict__
 
 // The query operand of one lane (query tile qt): its 8 KS slots of query j = 32 qt + lane % 32, and |zq|^2 of the two-piece query
 // (rounded up to f32).  Every score column is loaded once, all loads in flight together; the slots are picked with compile-time
-// indices for both halves of the wave and selected by the lane's half.  The waves of k_knn_gmin build their operand with this
-// themselves (round 4: a separate kernel in front of them cost 11 us per call at cfg5 for 2048 threads' worth of work) and the
-// first row chunk's waves store it for k_knn_survive.
+// indices for both halves of the wave and selected by the lane's half.  (Measured and dropped: the waves of k_knn_gmin building
+// their operand with this themselves instead of a kernel in front of them — 11 us per call at cfg5 for 2048 threads' worth of work
+// —: 7152 waves each running this once took the pass from 17 to 48 us.)
 template <int KS>
 __device__ __forceinline__ void ks_make_b(const ks_args &g, int qt, int lane, uint4 (&b)[KS], float &nqf)
 {
@@ -223,6 +223,21 @@ __device__ __forceinline__ void ks_make_b(const ks_args &g, int qt, int lane, ui
                            v[8 * ks + 4] | ((unsigned)v[8 * ks + 5] << 16), v[8 * ks + 6] | ((unsigned)v[8 * ks + 7] << 16));
 }
 
+// one thread per (query tile, lane)
+template <int KS>
+__global__ __launch_bounds__(256) void k_ks_pack_queries(ks_args g)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int qt = gid >> 6, lane = gid & 63;
+    if (qt >= g.nqt) return;
+    uint4 b[KS];
+    float nqf;
+    ks_make_b<KS>(g, qt, lane, b, nqf);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) g.Qs[((size_t)qt * KS + ks) * 64 + lane] = b[ks];
+    if (lane < 32) g.nq[qt * 32 + lane] = (double)nqf;
+}
+
 // ---------------------------------------------------------------- the two passes over all pairs
 template <int KS>
 __device__ __forceinline__ void ks_load_b(const ks_args &g, int qt, int lane, uint4 (&b)[KS])
@@ -264,7 +279,7 @@ __device__ __forceinline__ bool ks_item(int nchunks, int nqg, int &qg, int &chun
 // ran into the L2 bandwidth: 4 KB of operand per 1024 pairs, 17 TB/s at cfg5), row chunk w / nqg (gpw group slots); the four waves of
 // a workgroup share the chunk
 template <int KS, int QW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_knn_gmin(ks_args g)   // (four waves per SIMD: the operand builder at the top would take more registers than the tile loop if it were let)
+__global__ __launch_bounds__(256) void k_knn_gmin(ks_args g)
 {
     const int lane = threadIdx.x & 63;
     const int nqg = (g.nqt + QW - 1) / QW;
@@ -272,16 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (!ks_item(g.nchunks_g, nqg, qg, chunk)) return;
     uint4 b[QW][KS];
 #pragma unroll
-    for (int u = 0; u < QW; ++u) {
-        const int qt = min(qg * QW + u, g.nqt - 1);
-        float nqf;
-        ks_make_b<KS>(g, qt, lane, b[u], nqf);
-        if (chunk == 0 && qg * QW + u < g.nqt) {                  // for k_knn_bar (the norm) and k_knn_survive (the operand)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) g.Qs[((size_t)qt * KS + ks) * 64 + lane] = b[u][ks];
-            if (lane < 32) g.nq[qt * 32 + lane] = (double)nqf;
-        }
-    }
+    for (int u = 0; u < QW; ++u) ks_load_b<KS>(g, min(qg * QW + u, g.nqt - 1), lane, b[u]);
     for (int gi = 0; gi < g.gpw_g; ++gi) {
         const int slot = chunk * g.gpw_g + gi;
         if (slot >= g.nslots) break;
@@ -715,6 +721,7 @@ int32_t jch_knn_screen_build(jch_ctx *ctx, const double *dZt, int64_t ldzt, int6
 template <int KS>
 static void ks_launch_passes(jch_ctx *ctx, const ks_args &g)
 {
+    hipLaunchKernelGGL((k_ks_pack_queries<KS>), dim3((unsigned)((g.nqt * 64 + 255) / 256)), dim3(256), 0, ctx->stream, g);
     (void)jch_ev(ctx);
     constexpr int QWmax = KS <= 6 ? 2 : 1;                       // (registers: 4 KS per 32 queries for their operand)
     auto grid = [&](int qw, int nchunks) { return (unsigned)(((nchunks + 7) / 8) * (((g.nqt + qw - 1) / qw + 3) / 4) * 8); };   // (ks_item)
