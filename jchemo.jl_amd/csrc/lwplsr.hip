@@ -8,10 +8,12 @@
 //                       replaces locwlv (src/locwlv.jl:9-48: Threads.@threads over queries, plskern + predict per query)
 // The reference runs m independent small fits on CPU threads; here a query's whole fit lives in one workgroup:
 // its k x p block (0.8 MB at cfg5) is gathered once into an L2/MALL-resident scratch slab and swept once per LV.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <type_traits>
 #include <new>
 #include <vector>
@@ -913,11 +915,10 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     // fresh arrays that have never been touched) run on a second stream BESIDE the local fits instead of after them
     // JCH_LW_LISTS_STAGED=1 (round 4, measured, NOT the default): the neighbour lists go to pinned staging through copies queued on
     // the main stream IN FRONT of the local fits, and the host moves them on to the caller's arrays while the local fits run.  Why
-    // it was tried: copies are CU kernels on this stack and the local-fit launch takes every CU, so of the three copies queued beside
-    // it on the second stream (the default below) one runs during the launch and two after it — 150 us of device tail per call at cfg5;
-    // in front of the launch they cost 75 us (device timeline: profiles/r04_lw_timeline.txt).  The device span of a call shrank
-    // (1168 -> 1131 us under the tracer) but the call as the host sees it got SLOWER on the same box, three A/B pairs: 1.20-1.25 ms
-    // against 1.17-1.18 — the host's own copy of 4 MB out of the staging is not free either.  Kept for hosts where it pays.
+    // it was tried: under rocprofv3 two of the three list copies of the default arrangement (second stream, beside the local fits)
+    // show up AFTER the local-fit launch.  Without the tracer they do not (JCH_LW_HOST_DBG=1 host stamps: the lists are on the
+    // host 250 us after the kNN launches, the main stream's wait ends at 1036 us; staged: 1100-1115 us, the copies delay the local
+    // fits by their 75 us): 1.20-1.25 ms per call against 1.17-1.18 on the same box.  Kept for stacks where the copies do starve.
     const size_t list_bytes = (ind_out ? sizeof(int) : 0) * (size_t)m * k + ((dist_out ? 1 : 0) + (w_out ? 1 : 0)) * sizeof(double) * (size_t)m * k;
     const size_t pred_bytes_ = sizeof(double) * (size_t)m * le * q + sizeof(int) * 2 * (size_t)m + 64;
     const char *e_ls = getenv("JCH_LW_LISTS_STAGED");
@@ -941,13 +942,19 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     // the lists are on the host as soon as their event is: on to the caller's arrays (beside the batched local fits; BEFORE per-query
     // fits, which use the pinned staging themselves)
     bool lists_drained = !lists_staged;
+    const bool host_dbg = getenv("JCH_LW_HOST_DBG") != nullptr;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count(); };
     auto drain_lists = [&]() -> int32_t {
         if (lists_drained) return JCH_OK;
         lists_drained = true;
+        const double t0 = since();
         JCH_HIP(ctx, hipEventSynchronize(ctx->aux_event));
+        const double t1 = since();
         if (dist_out) memcpy(dist_out, hl_d, sizeof(double) * (size_t)m * k);
         if (w_out) memcpy(w_out, hl_w, sizeof(double) * (size_t)m * k);
         if (ind_out) memcpy(ind_out, hl_i, sizeof(int) * (size_t)m * k);
+        if (host_dbg) fprintf(stderr, "[jch] lists staged: wait for the event %.0f .. %.0f us after the kNN launches, host copy until %.0f\n", t0, t1, since());
         return JCH_OK;
     };
     bool side_copies = !lists_staged && (ind_out || dist_out || w_out) && !getenv("JCH_LW_SIDE_COPY_OFF");
@@ -1014,7 +1021,9 @@ static int32_t lw_run(jch_ctx *ctx, const double *Xrm, int ldr, int64_t n, int64
     if (ce != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return jch_fail(ctx, JCH_EHIP, "jch_lwplsr_predict: copy of the neighbour lists failed: %s", hipGetErrorString(ce)); }
     std::vector<int> hf, hsf;
     if (staged) {
+        const double ts0 = since();
         JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (host_dbg) fprintf(stderr, "[jch] stream wait %.0f .. %.0f us\n", ts0, since());
         memcpy(pred, hs + flag_bytes, pred_bytes);
         const int *hfl = reinterpret_cast<const int *>(hs);
         if (kflags) hf.assign(hfl, hfl + m);
