@@ -658,8 +658,8 @@ static int32_t launch_ks(jch_ctx *ctx, locw_args &g)
         attr.mark(ctx->device);
     }
     // as many workgroups as the queries need for the same number of rounds: 1000 queries on 256 CUs are 4 rounds with 250 workgroups as
-    // with 256, and the 6 CUs left free run the copy kernels of the neighbour lists, which travel to the host beside this launch
-    // (with every CU taken those copies waited for the end of the launch: 0.14 of a 1.17 ms call at cfg5)
+    // with 256, every workgroup then runs the same number of queries, and the CUs left free take the copy kernels of the neighbour
+    // lists, which travel to the host beside this launch (no measurable difference at cfg5)
     const int rounds = (g.m + ctx->cus - 1) / ctx->cus;
     const int nb = std::min(ctx->cus, (g.m + rounds - 1) / rounds);
     g.slab = ((size_t)std::max(g.ldr, 16 + KS_KP) + 31) & ~(size_t)31;
