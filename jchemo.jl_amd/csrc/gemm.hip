@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void k_affine_gemm32s(const double *__restrict
 // single barrier, X loads PD k-steps ahead of the MFMAs in a rotating register window.  With f64 MFMA at the vector rate
 // (64 cycles per 16x16x4) the product itself is 0.41 ms at cfg2 / nlv = 25 against 0.50 ms of HBM time for X: the kernel
 // is co-bound, and what matters is that neither pipe waits for the other.
-template <int NT, int NW, int RT>   // NW waves per workgroup share the one LDS copy of the coefficients; RT row tiles of 32 per wave-tile
+// PAIRED (round 4): the tile TRANSPOSED (operands swapped: the same registers) and rows 2 cl, 2 cl + 1 of a column stored as one
+// 16-byte piece — see k_affine_gemm_wideout.
+template <int NT, int NW, int RT, bool PAIRED>   // NW waves per workgroup share the one LDS copy of the coefficients; RT row tiles of 32 per wave-tile
 __global__ __launch_bounds__(64 * NW) void k_affine_gemm32p(const double *__restrict__ Xc, int64_t m, int p, int64_t ldx,
                                                          const double *__restrict__ Bs, int kpad, const double *__restrict__ bias,
                                                          int k, double *__restrict__ out, int64_t ldo)
@@ -280,14 +282,35 @@ __global__ __launch_bounds__(64 * NW) void k_affine_gemm32p(const double *__rest
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        acc[rt][0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][rt].x, b[t], acc[rt][0][t], 0, 0, 0);
-                        acc[rt][1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][rt].y, b[t], acc[rt][1][t], 0, 0, 0);
+                        if (PAIRED) {
+                            acc[rt][0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[t], x[u][rt].x, acc[rt][0][t], 0, 0, 0);
+                            acc[rt][1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[t], x[u][rt].y, acc[rt][1][t], 0, 0, 0);
+                        } else {
+                            acc[rt][0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][rt].x, b[t], acc[rt][0][t], 0, 0, 0);
+                            acc[rt][1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][rt].y, b[t], acc[rt][1][t], 0, 0, 0);
+                        }
                     }
                     x[u][rt] = ld(wrap ? nxt[rt] : cur[rt], kb + u);
                 }
             }
         }
         const int64_t i0 = tile * TR;
+        if (PAIRED) {
+            // acc[rt][par][t][reg] of lane (kq, cl) = out[row i0 + 32 rt + 2 cl + par][column 16 t + kq + 4 reg]  (f64 16x16x4: D[kq + 4 reg][cl])
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int col = 16 * t + kq + 4 * reg;
+                    if (col >= k) continue;
+                    const double bv = bias[col];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int64_t i = i0 + 32 * rt + 2 * cl;
+                        if (i + 1 < m) *reinterpret_cast<v2f64 *>(out + (size_t)i + (size_t)col * (size_t)ldo) = v2f64{acc[rt][0][t][reg] + bv, acc[rt][1][t][reg] + bv};
+                    }
+                }
+        } else
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = 16 * t + cl;
@@ -313,10 +336,15 @@ __global__ __launch_bounds__(64 * NW) void k_affine_gemm32p(const double *__rest
 // wrote 64-row pieces; here a wave keeps its 64 input rows (p <= 64 columns: <= 16 k-steps) in registers, walks ALL output column
 // tiles against the coefficient matrix in LDS and writes 512-B runs per output column.  The pass is bound by its OUTPUT (2.08 GB at
 // cfg2 against 0.2 GB read).
-template <int KS, int RT>   // KS k-steps of 4 input columns held in registers (p <= 4 KS); RT row tiles of 32 per wave-tile
+// PAIRED (round 4): the tile is computed TRANSPOSED — the coefficients as the A operand, the rows as the B operand: the same registers,
+// the operands swapped — so that a lane holds rows 2 cl and 2 cl + 1 of output column kq + 4 reg and stores them as ONE 16-byte
+// piece: 16 lanes write a contiguous 256-byte run of a column.  Untransposed, a store instruction scattered 64 8-byte pieces over
+// 16 columns x 4 rows 16 bytes apart, and the pieces of a line met in L2 from eight instructions (2.08 GB of output at 2.4 TB/s).
+// Needs out 16-byte aligned and ldo even (the launcher checks); the values are the same sums in the same order.
+template <int KS, int RT, bool PAIRED>   // KS k-steps of 4 input columns held in registers (p <= 4 KS); RT row tiles of 32 per wave-tile
 __global__ __launch_bounds__(256) void k_affine_gemm_wideout(const double *__restrict__ Xc, int64_t m, int p, int64_t ldx,
                                                            const double *__restrict__ Bs, int kpad, const double *__restrict__ bias,
-                                                           int k, double *__restrict__ out, int64_t ldo)
+                                                           int k, double *__restrict__ out, int64_t ldo, int nt)
 {
     extern __shared__ __attribute__((aligned(16))) double blw[];   // [4 KS][kpad + 1], zero rows beyond p
     const int PB = kpad + 1;
@@ -351,9 +379,34 @@ __global__ __launch_bounds__(256) void k_affine_gemm_wideout(const double *__res
                 const double b = blw[(4 * ks + kq) * PB + 16 * ct + cl];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks][rt].x, b, acc[rt][0], 0, 0, 0);
-                    acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks][rt].y, b, acc[rt][1], 0, 0, 0);
+                    if (PAIRED) {
+                        acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, x[ks][rt].x, acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, x[ks][rt].y, acc[rt][1], 0, 0, 0);
+                    } else {
+                        acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks][rt].x, b, acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks][rt].y, b, acc[rt][1], 0, 0, 0);
+                    }
                 }
+            }
+            if (PAIRED) {
+                // acc[rt][par][reg] of lane (kq, cl) = out[row i0 + 32 rt + 2 cl + par][column 16 ct + kq + 4 reg]  (f64 16x16x4: D[kq + 4 reg][cl])
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int col = 16 * ct + kq + 4 * reg;
+                    if (col < k) {
+                        const double bv = bias[col];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const int64_t i = i0 + 32 * rt + 2 * cl;
+                            if (i + 1 < m) {
+                                const v2f64 val = {acc[rt][0][reg] + bv, acc[rt][1][reg] + bv};
+                                v2f64 *dst = reinterpret_cast<v2f64 *>(out + (size_t)i + (size_t)col * (size_t)ldo);
+                                if (nt) __builtin_nontemporal_store(val, dst); else *dst = val;
+                            }
+                        }
+                    }
+                }
+                continue;
             }
             const int col = 16 * ct + cl;
             if (col < k) {
@@ -389,12 +442,16 @@ int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p,
             // row tiles per wave-tile = 256 rt bytes per column piece.  Measured at cfg2 (round 4, tools/bench_accessors.py, whole call):
             // transform (32 columns) rt = 1 / 2 / 4: 0.905 / 0.877 / 0.846 ms; predict at one nlv (16 columns): 0.839 / 0.769 / 0.768 ms
             const int rt = ert ? (atoi(ert) == 1 ? 1 : (atoi(ert) == 2 ? 2 : 4)) : 4;
+            const char *ep32 = getenv("JCH_GEMM_PAIRED");          // (=0: the untransposed tile with 8-byte stores — A/B runs)
+            const bool paired32 = !(ep32 && atoi(ep32) == 0) && ldo % 2 == 0 && (((uintptr_t)out) & 15) == 0;
             const int bpc = std::max(1, std::min((int)((158 * 1024) / ldsp), 8 / nw));
             const unsigned nb = (unsigned)std::min<int64_t>((m + 32 * rt * nw - 1) / (32 * rt * nw), (int64_t)ctx->cus * bpc);
 #define JCH_G32P(NT, NW, RT) do { \
                 static jch_per_device_once once_; \
-                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<NT, NW, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
-                hipLaunchKernelGGL((k_affine_gemm32p<NT, NW, RT>), dim3(nb), dim3(64 * NW), ldsp, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo); } while (0)
+                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<NT, NW, RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                    JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm32p<NT, NW, RT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
+                if (paired32) hipLaunchKernelGGL((k_affine_gemm32p<NT, NW, RT, true>), dim3(nb), dim3(64 * NW), ldsp, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo); \
+                else hipLaunchKernelGGL((k_affine_gemm32p<NT, NW, RT, false>), dim3(nb), dim3(64 * NW), ldsp, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo); } while (0)
 #define JCH_G32P_RT(NT, NW) do { if (rt == 1) JCH_G32P(NT, NW, 1); else if (rt == 2) JCH_G32P(NT, NW, 2); else JCH_G32P(NT, NW, 4); } while (0)
             if (kpad == 16) { if (nw == 4) JCH_G32P_RT(1, 4); else JCH_G32P_RT(1, 8); }
             else { if (nw == 4) JCH_G32P_RT(2, 4); else JCH_G32P_RT(2, 8); }
@@ -425,17 +482,23 @@ int32_t jch_launch_affine_gemm(jch_ctx *ctx, const double *Xc, int64_t m, int p,
         // and must meet in L2.
         const char *ew = getenv("JCH_GEMM_WIDEOUT"), *er = getenv("JCH_GEMM_WIDEOUT_RT");
         const int ks = (p + 3) / 4;
-        const int rtw = (er && atoi(er) == 2) ? 2 : 4;
+        const int rtw = er ? (atoi(er) == 1 ? 1 : atoi(er) == 4 ? 4 : 2) : 2;   // (round 4, with the paired stores: 64-row wave tiles 1.50 ms, 128-row 1.65)
         const size_t ldsw = sizeof(double) * (size_t)(4 * (ks <= 4 ? 4 : ks <= 8 ? 8 : 16)) * (kpad + 1);
         if (!(ew && atoi(ew) == 0) && p <= 64 && kpad > 32 && ldsw <= 150 * 1024 && m >= 4096 && m % 2 == 0 && ldx % 2 == 0 && (((uintptr_t)Xc) & 15) == 0) {
             const unsigned nb = (unsigned)std::min<int64_t>((m + 32 * rtw * 4 - 1) / (32 * rtw * 4), (int64_t)ctx->cus * 2);
+            const char *epair = getenv("JCH_GEMM_WIDEOUT_PAIRED");     // (=0: the untransposed tile with 8-byte stores — A/B runs)
+            const bool paired = !(epair && atoi(epair) == 0) && ldo % 2 == 0 && (((uintptr_t)out) & 15) == 0;
+            const char *ent = getenv("JCH_GEMM_WIDEOUT_NT");
+            const int nt_ = ent ? atoi(ent) : 0;
 #define JCH_GW(KS, RT) do { \
                 static jch_per_device_once once_; \
-                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm_wideout<KS, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
-                hipLaunchKernelGGL((k_affine_gemm_wideout<KS, RT>), dim3(nb), dim3(256), ldsw, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo); } while (0)
-            if (ks <= 4) { if (rtw == 2) JCH_GW(4, 2); else JCH_GW(4, 4); }
-            else if (ks <= 8) { if (rtw == 2) JCH_GW(8, 2); else JCH_GW(8, 4); }
-            else JCH_GW(16, 2);
+                if (!once_.done(ctx->device)) { JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm_wideout<KS, RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                    JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_affine_gemm_wideout<KS, RT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once_.mark(ctx->device); } \
+                if (paired) hipLaunchKernelGGL((k_affine_gemm_wideout<KS, RT, true>), dim3(nb), dim3(256), ldsw, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo, nt_); \
+                else hipLaunchKernelGGL((k_affine_gemm_wideout<KS, RT, false>), dim3(nb), dim3(256), ldsw, ctx->stream, Xc, m, p, ldx, Bs, kpad, bias, k, out, ldo, 0); } while (0)
+            if (ks <= 4) { if (rtw == 1) JCH_GW(4, 1); else if (rtw == 2) JCH_GW(4, 2); else JCH_GW(4, 4); }
+            else if (ks <= 8) { if (rtw == 1) JCH_GW(8, 1); else if (rtw == 2) JCH_GW(8, 2); else JCH_GW(8, 4); }
+            else { if (rtw == 1) JCH_GW(16, 1); else JCH_GW(16, 2); }
 #undef JCH_GW
             JCH_HIP(ctx, hipGetLastError());
             return JCH_OK;

@@ -522,6 +522,34 @@ def test_long_input_accessors(shape, J, ctx, monkeypatch):
     assert O.rel_fro(J.transform(fm, Xn, ctx=ctx), got_T) < 1e-13
 
 
+@pytest.mark.parametrize("shape", [(70000, 60, 3, 12), (4098, 37, 10, 25), (66002, 200, 2, 20)])
+def test_long_input_predict_over_an_nlv_range(shape, J, ctx, monkeypatch):
+    """`predict(fm, X; nlv = 0:a)` on long inputs: the second stage (scores -> q (a + 1) prediction columns) runs the wide-output
+    kernel, whose tile is computed transposed and stored in 16-byte pairs (round 4) — against numpy, and against the untransposed
+    tile (JCH_GEMM_WIDEOUT_PAIRED=0) and the general kernel (JCH_GEMM_WIDEOUT=0) bit for bit."""
+    m, p, q, nlv = shape
+    rng = np.random.default_rng(m + nlv)
+    Lt = rng.standard_normal((2000, 2 * nlv))
+    X = np.asfortranarray(Lt @ rng.standard_normal((2 * nlv, p)) + 0.3 * rng.standard_normal((2000, p)) + 1.0)
+    Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.2 * rng.standard_normal((2000, q)))
+    fm = J.plskern(X, Y, nlv=nlv, scal=True, ctx=ctx)
+    Xn = np.asfortranarray(rng.standard_normal((m, p)) + 1.0)
+    got = J.predict(fm, Xn, nlv=range(0, nlv + 1), ctx=ctx)
+    got = got if isinstance(got, (list, tuple)) else got.pred
+    assert len(got) == nlv + 1
+    for a in range(nlv + 1):
+        B = (fm.R[:, :a] @ fm.C[:, :a].T) / fm.xscales[:, None] * fm.yscales[None, :]
+        ref = fm.ymeans + (Xn - fm.xmeans) @ B
+        assert O.rel_fro(ref, np.asarray(got[a])) < 1e-11, a
+    for knob in ("JCH_GEMM_WIDEOUT_PAIRED", "JCH_GEMM_WIDEOUT"):
+        monkeypatch.setenv(knob, "0")
+        other = J.predict(fm, Xn, nlv=range(0, nlv + 1), ctx=ctx)
+        other = other if isinstance(other, (list, tuple)) else other.pred
+        for a in range(nlv + 1):
+            assert O.rel_fro(np.asarray(other[a]), np.asarray(got[a])) < 1e-13, (knob, a)
+        monkeypatch.delenv(knob)
+
+
 def test_plsnipals_many_lvs_inverse_outside_lds(J, ctx):
     """`R = W inv(P'W)` (src/plsnipals.jl:95) with nlv = 100 > 90: the Gauss-Jordan runs on global scratch instead of LDS copies."""
     n, p, q, nlv = 600, 130, 2, 100
