@@ -204,6 +204,17 @@ function ctx_nranks(ctx::JchCtx)
     Int(nr[])
 end
 
+# Diagnostic counters of a ctx (include/jchemo_hip.h): 0 raw-mode fits repeated on the centred copy, 1 kNN-LWPLSR queries refitted per
+# query after the neighbour-space kernel's pivot check, 2 queries whose neighbours the screened search found, 3 those of them the
+# exact scan redid (the results do not depend on it; ENV["JCH_KNN_SCREEN"] = "0" selects the exact scan for every query)
+const COUNTER_PIVOT_REFITS = Int32(0); const COUNTER_LOCW_REFITS = Int32(1)
+const COUNTER_KNN_SCREENED = Int32(2); const COUNTER_KNN_SCREEN_REDONE = Int32(3)
+function counter(ctx::JchCtx, which::Integer)
+    v = Ref{Int64}(0)
+    check(ctx, ccall((:jch_ctx_get_counter, LIB), Int32, (Ptr{Cvoid}, Int32, Ref{Int64}), ctx.h, Int32(which), v))
+    Int(v[])
+end
+
 # weights where X lives (`nothing` = ones(n), as the reference's default argument)
 _w(weights, X) = weights === nothing ? nothing : _colocate(vec(weights), X)
 # non-`!` variants: any real matrix / vector / DataFrame-free input; the library never writes the inputs (inplace = 0),
