@@ -263,7 +263,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     t_column_copier tcopy(ctx, (host && d.dtype == JCH_F64 && !(algo == ALGO_WOLD && (d.reserved & JCH_WOLD_REF_ZERO_WEIGHT_NAN))) ? io.T : nullptr, Tdev, n, nlv_cap);
     const size_t small_bytes = 256 * 21 + sizeof(double) * 16 * 2048 + sizeof(double) * (64 + (size_t)p + (size_t)p * qpad + 2 * (size_t)ldr + 3 * (size_t)nlv_cap * p +
                                                          (size_t)nlv_cap * q + 36 * nlv_cap + 1024 + (JCH_ZT_SLICES + 1) * ((size_t)ldr + 8 + qpad) + 2 * (size_t)(p + q) + 8 + 2 * (size_t)ldr + 128 +
-                                                         (p <= JCH_SWEEP_MAXP ? (size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv_cap) + 128 : 0));
+                                                         (p <= JCH_SWEEP_MAXP ? jch_lv_split_doubles(p, nlv_cap) + 128 : 0));
     JCH_TRY(jch_reserve(ctx, ctx->small, small_bytes));
     carve cv{(char *)ctx->small.ptr, 0};
     jch_small s;
@@ -284,7 +284,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     s.hdr = cv.take(8);
     s.variant = 0;
     s.niter = algo == ALGO_WOLD ? niter_dev : nullptr;
-    s.kr = nullptr; s.gpart = nullptr;
+    s.kr = nullptr; s.gpart = nullptr; s.lvctr = nullptr;
     // host copies of the small outputs: one pinned staging buffer, then plain memcpy into the caller's arrays
     auto fetch_small = [&](int k) -> int32_t {
         JCH_TRY(jch_reserve_host(ctx, out_bytes));
@@ -327,7 +327,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             const char *e_sp = getenv("JCH_LV_SPLIT");
             const bool fuse_b = ctx->p2p.ready && !ctx->loop && !getenv("JCH_P2P_UNFUSED");
             if (fastb && (!fuse_b || jch_lv_split_p2p_ok(ctx, p)) && !(e_sp && atoi(e_sp) == 0) && jch_lv_solve_lds_bytes(p, q, ldr, nlv_cap) <= 150 * 1024) {
-                s.kr = cv.take(16); s.gpart = cv.take((size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv_cap));
+                s.kr = cv.take(16); JCH_TRY(jch_lv_split_begin_fit(ctx, s, cv.take(jch_lv_split_doubles(p, nlv_cap)), p, nlv_cap));
             }
         }
         hipEvent_t evb = jch_ev(ctx);
@@ -448,7 +448,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         const char *e_sp = getenv("JCH_LV_SPLIT");
         split = (algo == ALGO_KERN || algo == ALGO_ROSA) && fast && !(e_sp && atoi(e_sp) == 0) &&
                 jch_lv_solve_lds_bytes(p, q, ldr, nlv) <= 150 * 1024 && (!fuse_inbox || jch_lv_split_p2p_ok(ctx, p));
-        if (split) { s.kr = cv.take(16); s.gpart = cv.take((size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv)); }
+        if (split) { s.kr = cv.take(16); JCH_TRY(jch_lv_split_begin_fit(ctx, s, cv.take(jch_lv_split_doubles(p, nlv)), p, nlv)); }
         JCH_TRY(jch_launch_lv_update(ctx, s, p, q, qpad, ldr, -1, nlv, kern_like ? 0 : 1, 1, ldz, fast));
     }
     int npend = 0, pend_a0 = 0;   // postponed deflations: LVs pend_a0 .. pend_a0 + npend - 1

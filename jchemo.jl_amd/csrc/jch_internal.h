@@ -207,6 +207,7 @@ struct jch_small {  // device-resident replicated small state of one fit
     double *niter;      // [nlv] plswold: inner iterations per LV (src/plswold.jl:93); null otherwise
     double *kr;         // [16] split small-state path (smallstate_split.hip): K' r of the current LV; null otherwise
     double *gpart;      // [blocks][gld] split path: per-block partials of K_new'K_new, zp'K_new and P_i . zp; null otherwise
+    unsigned *lvctr;    // split path, merged kernel: arrival counter of the fit's blocks (zeroed when a fit starts); null otherwise
 };
 
 int32_t jch_launch_lv_update(jch_ctx *ctx, const jch_small &s, int p, int q, int qpad, int ldr, int a /*-1: init*/,
@@ -219,6 +220,8 @@ int32_t jch_launch_lv_update_fast(jch_ctx *ctx, const jch_small &s, int p, int q
 // smallstate_split.hip: the per-LV step of the plskern-shaped loop as a p-parallel kernel + a single-workgroup kernel
 int jch_lv_split_blocks(int p);
 int jch_lv_split_gld(int nlv);
+size_t jch_lv_split_doubles(int p, int nlv);
+int32_t jch_lv_split_begin_fit(jch_ctx *ctx, jch_small &s, double *gbuf, int p, int nlv);
 size_t jch_lv_solve_lds_bytes(int p, int q, int ldr, int nlv);
 int32_t jch_launch_lv_split(jch_ctx *ctx, const jch_small &s, int p, int q, int ldr, int a, int nlv, const double *part, int nb,
                             int ldpart, int itt, int ist /*< 0: none*/, int mode /*0 centred copy, 1 f64 raw mode, 2 bf16*/, bool solve,

@@ -37,6 +37,8 @@ struct lvs_args {
                            // 2: bf16 storage mode (zp = (zp_raw - mom st) / scl)
     int nblk, gld;         // blocks of k_lv_spread, doubles per block in s.gpart
     p2p_dev px;            // P2P instantiation: the inbox transport (p2p.hip), one exchange per block
+    unsigned *ctr;         // merged kernel: arrival counter of the fit (zeroed at its start); the block that brings it to `ctr_target` solves
+    unsigned ctr_target;
 };
 
 #define JCH_SSTAMP(k) do { if (g.s.dbg && tid == 0) g.s.dbg[512 + 16 * (g.a + 1) + (k)] = (double)__builtin_readcyclecounter(); } while (0)
@@ -44,14 +46,17 @@ struct lvs_args {
 // P2P: the cross-GPU all-reduce of the sweep output happens HERE, block by block: every block pushes its 16 column sums + [tt, st]
 // into its own 24-double piece of slot [parity][rank] of every rank's inbox, publishes / waits on its OWN flags and adds the ranks'
 // pieces in rank order (the same bits on every rank) — the exchange of smallstate_fast.hip's fused kernel, 32 blocks wide.
-template <bool P2P>
-__global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
+// WIDE: called from the merged kernel's 512-thread blocks — threads 256 .. 511 only take part in the barriers.  Returns false when the
+// exchange has bailed out (uniform over the block).
+template <bool P2P, bool WIDE>
+__device__ __forceinline__ bool spread_body(const lvs_args &g, const int tid)
 {
     __shared__ double sc[16][18];
     __shared__ double tot[18];
     __shared__ double zpl[16], cl[16];
     __shared__ double Knl[16][17];
-    const int tid = threadIdx.x, col = tid & 15, gr = tid >> 4;
+    const bool act = !WIDE || tid < SP_NT;
+    const int col = tid & 15, gr = (tid >> 4) & 15;
     const int p = g.p, a = g.a, j0 = blockIdx.x * 16;
     if (g.s.dbg && tid == 0 && blockIdx.x == 0) g.s.dbg[512 + 16 * (a + 1) + 5] = (double)__builtin_readcyclecounter();
     // ---- every load this block needs is issued here (one trip to L2)
@@ -66,14 +71,14 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
         else if (g.mode == 2) { msh = g.s.mom[jcc]; scl = g.s.scl[jcc]; }
     }
     double pre[16];     // P_i[j0 .. j0 + 15] of the finished LV i = tid - 16 (threads 16 .. 16 + a)
-    const int ipre = tid - 16;
+    const int ipre = act ? tid - 16 : -1;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) pre[jj] = (ipre >= 0 && ipre < a) ? g.s.P[(size_t)ipre * p + min(j0 + jj, p - 1)] : 0.0;
     // sums of the partial rows: thread (gr, col) adds rows gr, gr + 16, ... of column j0 + col; fixed order
     const int cidx = min(jc, g.ldr - 1);
     double acc = 0.0, acc2 = 0.0;
     const int xidx = col == 0 ? g.itt : (g.ist >= 0 ? g.ist : g.itt);
-    for (int b0 = gr; b0 < g.nb; b0 += 16 * 8) {
+    for (int b0 = act ? gr : g.nb; b0 < g.nb; b0 += 16 * 8) {
         double v[8], x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -88,8 +93,10 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
             acc2 += live ? x[u] : 0.0;
         }
     }
-    sc[gr][col] = acc;
-    if (col < 2) sc[gr][16 + col] = acc2;
+    if (act) {
+        sc[gr][col] = acc;
+        if (col < 2) sc[gr][16 + col] = acc2;
+    }
     __syncthreads();
     if (tid < 18) {
         double t = 0.0;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
         char *mine = g.px.peer[g.px.rank];
         if (tid == 0) bail = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
         __syncthreads();
-        if (bail) return;
+        if (bail) return false;
         const long long ts0 = blk == 0 ? p2p_stat_begin(g.px, tid) : 0;
         if (tid < 18) {
             const double v = tot[tid];
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
         __syncthreads();
         if (tid == 0) bail = __hip_atomic_load(p2p_status(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
         __syncthreads();
-        if (bail) return;
+        if (bail) return false;
         if (tid < 18) {
             double s = 0.0;
             for (int r = 0; r < g.px.nranks; ++r) s += p2p_load_slot(p2p_slot(mine, par, r, g.px.nranks, g.px.cap) + blk * 24 + tid);
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
         }
     }
     __syncthreads();
-    {   // K <- K - zp c' : row j0 + gr, column col (pad columns stay exactly zero: c is zero there)
+    if (act) {   // K <- K - zp c' : row j0 + gr, column col (pad columns stay exactly zero: c is zero there)
         const bool live = j0 + gr < p;
         const double kn = kold - zpl[gr] * cl[col];
         if (live) g.s.K[(size_t)(j0 + gr) * 16 + col] = kn;
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
     }
     __syncthreads();
     double *gp = g.s.gpart + (size_t)blockIdx.x * g.gld;
-    {   // partial Gram matrix of this block's 16 rows of K_new
+    if (act) {   // partial Gram matrix of this block's 16 rows of K_new
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int jj = 0; jj < 16; jj += 2) {
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) s += zpl[jj] * Knl[jj][tid];
         gp[256 + tid] = s;
-    } else if (ipre < a) {   // partial of P_i . zp
+    } else if (act && ipre < a) {   // partial of P_i . zp
         double s = 0.0;
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) s += pre[jj] * zpl[jj];       // (zpl is zero beyond p)
@@ -180,13 +187,19 @@ __global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
         gp[SP_GP + i] = s;
     }
     if (g.s.dbg && tid == 0 && blockIdx.x == 0) g.s.dbg[512 + 16 * (a + 1) + 7] = (double)__builtin_readcyclecounter();
+    return true;
+}
+
+template <bool P2P>
+__global__ __launch_bounds__(SP_NT) void k_lv_spread(lvs_args g)
+{
+    spread_body<P2P, false>(g, threadIdx.x);
 }
 
 template <int QP>
-__global__ __launch_bounds__(FT) void k_lv_solve(lvs_args g)
+__device__ __forceinline__ void solve_body(const lvs_args &g, double *lds, const int tid)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int p = g.p, q = g.q, ldr = g.ldr, a = g.a, tid = threadIdx.x;
+    const int p = g.p, q = g.q, ldr = g.ldr, a = g.a;
     const int lane = tid & 63, wv = tid >> 6;
     const int an = a + 1;                          // finished LVs (rows of P / R / Z valid in global memory, row a from k_lv_spread)
     constexpr int ldk = QP | 1, lda = QP + 2;
@@ -362,10 +375,53 @@ __global__ __launch_bounds__(FT) void k_lv_solve(lvs_args g)
     JCH_SSTAMP(4);
 }
 
+template <int QP>
+__global__ __launch_bounds__(FT) void k_lv_solve(lvs_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    solve_body<QP>(g, lds, threadIdx.x);
+}
+
+// MERGED (round 4, second half; OPT-IN, JCH_LV_MERGED=1 — measured SLOWER than the two launches): one launch per LV.  Every block
+// runs the p-parallel half; the block that arrives LAST at the fit's counter — no block ever waits for another — goes on as the
+// single-workgroup half.  Release / acquire: every thread fences its stores at device scope, the block's thread 0 bumps the counter
+// (acq_rel), and the last block fences again before it reads what the other blocks (other XCDs, other L2s) wrote.
+// Results are bit-identical to the two launches (tests/test_gpu_parity.py::test_merged_small_state_kernel_...).  Measured (cfg2,
+// JCH_LV_DEBUG stamps): small state + gaps 0.51 -> 0.64 ms per fit.  The boundary it removes is worth 3.7 k cycles (end of block 0's
+// spread half to the solve kernel's first instruction); against that the spread half takes 11.1 k cycles instead of 7.6 k in
+// 512-thread blocks that reserve the solve half's LDS, and the solve half's first phase (partials in + barrier) 13.2 k instead of
+// 9.2 k behind the device-scope acquire — a kernel boundary is the CHEAPER release / acquire on this part.
+template <int QP, bool P2P>
+__global__ __launch_bounds__(FT) void k_lv_merged(lvs_args g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int last;
+    const int tid = threadIdx.x;
+    if (!spread_body<P2P, true>(g, tid)) return;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = __hip_atomic_fetch_add(g.ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == g.ctr_target;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    solve_body<QP>(g, lds, tid);
+}
+
 static int qp_of(int q) { return q <= 1 ? 1 : (q <= 2 ? 2 : (q <= 4 ? 4 : (q <= 8 ? 8 : 16))); }
 
 int jch_lv_split_blocks(int p) { return (p + 15) / 16; }
 int jch_lv_split_gld(int nlv) { return (SP_GP + nlv + 7) & ~7; }
+// doubles of jch_small::gpart: the block partials + 8 for the merged kernel's arrival counter (jch_small::lvctr)
+size_t jch_lv_split_doubles(int p, int nlv) { return (size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv) + 8; }
+// carve the split path's buffers out of `gbuf` (jch_lv_split_doubles(p, nlv) doubles); the arrival counter starts every fit at zero
+// (enqueued on the fit's stream before its first LV)
+int32_t jch_lv_split_begin_fit(jch_ctx *ctx, jch_small &s, double *gbuf, int p, int nlv)
+{
+    s.gpart = gbuf;
+    s.lvctr = reinterpret_cast<unsigned *>(gbuf + jch_lv_split_doubles(p, nlv) - 8);
+    JCH_HIP(ctx, hipMemsetAsync(s.lvctr, 0, 64, ctx->stream));
+    return JCH_OK;
+}
 
 size_t jch_lv_solve_lds_bytes(int p, int q, int ldr, int nlv)
 {
@@ -388,20 +444,44 @@ int32_t jch_launch_lv_split(jch_ctx *ctx, const jch_small &s, int p, int q, int 
     g.s = s; g.p = p; g.q = q; g.ldr = ldr; g.a = a; g.nlv = nlv; g.part = part; g.nb = nb; g.ldpart = ldpart; g.itt = itt; g.ist = ist;
     g.mode = mode; g.nblk = jch_lv_split_blocks(p); g.gld = jch_lv_split_gld(nlv);
     g.px = p2p_dev{};
+    g.ctr = s.lvctr;
+    g.ctr_target = (unsigned)(a + 1) * (unsigned)g.nblk;     // LV a is the fit's (a + 1)-th launch of the merged kernel
+    // default: two launches per LV (k_lv_spread, k_lv_solve); JCH_LV_MERGED=1: one (k_lv_merged) wherever an LV has a solve half
+    const char *e_mg = getenv("JCH_LV_MERGED");
+    const bool merged = solve && s.lvctr && e_mg && atoi(e_mg) == 1;
     if (fuse_p2p) {
         if (!jch_lv_split_p2p_ok(ctx, p)) return jch_fail(ctx, JCH_EINVAL, "internal: per-block inbox exchange outside its envelope");
         jch_p2p_next(ctx, &g.px);
-        hipLaunchKernelGGL(k_lv_spread<true>, dim3(g.nblk), dim3(SP_NT), 0, ctx->stream, g);
-    } else hipLaunchKernelGGL(k_lv_spread<false>, dim3(g.nblk), dim3(SP_NT), 0, ctx->stream, g);
+    }
     if (solve) {
-        const size_t lds = jch_lv_solve_lds_bytes(p, q, ldr, nlv);
         static jch_per_device_once attr_once;
         if (!attr_once.done(ctx->device)) {
-#define JCH_ATTR(QP) JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_solve<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define JCH_ATTR(QP) JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_solve<QP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                     JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_merged<QP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+                     JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_lv_merged<QP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
             JCH_ATTR(1); JCH_ATTR(2); JCH_ATTR(4); JCH_ATTR(8); JCH_ATTR(16);
 #undef JCH_ATTR
             attr_once.mark(ctx->device);
         }
+    }
+    const size_t lds = jch_lv_solve_lds_bytes(p, q, ldr, nlv);
+    if (merged) {
+#define JCH_MERGED(QP) do { if (fuse_p2p) hipLaunchKernelGGL((k_lv_merged<QP, true>), dim3(g.nblk), dim3(FT), lds, ctx->stream, g); \
+                            else hipLaunchKernelGGL((k_lv_merged<QP, false>), dim3(g.nblk), dim3(FT), lds, ctx->stream, g); } while (0)
+        switch (qp_of(q)) {
+        case 1: JCH_MERGED(1); break;
+        case 2: JCH_MERGED(2); break;
+        case 4: JCH_MERGED(4); break;
+        case 8: JCH_MERGED(8); break;
+        default: JCH_MERGED(16); break;
+        }
+#undef JCH_MERGED
+        JCH_HIP(ctx, hipGetLastError());
+        return JCH_OK;
+    }
+    if (fuse_p2p) hipLaunchKernelGGL(k_lv_spread<true>, dim3(g.nblk), dim3(SP_NT), 0, ctx->stream, g);
+    else hipLaunchKernelGGL(k_lv_spread<false>, dim3(g.nblk), dim3(SP_NT), 0, ctx->stream, g);
+    if (solve) {
         switch (qp_of(q)) {
         case 1: hipLaunchKernelGGL((k_lv_solve<1>), dim3(1), dim3(FT), lds, ctx->stream, g); break;
         case 2: hipLaunchKernelGGL((k_lv_solve<2>), dim3(1), dim3(FT), lds, ctx->stream, g); break;

@@ -1415,6 +1415,44 @@ def test_split_small_state_matches_one_kernel_path(shape, variant, J, ctx, monke
     assert np.abs(fm.R.T @ fm.P - np.eye(k)).max() < 1e-8
 
 
+@pytest.mark.parametrize("shape", [dict(n=3000, p=500, q=10, nlv=25), dict(n=900, p=37, q=1, nlv=12), dict(n=1200, p=130, q=2, nlv=9),
+                                   dict(n=2000, p=257, q=3, nlv=20), dict(n=2500, p=64, q=7, nlv=30), dict(n=1500, p=1000, q=16, nlv=15),
+                                   dict(n=700, p=16, q=5, nlv=16), dict(n=400, p=301, q=12, nlv=40), dict(n=5000, p=2048, q=4, nlv=6)])
+@pytest.mark.parametrize("variant", ["raw", "scal_w", "centred", "rosa", "bf16"])
+def test_merged_small_state_kernel_is_the_two_launch_path_bit_for_bit(shape, variant, J, ctx, monkeypatch):
+    """Round 4, second half, OPT-IN (JCH_LV_MERGED=1; measured slower, kept as a knob): ONE launch per LV (k_lv_merged: every block
+    runs the p-parallel half, the block that arrives last at the fit's counter goes on as the single-workgroup half —
+    smallstate_split.hip) against the default two launches.  The same code on the same data in the same order, so every output is IDENTICAL, bit for bit; and a repeated
+    fit reproduces itself (which block arrives last differs from launch to launch — it must not matter).  Every QP instantiation,
+    raw mode / scaling + weights / centred copy, plsrosa, the bf16 storage mode, nlv beyond 32, one block (p = 16) and the most
+    blocks the LDS-resident path takes (p = 2048)."""
+    n, p, q, nlv = (shape[k] for k in ("n", "p", "q", "nlv"))
+    X = CO.fill_uniform(411, n, p) + 3.0
+    B0 = CO.fill_uniform(412, p, q) - 0.5
+    Y = X @ B0 + 0.1 * CO.fill_uniform(413, n, q)
+    w = CO.fill_uniform(414, n, 1)[:, 0] + 0.2 if variant == "scal_w" else None
+    scal = variant == "scal_w"
+    fn = J.plsrosa if variant == "rosa" else J.plskern
+    kw = dict(nlv=nlv, scal=scal, ctx=ctx)
+    if variant == "bf16":   # device-resident bf16 inputs: the storage mode (results come back as device tensors)
+        import torch
+        Xb = J.colmajor_empty(n, p, dtype=torch.bfloat16); Xb.copy_(torch.from_numpy(X))
+        Yb = J.colmajor_empty(n, q, dtype=torch.bfloat16); Yb.copy_(torch.from_numpy(Y))
+        X, Y = Xb, Yb
+    if variant == "centred":
+        monkeypatch.setenv("JCH_CENTRED_COPY", "1")
+    monkeypatch.setenv("JCH_LV_MERGED", "1")
+    a = fn(X, Y, w, **kw)
+    b = fn(X, Y, w, **kw)
+    monkeypatch.delenv("JCH_LV_MERGED")
+    c = fn(X, Y, w, **kw)
+    host = lambda v: v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+    for f in FIELDS + ("TT",):
+        assert np.array_equal(host(getattr(a, f)), host(getattr(b, f))), (f, "merged kernel does not reproduce itself")
+        assert np.array_equal(host(getattr(a, f)), host(getattr(c, f))), (f, "merged vs two launches")
+    assert np.all(np.isfinite(host(a.T)))
+
+
 @pytest.mark.parametrize("shape", [dict(n=4000, p=500, q=10, nlv=14), dict(n=1500, p=60, q=1, nlv=8), dict(n=2500, p=300, q=4, nlv=13),
                                    dict(n=1200, p=1500, q=3, nlv=9), dict(n=900, p=2000, q=1, nlv=20), dict(n=3000, p=130, q=16, nlv=7)])
 @pytest.mark.parametrize("alg", ["nipals", "wold"])
