@@ -606,6 +606,89 @@ extern "C" int32_t jch_transform(jch_ctx *ctx, int32_t loc, const double *X, int
 // (src/plskern.jl:207-217: B = diag(1/xscales) R_k C_k' diag(yscales), int = ymeans' - xmeans' B) and
 // pred = int .+ X B (src/plskern.jl:226-238).  The coefficient blocks of the whole range are concatenated
 // [B_lo | ... | B_hi] so X is read ONCE; block b of `pred` (columns b*q .. b*q+q-1) is the prediction at nlv_lo + b.
+// `predict` over an nlv RANGE from the scores (round 4, second half): pred_a = ymeans + sum_{l <= a} t_l (c_l .* yscales)'
+// (src/plskern.jl:207-217, :234-236 with B_a = R_a C_a': X_c B_a = T_a C_a') — the le prediction blocks are RUNNING SUMS over the
+// score columns, so a thread keeps its rows' q sums in registers, adds one score column at a time and stores a block whenever the
+// level is asked for: m nlv q fused multiply-adds instead of a GEMM with le q output columns, no matrix pipe, and every store
+// instruction of a wave writes one contiguous V x 512-byte run of an output column.  The pass is its output (2.08 GB at cfg2
+// against 0.2 GB of scores).
+template <int QC, int V, bool NT>   // QC responses per thread (grid.y slices of QC), V rows per thread (2: 16-byte loads / stores)
+__global__ __launch_bounds__(256) void k_predict_prefix(const double *__restrict__ T, int64_t m, int64_t ldt, const double *__restrict__ Cs,
+                                                        const double *__restrict__ y0, int q, int lo, int hi, double *__restrict__ out, int64_t ldo)
+{
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (row >= m) return;
+    const int k0 = blockIdx.y * QC;
+    double acc[QC][V];
+#pragma unroll
+    for (int k = 0; k < QC; ++k) {
+        const double v = y0[min(k0 + k, q - 1)];
+#pragma unroll
+        for (int r = 0; r < V; ++r) acc[k][r] = v;
+    }
+    auto put = [&](int a) {
+#pragma unroll
+        for (int k = 0; k < QC; ++k) {
+            if (k0 + k >= q) continue;
+            double *dst = out + row + ((int64_t)(a - lo) * q + k0 + k) * ldo;
+            if constexpr (V == 2) {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                d2 v; v.x = acc[k][0]; v.y = acc[k][1];
+                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(dst));
+                else *reinterpret_cast<d2 *>(dst) = v;
+            } else {
+                if constexpr (NT) __builtin_nontemporal_store(acc[k][0], dst);
+                else *dst = acc[k][0];
+            }
+        }
+    };
+    if (lo == 0) put(0);
+    for (int a0 = 0; a0 < hi; a0 += 8) {
+        double t[8][V];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double *src = T + row + (int64_t)min(a0 + u, hi - 1) * ldt;
+            if constexpr (V == 2) {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src));
+                t[u][0] = v.x; t[u][1] = v.y;
+            } else t[u][0] = __builtin_nontemporal_load(src);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int a = a0 + u + 1;          // level reached after adding score column a - 1
+            if (a > hi) break;
+#pragma unroll
+            for (int k = 0; k < QC; ++k) {
+                const double c = Cs[(size_t)(a - 1) * q + min(k0 + k, q - 1)];
+#pragma unroll
+                for (int r = 0; r < V; ++r) acc[k][r] += t[u][r] * c;
+            }
+            if (a >= lo) put(a);
+        }
+    }
+}
+
+static int32_t jch_launch_predict_prefix(jch_ctx *ctx, const double *T, int64_t m, int64_t ldt, const double *Cs, const double *y0, int q,
+                                         int lo, int hi, double *out, int64_t ldo)
+{
+    const bool v2 = m % 2 == 0 && ldt % 2 == 0 && ldo % 2 == 0 && (((uintptr_t)T) & 15) == 0 && (((uintptr_t)out) & 15) == 0;
+    const char *ent = getenv("JCH_PREDICT_NT");                 // (=0: plain stores — A/B runs)
+    const bool nt = !(ent && atoi(ent) == 0);
+    const int qc = q <= 4 ? 4 : (q <= 8 ? 8 : 16);
+    const int64_t thr = v2 ? m / 2 : m;
+    dim3 grid((unsigned)((thr + 255) / 256), (unsigned)((q + qc - 1) / qc));
+#define JCH_PP(QC) do { \
+        if (v2 && nt) hipLaunchKernelGGL((k_predict_prefix<QC, 2, true>), grid, dim3(256), 0, ctx->stream, T, m, ldt, Cs, y0, q, lo, hi, out, ldo); \
+        else if (v2) hipLaunchKernelGGL((k_predict_prefix<QC, 2, false>), grid, dim3(256), 0, ctx->stream, T, m, ldt, Cs, y0, q, lo, hi, out, ldo); \
+        else if (nt) hipLaunchKernelGGL((k_predict_prefix<QC, 1, true>), grid, dim3(256), 0, ctx->stream, T, m, ldt, Cs, y0, q, lo, hi, out, ldo); \
+        else hipLaunchKernelGGL((k_predict_prefix<QC, 1, false>), grid, dim3(256), 0, ctx->stream, T, m, ldt, Cs, y0, q, lo, hi, out, ldo); } while (0)
+    if (qc == 4) JCH_PP(4); else if (qc == 8) JCH_PP(8); else JCH_PP(16);
+#undef JCH_PP
+    JCH_HIP(ctx, hipGetLastError());
+    return JCH_OK;
+}
+
 extern "C" int32_t jch_predict(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx, const double *xmeans,
                                const double *xscales, const double *ymeans, const double *yscales, const double *R,
                                const double *C, int64_t q, int32_t nlv_lo, int32_t nlv_hi, double *pred, int64_t ldo)
@@ -613,6 +696,56 @@ extern "C" int32_t jch_predict(jch_ctx *ctx, int32_t loc, const double *X, int64
     if (!ctx) return JCH_EINVAL;
     if (!R || !C || q < 1 || nlv_lo < 0 || nlv_hi < nlv_lo) return jch_fail(ctx, JCH_EINVAL, "jch_predict: bad model arguments");
     const int64_t le = (int64_t)nlv_hi - nlv_lo + 1, kcols = le * q;
+    // Three levels or more on a long input: the scores once (one pass over X: m x nlv_hi), then the prediction blocks as running
+    // sums over the score columns (k_predict_prefix).  JCH_PREDICT_PREFIX=0: the one-GEMM path below for every range.
+    const char *epp = getenv("JCH_PREDICT_PREFIX");
+    if (le > 2 && m >= 4096 && !(epp && atoi(epp) == 0)) {
+        if (!X || !pred || p < 1 || ldx < m || ldo < m) return jch_fail(ctx, JCH_EINVAL, "jch_predict: bad arguments");
+        if (loc != JCH_LOC_HOST && loc != JCH_LOC_DEVICE) return jch_fail(ctx, JCH_EINVAL, "jch_predict: bad loc");
+        JCH_HIP(ctx, hipSetDevice(ctx->device));
+        const int kh = nlv_hi, kpad = (kh + 15) / 16 * 16;
+        // host-side constants: Rs = diag(1 / xscales) R (p x kpad, row-major as the GEMM kernels take it), its bias -xmeans' Rs,
+        // Cs[l][k] = C[k][l] yscales[k], ymeans
+        std::vector<double> hb((size_t)p * kpad + kpad + (size_t)kh * q + q, 0.0);
+        double *Bs = hb.data(), *b2 = Bs + (size_t)p * kpad, *Cs = b2 + kpad, *y0 = Cs + (size_t)kh * q;
+        for (int c = 0; c < kh; ++c) {
+            double acc = 0.0;
+            for (int64_t j = 0; j < p; ++j) {
+                const double v = R[j + (size_t)c * p] / (xscales ? xscales[j] : 1.0);
+                Bs[j * kpad + c] = v;
+                if (xmeans) acc -= xmeans[j] * v;
+            }
+            b2[c] = acc;
+            for (int64_t k = 0; k < q; ++k) Cs[(size_t)c * q + k] = C[k + (size_t)c * q] * (yscales ? yscales[k] : 1.0);
+        }
+        for (int64_t k = 0; k < q; ++k) y0[k] = ymeans ? ymeans[k] : 0.0;
+        JCH_TRY(jch_reserve(ctx, ctx->gemm_b, sizeof(double) * hb.size()));
+        double *dB = (double *)ctx->gemm_b.ptr;
+        JCH_HIP(ctx, hipMemcpyAsync(dB, hb.data(), sizeof(double) * hb.size(), hipMemcpyHostToDevice, ctx->stream));
+        const int64_t ldt = (m + 1) & ~(int64_t)1;
+        JCH_TRY(jch_reserve(ctx, ctx->tbuf, sizeof(double) * (size_t)ldt * kh));
+        double *Tq = (double *)ctx->tbuf.ptr;
+        const double *dX = X;
+        double *dO = pred;
+        int64_t ldxd = ldx, ldod = ldo;
+        if (loc == JCH_LOC_HOST) {
+            ldod = ldt;
+            JCH_TRY(jch_reserve(ctx, ctx->xq, sizeof(double) * (size_t)m * p));
+            JCH_TRY(jch_reserve(ctx, ctx->gemm_out, sizeof(double) * (size_t)ldod * kcols));
+            if (ldx == m) JCH_HIP(ctx, hipMemcpyAsync(ctx->xq.ptr, X, sizeof(double) * (size_t)m * p, hipMemcpyHostToDevice, ctx->stream));
+            else JCH_HIP(ctx, hipMemcpy2DAsync(ctx->xq.ptr, sizeof(double) * m, X, sizeof(double) * ldx, sizeof(double) * m, p,
+                                               hipMemcpyHostToDevice, ctx->stream));
+            dX = (const double *)ctx->xq.ptr; dO = (double *)ctx->gemm_out.ptr; ldxd = m;
+        }
+        JCH_TRY(jch_launch_affine_gemm(ctx, dX, m, (int)p, ldxd, dB, kh, kpad, dB + (size_t)p * kpad, Tq, ldt));
+        JCH_TRY(jch_launch_predict_prefix(ctx, Tq, m, ldt, dB + (size_t)p * kpad + kpad, dB + (size_t)p * kpad + kpad + (size_t)kh * q, (int)q,
+                                          nlv_lo, nlv_hi, dO, ldod));
+        if (loc == JCH_LOC_HOST)
+            JCH_HIP(ctx, hipMemcpy2DAsync(pred, sizeof(double) * ldo, dO, sizeof(double) * ldod, sizeof(double) * m, kcols,
+                                          hipMemcpyDeviceToHost, ctx->stream));
+        JCH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `hb` alive until the H2D copy is done
+        return JCH_OK;
+    }
     std::vector<double> B((size_t)p * kcols, 0.0), b0((size_t)kcols, 0.0), cur((size_t)p * q, 0.0);
     for (int a = 0; a <= nlv_hi; ++a) {
         if (a > 0) {   // B_a = B_{a-1} + (r_a / xscales) (c_a * yscales)'

@@ -382,15 +382,8 @@ def coef(fm: Plsr, *, nlv: Optional[int] = None):
 def _pred_matrix(fm: "Plsr", X, rng, ctx):
     """m x (len(rng) * q) matrix [pred_{rng[0]} | pred_{rng[1]} | ...] (level-major columns)."""
     q = fm.C.shape[0]
-    if len(rng) > 2 and max(rng) > 0:
-        # several nlv: ONE pass over X for the scores (m x max(nlv)), then every prediction is a cumulative sum of
-        # score x loading terms, pred_a = ymeans + sum_{l < a} T_l (C_l .* yscales)' — a GEMM on the small score matrix
-        kmax = max(rng)
-        Tq = _affine(X, fm.xmeans, fm.xscales, fm.R[:, :kmax], None, ctx)
-        Bc = np.zeros((kmax, len(rng) * q))
-        for ai, a_ in enumerate(rng):
-            Bc[:a_, ai * q:(ai + 1) * q] = (fm.C[:, :a_] * fm.yscales[:, None]).T
-        return _affine(Tq, None, None, Bc, np.tile(fm.ymeans, len(rng)), ctx)
+    # several nlv: the library takes ONE pass over X for the scores (m x max(nlv)); every prediction block is then a running sum of
+    # score x loading terms, pred_a = ymeans + sum_{l <= a} T_l (C_l .* yscales)' (k_predict_prefix, csrc/gemm.hip)
     return _predict_range(fm, X, rng[0], rng[-1], ctx)   # rng is contiguous (src/plskern.jl:228)
 
 

@@ -522,11 +522,54 @@ def test_long_input_accessors(shape, J, ctx, monkeypatch):
     assert O.rel_fro(J.transform(fm, Xn, ctx=ctx), got_T) < 1e-13
 
 
-@pytest.mark.parametrize("shape", [(70000, 60, 3, 12), (4098, 37, 10, 25), (66002, 200, 2, 20)])
-def test_long_input_predict_over_an_nlv_range(shape, J, ctx, monkeypatch):
-    """`predict(fm, X; nlv = 0:a)` on long inputs: the second stage (scores -> q (a + 1) prediction columns) runs the wide-output
-    kernel, whose tile is computed transposed and stored in 16-byte pairs (round 4) — against numpy, and against the untransposed
-    tile (JCH_GEMM_WIDEOUT_PAIRED=0) and the general kernel (JCH_GEMM_WIDEOUT=0) bit for bit."""
+@pytest.mark.parametrize("shape", [(70000, 60, 3, 12), (4098, 37, 10, 25), (66002, 200, 2, 20), (5001, 45, 5, 9), (4100, 50, 19, 11)])
+@pytest.mark.parametrize("resident", [False, True])
+def test_long_input_predict_over_an_nlv_range(shape, resident, J, ctx, monkeypatch):
+    """`predict(fm, X; nlv = lo:hi)` on long inputs (src/plskern.jl:226-238): one pass over X for the scores, then the prediction
+    blocks as running sums over the score columns (k_predict_prefix, round 4) — against numpy for every level; against the one-GEMM
+    path (JCH_PREDICT_PREFIX=0: B_a accumulated on the host, le q output columns) to rounding; plain instead of streaming stores
+    (JCH_PREDICT_NT=0) bit for bit.  Even and odd m (two rows / one row per thread), q beyond one response slice (19), ranges that
+    start above 0, host and device-resident inputs."""
+    m, p, q, nlv = shape
+    rng = np.random.default_rng(m + nlv)
+    Lt = rng.standard_normal((2000, 2 * nlv))
+    X = np.asfortranarray(Lt @ rng.standard_normal((2 * nlv, p)) + 0.3 * rng.standard_normal((2000, p)) + 1.0)
+    Y = np.asfortranarray(Lt[:, :min(q, 2 * nlv)] @ rng.standard_normal((min(q, 2 * nlv), q)) + 0.2 * rng.standard_normal((2000, q)))
+    fm = J.plskern(X, Y, nlv=nlv, scal=True, ctx=ctx)
+    Xn = np.asfortranarray(rng.standard_normal((m, p)) + 1.0)
+    Xin = Xn
+    if resident:
+        import torch
+        Xin = J.colmajor_empty(m, p); Xin.copy_(torch.from_numpy(Xn))
+    host = lambda v: v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+
+    def run(lo, hi):
+        got = J.predict(fm, Xin, nlv=range(lo, hi + 1), ctx=ctx)
+        got = got if isinstance(got, (list, tuple)) else got.pred
+        assert len(got) == hi - lo + 1
+        return [host(g) for g in got]
+
+    for lo, hi in ((0, nlv), (3, nlv - 1), (nlv - 2, nlv)):
+        got = run(lo, hi)
+        for a in range(lo, hi + 1):
+            B = (fm.R[:, :a] @ fm.C[:, :a].T) / fm.xscales[:, None] * fm.yscales[None, :]
+            ref = fm.ymeans + (Xn - fm.xmeans) @ B
+            assert O.rel_fro(ref, got[a - lo]) < 1e-11, (lo, hi, a)
+        monkeypatch.setenv("JCH_PREDICT_NT", "0")
+        for x, y in zip(run(lo, hi), got):
+            assert np.array_equal(x, y), "plain vs streaming stores"
+        monkeypatch.delenv("JCH_PREDICT_NT")
+        monkeypatch.setenv("JCH_PREDICT_PREFIX", "0")
+        for a, (x, y) in enumerate(zip(run(lo, hi), got)):
+            assert O.rel_fro(x, y) < 1e-12, ("one-GEMM path", lo + a)
+        monkeypatch.delenv("JCH_PREDICT_PREFIX")
+
+
+@pytest.mark.parametrize("shape", [(70000, 60, 3, 12), (4098, 37, 10, 25)])
+def test_long_input_xfit_wide_output_kernel(shape, J, ctx, monkeypatch):
+    """`xfit` on long inputs (src/xfit.jl:37-56): its second stage (m x nlv scores -> m x p) runs the wide-output accessor kernel,
+    whose tile is computed transposed and stored in 16-byte pairs — against numpy, and against the untransposed tile
+    (JCH_GEMM_WIDEOUT_PAIRED=0) and the general kernel (JCH_GEMM_WIDEOUT=0)."""
     m, p, q, nlv = shape
     rng = np.random.default_rng(m + nlv)
     Lt = rng.standard_normal((2000, 2 * nlv))
@@ -534,19 +577,12 @@ def test_long_input_predict_over_an_nlv_range(shape, J, ctx, monkeypatch):
     Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.2 * rng.standard_normal((2000, q)))
     fm = J.plskern(X, Y, nlv=nlv, scal=True, ctx=ctx)
     Xn = np.asfortranarray(rng.standard_normal((m, p)) + 1.0)
-    got = J.predict(fm, Xn, nlv=range(0, nlv + 1), ctx=ctx)
-    got = got if isinstance(got, (list, tuple)) else got.pred
-    assert len(got) == nlv + 1
-    for a in range(nlv + 1):
-        B = (fm.R[:, :a] @ fm.C[:, :a].T) / fm.xscales[:, None] * fm.yscales[None, :]
-        ref = fm.ymeans + (Xn - fm.xmeans) @ B
-        assert O.rel_fro(ref, np.asarray(got[a])) < 1e-11, a
+    got = np.asarray(J.xfit(fm, Xn, nlv=nlv, ctx=ctx))
+    ref = (((Xn - fm.xmeans) / fm.xscales) @ fm.R) @ (fm.P.T * fm.xscales[None, :]) + fm.xmeans
+    assert O.rel_fro(ref, got) < 1e-11
     for knob in ("JCH_GEMM_WIDEOUT_PAIRED", "JCH_GEMM_WIDEOUT"):
         monkeypatch.setenv(knob, "0")
-        other = J.predict(fm, Xn, nlv=range(0, nlv + 1), ctx=ctx)
-        other = other if isinstance(other, (list, tuple)) else other.pred
-        for a in range(nlv + 1):
-            assert O.rel_fro(np.asarray(other[a]), np.asarray(got[a])) < 1e-13, (knob, a)
+        assert O.rel_fro(np.asarray(J.xfit(fm, Xn, nlv=nlv, ctx=ctx)), got) < 1e-13, knob
         monkeypatch.delenv(knob)
 
 
