@@ -292,6 +292,17 @@ JCH_API int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, int
 JCH_API int32_t jch_score_sums(jch_ctx *ctx, int32_t loc, const double *Pred, int64_t m, int64_t ncol, int64_t ldp,
                                const double *Y, int64_t q, int64_t ldy, const double *mask, double *sums);
 
+/* jch_score_sums_lv — the statistics of jch_score_sums for the predictions with nlv = nlv_lo..nlv_hi latent variables, straight
+ * from the rows' scores: pred_a = ymeans + sum_{l <= a} t_l (c_l .* yscales)' (src/plskern.jl:207-217, 226-238 applied to
+ * `transform(object, X)`), accumulated level by level in registers — the m x (levels q) prediction matrix that gridscorelv /
+ * gridcvlv (src/gridscore.jl:196-216, src/gridcv.jl:206-224) would score never exists.  Levels beyond kfit repeat level kfit (the
+ * reference clamps, src/plskern.jl:228).
+ *   T m x kfit (scores of the rows, ld ldt), Y m x q, mask m (may be NULL) [loc]; C q x kfit (ld q), ymeans, yscales (q; NULL = 0 / 1)
+ *   HOST; sums (nlv_hi - nlv_lo + 1) q x 6 HOST, laid out like jch_score_sums on the level-major prediction matrix. */
+JCH_API int32_t jch_score_sums_lv(jch_ctx *ctx, int32_t loc, const double *T, int64_t m, int64_t kfit, int64_t ldt, const double *C,
+                                  const double *ymeans, const double *yscales, const double *Y, int64_t q, int64_t ldy, const double *mask,
+                                  int32_t nlv_lo, int32_t nlv_hi, double *sums);
+
 /* ---- harness utilities (bench / tests) ---------------------------------------------------------- */
 /* Fill device matrix out (n x p, column-major ld) with rows [row0,row0+n) of the n_total x p matrix
  * whose element (i,j) is splitmix64-uniform(seed, i + j*n_total) — the README's `rand(n,p)` stand-in

@@ -223,6 +223,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     ctx->ev_used = 0;
     ctx->prof = jch_profile{};
     jch_coll_reset(ctx);
+    ctx->sweep_seq = 0;   // (JCH_SWEEP_ALT: every fit starts its walk in the same direction — repeated fits stay bit-identical)
     // JCH_HOST_TIMING=1: host-side timeline of a fit on host arrays (stderr): where the wall time of the secondary metric goes
     static const bool host_timing = getenv("JCH_HOST_TIMING") != nullptr;
     auto now_ms = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };

@@ -60,6 +60,7 @@ struct jch_ctx {
     // workspace (grow-only)
     void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
     size_t hstage_bytes = 0;
+    unsigned sweep_seq = 0;   // launches of the plskern-shaped sweep so far (JCH_SWEEP_ALT: alternating walk direction)
     jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz, lw_work, lw_xrm, lvws, lw_flags, lw_screen;
     // profiling
     bool profiling = false;

@@ -206,12 +206,15 @@ __device__ __forceinline__ void jch_slice_sum_by_last_block(const double *__rest
     }
 }
 
-template <int KC, int R, int NBUF>
+// NT = false, rev alternating launch by launch (JCH_SWEEP_ALT=1, round 4): default-policy loads leave the rows in the 256 MiB
+// Infinity Cache, and a sweep that walks the row groups in the OPPOSITE order of the previous one starts with what that one read
+// last — measured in DESIGN.md §4 / §8.
+template <int KC, int R, int NBUF, bool NT = true>
 __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr, int64_t n, int ldr,
                                                   const double *__restrict__ dw, const double *__restrict__ rvec,
                                                   double *__restrict__ tcol, double *__restrict__ part, int ldpart,
                                                   const double *__restrict__ mu, int *__restrict__ tickets,
-                                                  double *__restrict__ zt, int ldz, int nslice)
+                                                  double *__restrict__ zt, int ldz, int nslice, int rev = 0)
 {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [nw][KC*128] + [16] tt, st
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -227,14 +230,18 @@ __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr,
     const int64_t gstride = (int64_t)gridDim.x * nw;
     v2f64 X[NBUF][R][KC];
     double D[NBUF][R];
+    const int64_t gbase = rev ? ngroups - 1 : 0, gsign = rev ? -1 : 1;   // group gg of the walk is row group gbase + gsign gg
     auto fetch = [&](v2f64 (&xb)[R][KC], double (&db)[R], int64_t gg) {
-        const int64_t r0 = gg * R;
+        const int64_t r0 = (gbase + gsign * gg) * R;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int64_t row = r0 + rr < n ? r0 + rr : n - 1;         // wave-uniform clamp
             const double *rp = Xr + (size_t)row * (size_t)ldr;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) xb[rr][k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(rp + coff[k]));
+            for (int k = 0; k < KC; ++k) {
+                if constexpr (NT) xb[rr][k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(rp + coff[k]));
+                else xb[rr][k] = *reinterpret_cast<const v2f64 *>(rp + coff[k]);
+            }
             db[rr] = dw[row];
         }
     };
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) void k_sweep_v2(const double *__restrict__ Xr,
         off = jch_wave_sum(o);
     }
     auto process = [&](v2f64 (&x)[R][KC], double (&dv)[R], int64_t gg) {
-        const int64_t row0 = gg * R;
+        const int64_t row0 = (gbase + gsign * gg) * R;
         double s[R];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
@@ -556,7 +563,7 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     static int bpc_cache = 0;
     if (bpc_cache == 0) {
         int nblk = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_v2<KC, R, NBUF>, 256, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_v2<KC, R, NBUF, true>, 256, lds);
         bpc_cache = (e == hipSuccess && nblk > 0) ? nblk : 1;
     }
     const int bpc = ctx->sweep_blocks_per_cu > 0 ? ctx->sweep_blocks_per_cu : bpc_cache;
@@ -578,8 +585,16 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     int *tickets = nullptr;
     if (fused) JCH_TRY(jch_sweep_tickets(ctx, &tickets));
     (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
-    hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
-                       tickets, zt, ldz, fused ? nslice : 0);
+    // JCH_SWEEP_ALT=1: default-policy loads + the row groups walked in alternating directions, launch by launch (see k_sweep_v2)
+    const char *e_alt = getenv("JCH_SWEEP_ALT");
+    const int alt = e_alt ? atoi(e_alt) : 0;
+    if (alt) {
+        const int rev = alt == 2 ? 0 : (int)(ctx->sweep_seq++ & 1u);   // (=2: default-policy loads, one direction — A/B runs)
+        hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF, false>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
+                           tickets, zt, ldz, fused ? nslice : 0, rev);
+    } else
+    hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF, true>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
+                       tickets, zt, ldz, fused ? nslice : 0, 0);
     (void)jch_ev(ctx);  // (end)
     if (pv && !fused) {   // split small-state path: k_lv_spread sums the block partials itself (no k_reduce_part launch)
         pv->part = part; pv->nb = nb; pv->ldpart = ldpart;

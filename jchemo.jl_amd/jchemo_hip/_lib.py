@@ -24,7 +24,7 @@ SYMBOLS = (
     "jch_version", "jch_ctx_create", "jch_ctx_destroy", "jch_last_error", "jch_comm_unique_id",
     "jch_ctx_comm_init", "jch_ctx_comm_info", "jch_plskern_fit", "jch_plsnipals_fit", "jch_affine_gemm",
     "jch_weighted_ss", "jch_fill_uniform", "jch_ctx_set_profiling", "jch_ctx_get_profile", "jch_lwplsr_predict",
-    "jch_weighted_cov", "jch_score_sums", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
+    "jch_weighted_cov", "jch_score_sums", "jch_score_sums_lv", "jch_plssimp_fit", "jch_plsrosa_fit", "jch_plswold_fit", "jch_transform",
     "jch_predict", "jch_loopback_group_create", "jch_loopback_group_destroy", "jch_ctx_comm_init_loopback",
     "jch_ctx_p2p_export", "jch_ctx_p2p_import", "jch_ctx_p2p_enable", "jch_plskern_fit_scaled", "jch_col_stats",
     "jch_ctx_get_counter", "jch_ctx_allreduce_probe", "jch_lwplsr_prepare", "jch_lwplsr_predict_prepared", "jch_lwplsr_release", "jch_lwplsr_add_query_map",
@@ -99,6 +99,7 @@ def load():
     L.jch_lwplsr_add_query_map.argtypes = [vp, vp, dp, dp, dp, i64, i64, dp]
     L.jch_weighted_cov.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp]
     L.jch_score_sums.argtypes = [vp, i32, dp, i64, i64, i64, dp, i64, i64, dp, dp]
+    L.jch_score_sums_lv.argtypes = [vp, i32, dp, i64, i64, i64, dp, dp, dp, dp, i64, i64, dp, i32, i32, dp]
     L.jch_fill_uniform.argtypes = [vp, dp, i64, i64, i64, i64, i64, C.c_uint64]
     L.jch_ctx_set_profiling.argtypes = [vp, i32]
     L.jch_ctx_get_profile.argtypes = [vp, C.POINTER(Profile)]

@@ -791,6 +791,44 @@ def _score_sums(pred, Y, mask, ctx):
     return sums.reshape(ncol // q, q, 6)
 
 
+def _score_sums_lv(T, fm, Y, mask, rng, ctx):
+    """jch_score_sums_lv: the statistics of `_score_sums` for the predictions with nlv = rng[0]..rng[-1] (contiguous) straight from
+    the rows' scores T (m x k) and the model's C / ymeans / yscales — the prediction matrix is never formed.  (levels, q, 6)."""
+    T = ensure_mat(T); Y = ensure_mat(Y)
+    dev = _is_torch(T)
+    if dev != _is_torch(Y):
+        Y = torch.as_tensor(np.asarray(Y), device=T.device) if dev else Y.cpu().numpy()
+    try:
+        _addr_ld(T)
+    except (ValueError, TypeError):
+        T = _as_colmajor_copy(T)
+    try:
+        _addr_ld(Y)
+    except (ValueError, TypeError):
+        Y = _as_colmajor_copy(Y)
+    m, k = T.shape
+    q = Y.shape[1]
+    if Y.shape[0] != m or fm.C.shape[0] != q:
+        raise ValueError("DimensionMismatch between the scores, Y and the model")
+    k = min(k, fm.C.shape[1])
+    lo, hi = int(rng[0]), int(rng[-1])
+    ctx = ctx or default_context((T.device.index or 0) if dev else 0)
+    ta, ldt = _addr_ld(T); ya, ldy = _addr_ld(Y)
+    ma = None
+    if mask is not None:
+        mask = mask if _is_torch(mask) == dev else (torch.as_tensor(np.asarray(mask, dtype=np.float64), device=T.device) if dev else mask.cpu().numpy())
+        mask = mask.to(torch.float64).contiguous() if dev else np.ascontiguousarray(mask, dtype=np.float64)
+        ma = mask.data_ptr() if dev else mask.ctypes.data
+    Cm = np.asfortranarray(fm.C[:, :k], dtype=np.float64)
+    ym, ys = _model_vec(fm.ymeans), _model_vec(fm.yscales)
+    sums = np.empty(((hi - lo + 1) * q, 6))
+    if dev:
+        torch.cuda.current_stream(T.device).synchronize()
+    ctx.check(_lib.load().jch_score_sums_lv(ctx._h, _lib.LOC_DEVICE if dev else _lib.LOC_HOST, ta, m, k, ldt, Cm.ctypes.data, _np(ym), _np(ys),
+                                            ya, q, ldy, ma, lo, hi, sums.ctypes.data))
+    return sums.reshape(hi - lo + 1, q, 6)
+
+
 def _score_from_sums(name: str, S: np.ndarray) -> np.ndarray:
     """S: (levels, q, 6) = {sum e, sum e^2, sum y e, sum y, sum y^2, count}.  Formulas: src/scores.jl."""
     se, see, sye, sy, syy, cnt = (S[..., i] for i in range(6))
@@ -899,7 +937,13 @@ def gridscorelv(Xtrain, Ytrain, X, Y, *, score, fun, nlv, pars=None, verbose: bo
             pred = [pred] if len(rng) == 1 else pred
             blocks.append(np.vstack([np.asarray(score(pr, Y)).reshape(1, -1) for pr in pred]))
         else:
-            blocks.append(_score_from_sums(name, _score_sums(_pred_matrix(fm, X, rng, ctx), Y, None, ctx)))
+            # the scores of X once (one pass), then every level's statistics from running sums over the score columns
+            kmax = min(max(rng), fm.P.shape[1])
+            Tq = transform(fm, X, nlv=kmax, ctx=ctx) if kmax > 0 else np.zeros((ensure_mat(X).shape[0], 0))
+            if kmax == 0:
+                blocks.append(_score_from_sums(name, _score_sums(_pred_matrix(fm, X, rng, ctx), Y, None, ctx)))
+            else:
+                blocks.append(_score_from_sums(name, _score_sums_lv(Tq, fm, Y, None, rng, ctx)))
     if verbose:
         print("-- End.")
     return _grid_table(pars, rng, np.vstack(blocks))
@@ -912,7 +956,7 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, verbose: bool = False, c
     """`gridcvlv(X, Y; segm, score, fun, nlv, pars)` — src/gridcv.jl:187-228.  The reference copies rmrow(X, s) for
     every segment; here X stays where it is and each fold is ONE weighted fit with weight 0 on the held-out rows
     (identical means / XtY / loadings), whose scores T on the held-out rows already are their transformed rows:
-    predictions for every nlv are T[:, :a] * C[:, :a]' — a GEMM on the n x nlv scores, no second pass over X.
+    predictions for every nlv are T[:, :a] * C[:, :a]' — running sums over the n x nlv scores, no second pass over X.
     Returns dict(nlv, <pars columns>, res (ncomb * le, q) mean over folds, res_rep (nrep, nsegm, ncomb * le, q))."""
     name = getattr(score, "_jch_name", None)
     if name is None or fun not in (plskern, plsnipals, plssimp, plsrosa, plswold):
@@ -936,22 +980,20 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, verbose: bool = False, c
             if verbose:
                 print(f"segm={jseg + 1} ", end="")
             s = np.asarray(s)
-            held = np.zeros(n); held[s] = 1.0
-            w = 1.0 - held
-            if dev:
-                held = torch.as_tensor(held, device=X.device); w = torch.as_tensor(w, device=X.device)
+            if dev:   # the fold's 0/1 vectors are made where they are used: only the held-out row numbers cross the bus
+                held = torch.zeros(n, dtype=torch.float64, device=X.device)
+                held[torch.as_tensor(s, dtype=torch.int64).to(X.device)] = 1.0
+                w = 1.0 - held
+            else:
+                held = np.zeros(n); held[s] = 1.0
+                w = 1.0 - held
             kfit = min(max(rng), n - len(s))                                   # the reference clamps with the TRAINING rows
             blocks = []
             for kw in combos:
                 fm = fun(X, Y, w, nlv=kfit, ctx=ctx, **kwargs, **kw)
-                k = fm.P.shape[1]
-                # B_c[l, a*q + j] = C[j, l] * yscale_j for l < min(a, k); bias = ymeans
-                Bc = np.zeros((k, len(rng) * q))
-                for ai, a in enumerate(rng):
-                    kk = min(a, k)
-                    Bc[:kk, ai * q:(ai + 1) * q] = (fm.C[:, :kk] * fm.yscales[:, None]).T
-                Pm = _affine(fm.T, None, None, Bc, np.tile(fm.ymeans, len(rng)), ctx)
-                blocks.append(_score_from_sums(name, _score_sums(Pm, Y, held, ctx)))
+                # pred_a = ymeans + sum_{l < min(a, k)} T_l (C_l .* yscales)' on the held-out rows: running sums over the score
+                # columns inside jch_score_sums_lv — the n x (levels q) prediction matrix is never formed
+                blocks.append(_score_from_sums(name, _score_sums_lv(fm.T, fm, Y, held, rng, ctx)))
             zres.append(np.vstack(blocks))
         rep_out.append(np.stack(zres))
     if verbose:

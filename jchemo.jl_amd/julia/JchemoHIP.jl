@@ -537,6 +537,24 @@ function _score_sums(pred, Y, mask, ctx)
     reshape(sums, 6, q, ncol ÷ q)            # [stat, response, level]
 end
 
+# the same sums for the predictions with nlv = lo..hi latent variables straight from the rows' scores T (m x k): running sums over the
+# score columns inside the library (jch_score_sums_lv) — the m x (levels q) prediction matrix is never formed
+function _score_sums_lv(T, fm, Y, mask, rng, ctx)
+    T = _in(T); Y = _colocate_mat(_in(Y), T)
+    m = size(T, 1); q = size(Y, 2); k = min(size(T, 2), size(fm.C, 2))
+    (size(Y, 1) == m && size(fm.C, 1) == q) || throw(DimensionMismatch("scores are $m x $(size(T, 2)), Y is $(size(Y, 1)) x $q"))
+    mask = mask === nothing ? nothing : _colocate(vec(Float64.(Array(mask))), T)
+    lo, hi = first(rng), last(rng)
+    Cm = Matrix{Float64}(fm.C[:, 1:k]); ym = Vector{Float64}(vec(fm.ymeans)); ys = Vector{Float64}(vec(fm.yscales))
+    sums = zeros(6, (hi - lo + 1) * q)
+    GC.@preserve T Y mask Cm ym ys check(ctx, ccall((:jch_score_sums_lv, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64,
+         Ptr{Float64}, Int32, Int32, Ptr{Float64}),
+        ctx.h, _loc(T), pointer(T), m, k, max(stride(T, 2), m), pointer(Cm), pointer(ym), pointer(ys), pointer(Y), q, max(stride(Y, 2), m),
+        mask === nothing ? Ptr{Float64}(C_NULL) : pointer(mask), lo, hi, sums))
+    reshape(sums, 6, q, hi - lo + 1)         # [stat, response, level]
+end
+
 # one score from the sums: levels x q  (formulas: src/scores.jl:25-32,54-62,155-158,190-196,268,426-429)
 function _score_from_sums(name::Symbol, S)
     se, see, sye, sy, syy, cnt = (permutedims(S[i, :, :]) for i in 1:6)
@@ -621,7 +639,9 @@ function gridscorelv(Xtrain, Ytrain, X, Y; score, fun, nlv, pars = nothing, verb
         verbose && pars !== nothing && println(pairs(kw)...)
         fm = fun(Xtrain, Ytrain; nlv = maximum(rng), kw...)
         if score isa ScoreFun && hasproperty(fm, :TT) && !hasproperty(fm, :lev)
-            push!(blocks, _score_from_sums(score.name, _score_sums(_pred_matrix(fm, X, rng, ctx), Y, nothing, ctx)))
+            kmax = min(maximum(rng), _nlv_fit(fm))
+            push!(blocks, kmax == 0 ? _score_from_sums(score.name, _score_sums(_pred_matrix(fm, X, rng, ctx), Y, nothing, ctx)) :
+                          _score_from_sums(score.name, _score_sums_lv(transform(fm, X; nlv = kmax, ctx = ctx), fm, Y, nothing, rng, ctx)))
         else                                   # any score(pred, Y) / any model with a `predict`
             pr = predict(fm, X; nlv = rng).pred
             pr = length(rng) == 1 ? [pr] : pr
@@ -637,7 +657,7 @@ end
 
 src/gridcv.jl:187-228.  The reference copies `rmrow(X, s)` for every segment; here X stays where it is: each fold is ONE
 weighted fit with weight 0 on the held-out rows (same means, X'DY and loadings as the fit on the remaining rows), whose scores on
-the held-out rows already are their transformed rows, so the predictions for every nlv are a GEMM on the n x nlv scores.
+the held-out rows already are their transformed rows, so the predictions for every nlv are running sums over the n x nlv scores.
 `score`: one of `msep, rmsep, ssr, bias, r2, cor2`; `fun`: a PLS fit of this module taking `(X, Y, weights; nlv, ...)`.
 Returns what the reference returns (:211-227): `(res = table, res_rep = table)` — `res_rep` with the columns
 `repl, segm, <pars...>, nlv, y1 ... yq` (one row per replication, segment, combination and nlv), `res` the means of `y1 ... yq` over
@@ -661,14 +681,8 @@ function gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false, 
             blocks = Matrix{Float64}[]
             for kw in _pars_rows(pars)
                 fm = fun(X, Y, w; nlv = kfit, kw...)
-                k = _nlv_fit(fm)
-                Bc = zeros(k, length(rng) * q)
-                for (ai, a) in enumerate(rng)
-                    kk = min(a, k)
-                    kk > 0 && (Bc[1:kk, (ai - 1) * q + 1:ai * q] = (fm.C[:, 1:kk] .* fm.yscales)')
-                end
-                Pm = _affine(fm.T, nothing, nothing, Bc, repeat(fm.ymeans, length(rng)), ctx)
-                push!(blocks, _score_from_sums(score.name, _score_sums(Pm, Y, held, ctx)))
+                # pred_a = ymeans + sum_{l <= min(a, k)} T_l (C_l .* yscales)' on the held-out rows, level by level inside the library
+                push!(blocks, _score_from_sums(score.name, _score_sums_lv(fm.T, fm, Y, held, rng, ctx)))
             end
             push!(zres, reduce(vcat, blocks))
         end

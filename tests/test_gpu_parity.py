@@ -499,6 +499,26 @@ def test_slice_sums_inside_the_sweep_are_bit_identical(shape, J, ctx, monkeypatc
     _cmp(O.plskern(X, Y, nlv=nlv), fm)
 
 
+@pytest.mark.parametrize("shape", [dict(n=9001, p=500, q=10, nlv=7), dict(n=3000, p=100, q=1, nlv=6), dict(n=70001, p=300, q=3, nlv=5)])
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_sweep_with_cached_loads_and_alternating_direction(shape, mode, J, ctx, monkeypatch):
+    """Measurement knob JCH_SWEEP_ALT (round 4; NOT the default — slower): default-policy instead of streaming loads
+    in the plskern sweep, the row groups walked in alternating directions launch by launch (=1) or always forward (=2).  The same
+    sums in another order: results equal the default's to rounding, and a repeated fit reproduces itself bit for bit (every fit
+    starts its walk in the same direction)."""
+    n, p, q, nlv = (shape[k] for k in ("n", "p", "q", "nlv"))
+    X = CO.fill_uniform(421, n, p) + 1.0
+    Y = X @ (CO.fill_uniform(422, p, q) - 0.5) + 0.1 * CO.fill_uniform(423, n, q)
+    ref = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    monkeypatch.setenv("JCH_SWEEP_ALT", mode)
+    a = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    b = J.plskern(X, Y, nlv=nlv, ctx=ctx)
+    s = O.sign_align(ref.W, a.W)
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert O.rel_fro(getattr(ref, f), getattr(a, f) * s) < 1e-9, f
+
+
 @pytest.mark.parametrize("shape", [(70000, 123, 3, 5), (66002, 500, 10, 25), (65537, 500, 2, 20), (131072, 37, 1, 16)])
 def test_long_input_accessors(shape, J, ctx, monkeypatch):
     """`transform` / `predict` on inputs long enough for the persistent accessor kernel (whole coefficient matrix in LDS,
@@ -597,6 +617,44 @@ def test_plsnipals_many_lvs_inverse_outside_lds(J, ctx):
     assert np.allclose(fm.R.T @ fm.P, np.eye(nlv), atol=1e-8)
     s = O.sign_align(ref.W, fm.W)
     assert O.rel_fro(ref.R, fm.R * s) < 1e-6 and O.rel_fro(ref.T, fm.T * s) < 1e-6
+
+
+@pytest.mark.parametrize("case", [dict(m=5000, p=40, q=3, k=12, lo=0, hi=12), dict(m=3001, p=30, q=1, k=5, lo=2, hi=9),
+                                  dict(m=2500, p=60, q=11, k=40, lo=0, hi=40), dict(m=4000, p=50, q=2, k=45, lo=7, hi=45)])
+@pytest.mark.parametrize("resident", [False, True])
+def test_score_sums_from_the_scores_equal_those_of_the_predictions(case, resident, J, ctx):
+    """jch_score_sums_lv (round 4): the msep / r2 / ... statistics for nlv = lo..hi from running sums over the rows' score columns
+    against jch_score_sums on the prediction matrix itself (src/plskern.jl:226-238, src/gridscore.jl:196-216): with and without a
+    row mask, ranges that start above 0, levels beyond the fitted LVs (clamped, :228), more than 32 levels (two launches), one
+    response and more than eight, host and device-resident inputs."""
+    from jchemo_hip import plsr as PL
+    m, p, q, k, lo, hi = (case[x] for x in ("m", "p", "q", "k", "lo", "hi"))
+    rng = np.random.default_rng(m + k)
+    Lt = rng.standard_normal((1500, k))
+    X = np.asfortranarray(Lt @ rng.standard_normal((k, p)) + 0.2 * rng.standard_normal((1500, p)) + 1.0)
+    Y = np.asfortranarray(Lt[:, :q] @ rng.standard_normal((q, q)) + 0.3 * rng.standard_normal((1500, q)) + 2.0)
+    fm = J.plskern(X, Y, nlv=min(k, p), scal=True, ctx=ctx)
+    kf = fm.P.shape[1]
+    Xn = np.asfortranarray(rng.standard_normal((m, p)) + 1.0)
+    Yn = np.asfortranarray(rng.standard_normal((m, q)) + 2.0)
+    mask = (rng.random(m) < 0.3).astype(np.float64)
+    levels = list(range(lo, hi + 1))
+    preds = J.predict(fm, Xn, nlv=range(lo, min(hi, kf) + 1), ctx=ctx)
+    preds = preds if isinstance(preds, list) else [preds]
+    preds = preds + [preds[-1]] * (len(levels) - len(preds))            # levels beyond the fit repeat the last one
+    Pm = np.asfortranarray(np.hstack([np.asarray(z) for z in preds]))
+    Tq = J.transform(fm, Xn, ctx=ctx)
+    if resident:
+        import torch
+        dv = lambda a: (lambda t: (t.copy_(torch.from_numpy(a)), t)[1])(J.colmajor_empty(a.shape[0], a.shape[1]))
+        Tq, Yin, Pm_in, msk = dv(np.asfortranarray(Tq)), dv(Yn), dv(Pm), torch.from_numpy(mask).cuda()
+    else:
+        Yin, Pm_in, msk = Yn, Pm, mask
+    for mk in (None, msk):
+        ref = PL._score_sums(Pm_in, Yin, mk, ctx)
+        got = PL._score_sums_lv(Tq, fm, Yin, mk, levels, ctx)
+        assert got.shape == ref.shape == (len(levels), q, 6)
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-9 * np.abs(ref).max()), np.abs(got - ref).max()
 
 
 def test_scores_and_gridscorelv(J, ctx):
