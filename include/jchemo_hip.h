@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 105 /* 0.1.5: screened kNN (JCH_COUNTER_KNN_SCREENED / _REDONE); 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
+#define JCH_VERSION 106 /* 0.1.6: + jch_score_sums_lv, jch_predict over an nlv range as running sums over the scores; 0.1.5: screened kNN (JCH_COUNTER_KNN_SCREENED / _REDONE); 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
@@ -213,7 +213,9 @@ JCH_API int32_t jch_transform(jch_ctx *ctx, int32_t loc, const double *X, int64_
  * [nlv_lo, nlv_hi] (0 = intercept only) in ONE pass over X: pred (m x q*(nlv_hi-nlv_lo+1), ld ldo) [loc]; block b =
  * columns b*q .. b*q+q-1 = prediction with nlv_lo + b LVs.  Model pieces (xmeans, xscales p; ymeans, yscales q;
  * R p x nlv_fit ld p; C q x nlv_fit ld q) HOST, nlv_hi <= nlv_fit is the caller's responsibility (the reference
- * clamps at :228). */
+ * clamps at :228).  One or two levels: one GEMM with the levels' coefficient matrices side by side.  Three or more on a long input
+ * (m >= 4096): the scores X_c R once (m x nlv_hi), then the blocks as running sums over the score columns,
+ * pred_a = pred_{a-1} + t_a (c_a .* yscales)' — X_c B_a = T_a C_a' — written in one streaming pass (cfg2 size, nlv = 0..25: 1.15 ms). */
 JCH_API int32_t jch_predict(jch_ctx *ctx, int32_t loc, const double *X, int64_t m, int64_t p, int64_t ldx, const double *xmeans,
                     const double *xscales, const double *ymeans, const double *yscales, const double *R, const double *C,
                     int64_t q, int32_t nlv_lo, int32_t nlv_hi, double *pred, int64_t ldo);

@@ -26,6 +26,7 @@
 #include "lv_device.h"
 
 #define SP_NT 256
+#define SP_RB 16          // partial rows per thread and load batch of k_lv_spread
 #define SP_GP 272          // doubles per block in gpart before the s_i: 256 Gram entries + 16 of zp' K_new
 
 struct lvs_args {
@@ -78,16 +79,17 @@ __device__ __forceinline__ bool spread_body(const lvs_args &g, const int tid)
     const int cidx = min(jc, g.ldr - 1);
     double acc = 0.0, acc2 = 0.0;
     const int xidx = col == 0 ? g.itt : (g.ist >= 0 ? g.ist : g.itt);
-    for (int b0 = act ? gr : g.nb; b0 < g.nb; b0 += 16 * 8) {
-        double v[8], x[8];
+    // (16 rows per thread and trip: the 256 partial rows of a full-chip sweep in ONE round trip to L2 instead of two dependent ones)
+    for (int b0 = act ? gr : g.nb; b0 < g.nb; b0 += 16 * SP_RB) {
+        double v[SP_RB], x[SP_RB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < SP_RB; ++u) {
             const size_t row = (size_t)min(b0 + 16 * u, g.nb - 1) * g.ldpart;
             v[u] = g.part[row + cidx];
             x[u] = col < 2 ? g.part[row + xidx] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < SP_RB; ++u) {
             const bool live = b0 + 16 * u < g.nb;
             acc += live ? v[u] : 0.0;
             acc2 += live ? x[u] : 0.0;
