@@ -384,7 +384,14 @@ def _pred_matrix(fm: "Plsr", X, rng, ctx):
     q = fm.C.shape[0]
     # several nlv: the library takes ONE pass over X for the scores (m x max(nlv)); every prediction block is then a running sum of
     # score x loading terms, pred_a = ymeans + sum_{l <= a} T_l (C_l .* yscales)' (k_predict_prefix, csrc/gemm.hip)
-    return _predict_range(fm, X, rng[0], rng[-1], ctx)   # rng is contiguous (src/plskern.jl:228)
+    a = fm.P.shape[1]
+    if rng[-1] <= a:
+        return _predict_range(fm, X, rng[0], rng[-1], ctx)   # rng is contiguous (src/plskern.jl:228)
+    # levels beyond the fitted LVs repeat the last one (the reference clamps, :228)
+    lo, hi = min(rng[0], a), a
+    out = _predict_range(fm, X, lo, hi, ctx)
+    cols = np.concatenate([np.arange(q) + (min(k, a) - lo) * q for k in rng])
+    return out[:, torch.as_tensor(cols, device=out.device)] if _is_torch(out) else out[:, cols]
 
 
 def predict(fm: Plsr, X, *, nlv: Union[None, int, Sequence[int]] = None, ctx: Optional[Context] = None, rank: Optional[int] = None,

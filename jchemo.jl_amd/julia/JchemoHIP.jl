@@ -305,16 +305,32 @@ function coef(object; nlv = nothing)
     (B = B, int = int)
 end
 
+# m x (q * (hi - lo + 1)) predictions for nlv = lo..hi, level-major columns: ONE library call (jch_predict) and one pass over X — up to two
+# levels as one GEMM, more as the scores X_c R followed by running sums over the score columns (include/jchemo_hip.h)
+function _predict_range(object, X, lo::Integer, hi::Integer, ctx)
+    X = _in(X); m, p = size(X); q = size(object.C, 1)
+    size(object.R, 1) == p || throw(DimensionMismatch("X has $p columns, the model has $(size(object.R, 1))"))
+    out = _similar(X, m, q * (hi - lo + 1))
+    R = Matrix{Float64}(object.R); Cm = Matrix{Float64}(object.C)
+    xm = Vector{Float64}(vec(object.xmeans)); xs = Vector{Float64}(vec(object.xscales))
+    ym = Vector{Float64}(vec(object.ymeans)); ys = Vector{Float64}(vec(object.yscales))
+    GC.@preserve X out R Cm xm xs ym ys check(ctx, ccall((:jch_predict, LIB), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Int64, Int32, Int32, Ptr{Float64}, Int64),
+        ctx.h, _loc(X), pointer(X), m, p, stride(X, 2), pointer(xm), pointer(xs), pointer(ym), pointer(ys), pointer(R), pointer(Cm), q,
+        lo, hi, pointer(out), max(m, 1)))
+    out
+end
+
 """`predict(object, X; nlv)` — src/plskern.jl:226-238 (a `Plsr` record) or src/lwplsr.jl:134-166 (an `Lwplsr` record).
-PLSR: the whole nlv range in ONE pass over X (the B blocks concatenated)."""
+PLSR: the whole nlv range in ONE pass over X (`jch_predict`)."""
 function predict(object, X; nlv = nothing, ctx = default_ctx())
     hasproperty(object, :metric) && return _predict_lwplsr(object, X, nlv, ctx)
     hasproperty(object, :lev) && return _predict_plsrda(object, X, nlv, ctx)
     hasproperty(object, :bscales) && return _predict_mbplsr(object, X, nlv, ctx)
     a = _nlv_fit(object); q = size(object.C, 1)
     rng = nlv === nothing ? (a:a) : (max(0, minimum(nlv)):min(a, maximum(nlv)))
-    zs = [coef(object; nlv = k) for k in rng]
-    out = _affine(X, nothing, nothing, reduce(hcat, [z.B for z in zs]), reduce(vcat, [vec(z.int) for z in zs]), ctx)
+    out = _predict_range(object, X, first(rng), last(rng), ctx)
     pred = [out[:, (i - 1) * q + 1:i * q] for i in 1:length(rng)]
     (pred = length(rng) == 1 ? pred[1] : pred,)
 end
@@ -599,16 +615,8 @@ _randperm(n) = sortperm(rand(n))
 _nlv_range(nlv, p) = max(0, minimum(nlv)):min(p, maximum(nlv))
 _pars_rows(pars) = pars === nothing ? [NamedTuple()] : [NamedTuple{keys(pars)}(Tuple(v[i] for v in values(pars))) for i in 1:length(first(values(pars)))]
 
-# m x (length(rng) * q) predictions [pred_rng[1] | pred_rng[2] | ...]: ONE pass over X for the scores, then a GEMM on the scores
-function _pred_matrix(fm, X, rng, ctx)
-    q = size(fm.C, 1); kmax = maximum(rng); a = _nlv_fit(fm)
-    Bc = zeros(max(kmax, 1), length(rng) * q)
-    for (ai, k) in enumerate(rng)
-        k > 0 && (Bc[1:k, (ai - 1) * q + 1:ai * q] = (fm.C[:, 1:k] .* fm.yscales)')
-    end
-    Tq = kmax == 0 ? _affine(X, nothing, nothing, zeros(size(fm.R, 1), 1), nothing, ctx) : transform(fm, X; nlv = min(kmax, a), ctx = ctx)
-    _affine(Tq, nothing, nothing, Bc[1:size(Tq, 2), :], repeat(fm.ymeans, length(rng)), ctx)
-end
+# m x (length(rng) * q) predictions [pred_rng[1] | pred_rng[2] | ...] (rng contiguous, src/plskern.jl:228): one library call
+_pred_matrix(fm, X, rng, ctx) = _predict_range(fm, X, first(rng), min(last(rng), _nlv_fit(fm)), ctx)
 
 # Columns of the reference's result table, in its order (src/gridscore.jl:196-220: `hcat(dat, res)` with dat = the `pars` columns,
 # each combination repeated le_nlv times, then `nlv`; res = y1 ... yq), rows combination-major.
