@@ -913,7 +913,7 @@ __device__ __forceinline__ constexpr int bf_rowsum_lane(int rr)
     return 16 * (((rr & 3) == 1) ? 2 : ((rr & 3) == 2) ? 1 : (rr & 3)) + (R == 8 ? 8 * (rr >> 2) : 0);
 }
 
-template <int KC, int R>
+template <int KC, int R, int NBUF = 2>   // NBUF register buffers in rotation: NBUF - 1 row groups in flight behind the one being reduced
 __global__ __launch_bounds__(256) void k_sweep_bf16_v2(const bf16_t *__restrict__ Xr, int64_t n, int ldr, const double *__restrict__ dw,
                                                        const double *__restrict__ rvec, const double *__restrict__ mom,
                                                        const double *__restrict__ scl, int p,
@@ -929,8 +929,8 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_v2(const bf16_t *__restrict_
     }
     const int64_t ngroups = (n + R - 1) / R;
     const int64_t gstride = (int64_t)gridDim.x * 4;
-    v4u32 X[2][R][KC];
-    double D[2][R];   // (kept as loaded: converting here would make the prefetch wait for its own loads)
+    v4u32 X[NBUF][R][KC];
+    double D[NBUF][R];   // (kept as loaded: converting here would make the prefetch wait for its own loads)
     auto fetch = [&](v4u32 (&xb)[R][KC], double (&db)[R], int64_t gg) {
         const int64_t r0 = gg * R;
 #pragma unroll
@@ -943,7 +943,9 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_v2(const bf16_t *__restrict_
         }
     };
     int64_t g = (int64_t)blockIdx.x * 4 + wv;
-    if (g < ngroups) fetch(X[0], D[0], g);
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (g + b * gstride < ngroups) fetch(X[b], D[b], g + b * gstride);
     // rt_j = r_j / s_j (fp32) and off = sum_j m_j * rt_j (fp64, from the fp32-rounded rt): see k_sweep_bf16
     float rf[KC][8], zp[KC][8];
     double offd = 0.0;
@@ -1000,9 +1002,10 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_v2(const bf16_t *__restrict_
     };
     while (g < ngroups) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NBUF; ++b) {
             if (g < ngroups) {
-                if (g + gstride < ngroups) fetch(X[b ^ 1], D[b ^ 1], g + gstride);
+                const int64_t ahead = g + (NBUF - 1) * gstride;
+                if (ahead < ngroups) fetch(X[(b + NBUF - 1) % NBUF], D[(b + NBUF - 1) % NBUF], ahead);
                 process(X[b], D[b], g);
                 g += gstride;
             }
@@ -1072,7 +1075,7 @@ static int32_t launch_sweep_bf16_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, in
     return JCH_OK;
 }
 
-template <int KC, int R>
+template <int KC, int R, int NBUF = 2>
 static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n, int ldr_b, const double *d, const double *rvec,
                                       const double *mom, const double *scl, int p, double *tcol, double *zt8, int ldzb, int *nslice,
                                       jch_part_view *pv = nullptr /*split small-state path on one rank / with the per-block inbox: leave the block partials unreduced*/)
@@ -1082,10 +1085,10 @@ static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n,
     static jch_per_device_once occ_once;
     if (!occ_once.done(ctx->device)) {
         int nblk = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_bf16_v2<KC, R>, 256, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_sweep_bf16_v2<KC, R, NBUF>, 256, lds);
         bpc = (e == hipSuccess && nblk > 0) ? nblk : 2;
         if (lds > 64 * 1024)
-            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_bf16_v2<KC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            JCH_HIP(ctx, hipFuncSetAttribute((const void *)k_sweep_bf16_v2<KC, R, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         occ_once.mark(ctx->device);
     }
     const int64_t ngroups = (n + R - 1) / R;
@@ -1096,7 +1099,7 @@ static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n,
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->part.ptr;
     (void)jch_ev(ctx);
-    hipLaunchKernelGGL((k_sweep_bf16_v2<KC, R>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
+    hipLaunchKernelGGL((k_sweep_bf16_v2<KC, R, NBUF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
     (void)jch_ev(ctx);
     if (pv) { pv->part = part; pv->nb = nb; pv->ldpart = ldpart; *nslice = 1; JCH_HIP(ctx, hipGetLastError()); return JCH_OK; }
     JCH_TRY(jch_launch_reduce_part8(ctx, part, nb, ldpart, m, zt8, ldzb, nslice));
@@ -1290,6 +1293,12 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
             const char *e2 = getenv("JCH_BF16_V2");
             const int v2 = e2 ? atoi(e2) : 1;
             if (v2 && ldr_b >= 8 && ldr_b <= 1024) {
+                const char *e_nb = getenv("JCH_BF16_NBUF");      // (=3 / =4: deeper rotation of the row-group buffers — A/B runs)
+                const int nbuf = e_nb ? atoi(e_nb) : 2;
+                if (ldr_b <= 512 && nbuf == 3 && v2 != 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 8, 3>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
+                else if (ldr_b <= 512 && nbuf == 4 && v2 != 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4, 4>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
+                else if (ldr_b <= 512 && nbuf == 5 && v2 != 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4, 3>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
+                else
                 if (ldr_b <= 512) { if (v2 == 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
                                     else JCH_TRY((launch_sweep_bf16_v2_t<1, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp))); }
                 else JCH_TRY((launch_sweep_bf16_v2_t<2, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
