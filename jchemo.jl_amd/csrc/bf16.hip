@@ -1293,12 +1293,9 @@ int32_t jch_fit_plskern_bf16(jch_ctx *ctx, const jch_pls_desc &d, const void *Xv
             const char *e2 = getenv("JCH_BF16_V2");
             const int v2 = e2 ? atoi(e2) : 1;
             if (v2 && ldr_b >= 8 && ldr_b <= 1024) {
-                const char *e_nb = getenv("JCH_BF16_NBUF");      // (=3 / =4: deeper rotation of the row-group buffers — A/B runs)
-                const int nbuf = e_nb ? atoi(e_nb) : 2;
-                if (ldr_b <= 512 && nbuf == 3 && v2 != 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 8, 3>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
-                else if (ldr_b <= 512 && nbuf == 4 && v2 != 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4, 4>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
-                else if (ldr_b <= 512 && nbuf == 5 && v2 != 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4, 3>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
-                else
+                // (Measured, round 4: deeper rotations of the row-group buffers, NBUF template parameter — <1,8,3> 221-225 us per launch at
+                // n = 1e6 (one wave per SIMD), <1,4,4> 196-201, <1,4,3> 164-168 against 160-168 for the default <1,8,2>; n = 8e6: 1 575 /
+                // 1 338 against 1 282 — more bytes in flight per wave do not make up for the waves they cost.)
                 if (ldr_b <= 512) { if (v2 == 4) JCH_TRY((launch_sweep_bf16_v2_t<1, 4>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));
                                     else JCH_TRY((launch_sweep_bf16_v2_t<1, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp))); }
                 else JCH_TRY((launch_sweep_bf16_v2_t<2, 8>(ctx, Xr, n, ldr_b, dn, s.r, s.mom, s.scl, p, tcol, zt8, ldzb, &nslice, pvp)));

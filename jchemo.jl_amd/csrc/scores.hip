@@ -79,7 +79,10 @@ extern "C" int32_t jch_score_sums(jch_ctx *ctx, int32_t loc, const double *Pred,
 // yscales)' (src/plskern.jl:207-217, :226-238 on the rows' scores), so the (hi - lo + 1) q prediction columns never have to exist:
 // a thread walks its rows' score columns once, carries the running prediction of ONE response and adds e = y - pred to the
 // level's three sums.  Reads m x k scores (once per response slice: L2 / Infinity Cache hits after the first) + Y + mask instead
-// of writing and re-reading m x (hi - lo + 1) q predictions (2.08 GB twice at cfg2).  Levels beyond the fit's k LVs repeat level k
+// of writing and re-reading m x (hi - lo + 1) q predictions (2.08 GB twice at cfg2).  (Measured and dropped, round 4: a wave per
+// response with the four waves of a block on the same 64 rows — the score columns from the CU's L1 for three of them, wave sums
+// instead of block sums — needs 324 registers for 16-column load batches, runs one wave per SIMD and takes 1.18 ms against 0.58
+// for a fold of cfg2.)  Levels beyond the fit's k LVs repeat level k
 // (the reference clamps, src/plskern.jl:228).  Same two-stage fixed-order reduction as k_score_sums; part laid out [nbx][ncol][6].
 #define SLV_LE 32     // levels per launch (accumulators in registers: 3 per level)
 __global__ __launch_bounds__(256) void k_score_sums_lv(const double *__restrict__ T, int64_t m, int64_t ldt, int kfit, const double *__restrict__ Cs,
