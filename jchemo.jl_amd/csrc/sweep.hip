@@ -838,6 +838,8 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
                 // rotation keeps two groups in flight behind the one being reduced (round 4, three A/B pairs on one box: 125 k rows
                 // 79.0-80.3 against 80.2-81.6 us per launch, 250 k rows 151.4 against 153.9); JCH_SWEEP_NBUF=2 / =3 force either
                 const bool shortshard = n < (int64_t)1280 * ctx->cus;
+                // (measured, round 4: <4, 8, 3> — two 32 KB row groups in flight per wave, 256 + 254 registers — 589.0-589.4 us per launch
+                // at n = 1e6 against 587.6 for <4, 8, 2>: the sweep is not short of bytes in flight)
                 if (nbuf == 3 || (!eb && v2 != 8 && v2 != 4 && shortshard)) JCH_SWEEP_V2_CASE(4, 4, 3);
                 if (v2 == 4 || (v2 != 8 && n < (int64_t)640 * ctx->cus)) JCH_SWEEP_V2_CASE(4, 4, 2);
                 JCH_SWEEP_V2_CASE(4, 8, 2);
