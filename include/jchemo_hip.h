@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 106 /* 0.1.6: + jch_score_sums_lv, jch_predict over an nlv range as running sums over the scores; 0.1.5: screened kNN (JCH_COUNTER_KNN_SCREENED / _REDONE); 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
+#define JCH_VERSION 107 /* 0.1.7: JCH_REUSE_XCOPY, JCH_COUNTER_XCOPY_REUSED; 0.1.6: + jch_score_sums_lv, jch_predict over an nlv range as running sums over the scores; 0.1.5: screened kNN (JCH_COUNTER_KNN_SCREENED / _REDONE); 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
@@ -112,7 +112,8 @@ typedef struct jch_pls_desc {
                          bit 0 (1) = OPT-IN kernel algorithm #2 (X'DX once, no pass over X and no collective in the LV
                          loop; plskern, q <= 16, p <= 2048): same results up to rounding;
                          JCH_WOLD_REF_ZERO_WEIGHT_NAN (jch_plswold_fit only): see below;
-                         JCH_NIPALS_ONE_PASS (jch_plsnipals_fit / jch_plswold_fit): see below */
+                         JCH_NIPALS_ONE_PASS (jch_plsnipals_fit / jch_plswold_fit): see below;
+                         JCH_REUSE_XCOPY (any fit): X is unchanged since the previous fit on this ctx, see below */
 } jch_pls_desc;
 /* jch_plswold_fit: give the rows with weight 0 NaN scores, as the reference does (src/plswold.jl:107 divides by sqrt(w) = 0).
  * Default (bit clear): finite scores t_i = x_i' r for those rows — what a cross-validation fold with zero weights on its
@@ -125,6 +126,13 @@ typedef struct jch_pls_desc {
  * written back every few LVs (the postponed write-back needs q <= 16, p <= 2048, inplace = 0, Float64: JCH_EINVAL otherwise).
  * Same results up to rounding (gate of the tests: 1e-9 against the default path on well-conditioned LVs). */
 #define JCH_NIPALS_ONE_PASS 4
+/* Any fit: the caller PROMISES that X (pointer, shape, leading dimension and contents) is what the previous fit on this ctx was
+ * given — the folds of a cross-validation (`gridcvlv`, src/gridcv.jl:200-208: the same X with other rows held out), the combinations
+ * of a parameter grid.  A Float64 plskern-shaped fit whose predecessor left its row-major working copy in the workspace then skips
+ * the staging of X (host arrays) and the transposing copy, and takes X'D[Yc | 1] from one streaming read of that copy (q <= 11,
+ * p <= 512; same results up to the summation order of X'DY).  In every other situation the bit is ignored.  Y and the weights may
+ * change freely; if X changed, the results are those of the OLD X. */
+#define JCH_REUSE_XCOPY 8
 
 /*
  * jch_plskern_fit — replaces `plskern!` / `plskern` (src/plskern.jl:106-178): weight normalisation
@@ -370,6 +378,8 @@ JCH_API int32_t jch_ctx_allreduce_probe(jch_ctx *ctx, int32_t transport, double 
  * (jch_lwplsr_prepare) that sees more than a quarter of a call's queries redone stops screening. */
 #define JCH_COUNTER_KNN_SCREENED 2
 #define JCH_COUNTER_KNN_SCREEN_REDONE 3
+/* which = JCH_COUNTER_XCOPY_REUSED: fits that honoured JCH_REUSE_XCOPY, i.e. took X'D[Yc | 1] from the previous fit's row-major copy */
+#define JCH_COUNTER_XCOPY_REUSED 4
 JCH_API int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_t *out);
 
 #ifdef __cplusplus

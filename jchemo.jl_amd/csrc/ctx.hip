@@ -437,6 +437,7 @@ extern "C" int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_
     if (which == JCH_COUNTER_LOCW_REFITS) { *out = ctx->locw_refits; return JCH_OK; }
     if (which == JCH_COUNTER_KNN_SCREENED) { *out = ctx->knn_screened; return JCH_OK; }
     if (which == JCH_COUNTER_KNN_SCREEN_REDONE) { *out = ctx->knn_screen_redone; return JCH_OK; }
+    if (which == JCH_COUNTER_XCOPY_REUSED) { *out = ctx->xcopy_reused; return JCH_OK; }
     return JCH_EINVAL;
 }
 

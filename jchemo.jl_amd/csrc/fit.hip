@@ -198,6 +198,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         // Float64 device buffers and the Float64 path runs on them.  No bandwidth saving there, but no refusal either.
         const jch_pls_desc &db = *io.d;
         JCH_HIP(ctx, hipSetDevice(ctx->device));
+        ctx->xcopy_valid = false;
         JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * (size_t)db.n * db.p));
         JCH_TRY(jch_reserve(ctx, ctx->ystage, sizeof(double) * (size_t)db.n * db.q));
         const unsigned nbw = (unsigned)std::min<int64_t>(((int64_t)db.n * db.p + 255) / 256, (int64_t)ctx->cus * 16);
@@ -230,6 +231,14 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     const double tl0 = now_ms();
     double tl_h2d = tl0, tl_enq = tl0, tl_sync = tl0;
 
+    // JCH_REUSE_XCOPY: the caller promises that X is what the previous fit on this ctx was given (the folds of a cross-validation:
+    // other weights, other Y rows held out — the same X).  If that fit left its raw row-major copy in the workspace (same pointer,
+    // shape and leading dimension, f64, raw mode) this one skips the staging of X and the transposing pass and takes X'D[Yc | 1]
+    // from the copy (prologue.hip k_xty_rows); otherwise the bit changes nothing.
+    const xcopy_key xkey{io.X, (int64_t)n, (int64_t)io.ldx, p, host ? 1 : 0};
+    const bool reuse_x = (d.reserved & JCH_REUSE_XCOPY) && allow_raw && ctx->xcopy_valid && ctx->xcopy == xkey && d.dtype == JCH_F64 &&
+                         q + 1 <= 12 && ldr <= 512 && !getenv("JCH_NO_REUSE_XCOPY");
+    if (!reuse_x) ctx->xcopy_valid = false;   // (whatever this fit does to the workspace, the old copy is not to be trusted afterwards)
     // ---- inputs on the device (column-major as handed over)
     double *Xc = (double *)io.X, *Yc = (double *)io.Y;
     const double *wdev = io.weights;
@@ -238,7 +247,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * (size_t)n * p));
         JCH_TRY(jch_reserve(ctx, ctx->ystage, sizeof(double) * (size_t)n * q));
         Xc = (double *)ctx->xstage.ptr; Yc = (double *)ctx->ystage.ptr; ldxc = n; ldyc = n;
-        JCH_TRY(h2d_matrix(ctx, Xc, (const double *)io.X, n, p, io.ldx));
+        if (!reuse_x) JCH_TRY(h2d_matrix(ctx, Xc, (const double *)io.X, n, p, io.ldx));   // (reuse: the staging copy of the previous fit is this X)
         JCH_TRY(h2d_matrix(ctx, Yc, (const double *)io.Y, n, q, io.ldy));
         if (io.weights) {
             JCH_TRY(jch_reserve(ctx, ctx->wstage, sizeof(double) * (size_t)n));
@@ -386,7 +395,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
     // instead of two).  The sweeps then use t_i = x_i.r - mu.r and zp = zp_raw - mu * sum_i d_i t_i (sweep.hip,
     // smallstate_fast.hip); T, P, C, TT, xmeans are the same quantities as in the centred formulation.
     const bool raw_mode = (((algo == ALGO_KERN || algo == ALGO_ROSA) && fast) || (algo == ALGO_SIMP && all_fast)) && !ext_scales && !inplace &&
-                          q <= 15 && d.reserved == 0 && p <= JCH_SWEEP_MAXP && allow_raw && !getenv("JCH_CENTRED_COPY") &&
+                          q <= 15 && (d.reserved & ~JCH_REUSE_XCOPY) == 0 && p <= JCH_SWEEP_MAXP && allow_raw && !getenv("JCH_CENTRED_COPY") &&
                           !(d.scal && getenv("JCH_CENTRED_COPY_SCAL"));
     if (raw_mode) {
         // (mshift and the pivot-quality word were zeroed by the weights launch above; the divisor slots `s.mom` handed to K2
@@ -395,8 +404,15 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         double *spread2 = cv.take(p);
         JCH_TRY(jch_launch_pivot(ctx, Xc, ldxc, n, p, s.hdr, s.scl, spread2));                      // scl[0..p): the pivot K2 subtracts
         JCH_TRY(jch_launch_moments(ctx, Yc, ldyc, nullptr, 0, dn, n, q, 0, nullptr, s.scl + p));  // Y means -> scl[p..p+q)
+        bool from_copy = false;
+        if (reuse_x) JCH_TRY(jch_launch_xty_rows(ctx, Xr, ldr, Yc, ldyc, dn, n, p, q, /*mom =*/s.scl, Yr, qpad, s.K, /*means_out =*/s.mom,
+                                                 /*mshift_out =*/s.mshift, spread2, qual_dev, /*ones_out =*/s.scl, &from_copy));
+        if (from_copy) ctx->xcopy_reused++;
+        else {
         JCH_TRY(jch_launch_center_xty(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, /*mom =*/s.scl, /*scl =*/s.mom, false, Xr, ldr, Yr, qpad, s.K, false,
                                       /*means_out =*/s.mom, /*mshift_out =*/s.mshift, spread2, qual_dev, /*ones_out =*/s.scl));
+        ctx->xcopy = xkey; ctx->xcopy_valid = true;   // the raw copy x - pivot of THIS X now sits in the workspace
+        }
         if (d.scal) {   // stds from ONE streaming pass over the row-major copy; the scaling itself is folded into r / s and zp / s
             s.rs = cv.take((size_t)ldr + 2);
             JCH_HIP(ctx, hipMemsetAsync(s.rs, 0, sizeof(double) * ((size_t)ldr + 2), ctx->stream));
@@ -404,6 +420,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         }
         s.variant = 2;
     } else {
+    ctx->xcopy_valid = false;   // (the working copy becomes the centred / scaled / deflated one)
     JCH_TRY(jch_launch_moments(ctx, Xc, ldxc, Yc, ldyc, dn, n, p, q, nullptr, s.mom));
     if (ext_scales) {   // divisors handed in by the caller (multiblock scaling): no second-moment pass
         JCH_TRY(jch_reserve_host(ctx, sizeof(double) * (size_t)(p + q)));
@@ -691,6 +708,7 @@ extern "C" int32_t jch_col_stats(jch_ctx *ctx, int32_t loc, const double *X, int
     const double *dX = X, *dw = weights;
     int64_t ldxd = ldx;
     if (loc == JCH_LOC_HOST) {
+        if (ctx->xcopy.host) ctx->xcopy_valid = false;   // (the staging buffer a host-array fit would re-use is overwritten)
         JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * (size_t)n * p));
         JCH_TRY(h2d_matrix(ctx, (double *)ctx->xstage.ptr, X, n, p, ldx));
         dX = (const double *)ctx->xstage.ptr; ldxd = n;

@@ -14,6 +14,10 @@
 #define JCH_ZT_SLICES 8      // max second-stage partial slices of the sweep reduction
 #define JCH_SWEEP_MAXP 2048  // widest row the register-resident fused sweep holds (16 column chunks of 128)
 
+struct xcopy_key {
+    const void *X; int64_t n, ldx; int p, host;
+    bool operator==(const xcopy_key &o) const { return X == o.X && n == o.n && ldx == o.ldx && p == o.p && host == o.host; }
+};
 struct jch_buf {  // grow-only device buffer
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -60,6 +64,10 @@ struct jch_ctx {
     // workspace (grow-only)
     void *hstage = nullptr;          // pinned host staging for the small outputs (grow-only)
     size_t hstage_bytes = 0;
+    // the raw row-major working copy a plskern-shaped fit left in `xr` (JCH_REUSE_XCOPY): which X it is a copy of
+    xcopy_key xcopy{};
+    bool xcopy_valid = false;
+    long long xcopy_reused = 0;   // fits that took their kernel matrix from it
     unsigned sweep_seq = 0;   // launches of the plskern-shaped sweep so far (JCH_SWEEP_ALT: alternating walk direction)
     jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz, lw_work, lw_xrm, lvws, lw_flags, lw_screen;
     // profiling
@@ -165,6 +173,9 @@ int32_t jch_launch_sweep(jch_ctx *ctx, const double *Xr, int64_t n, int p, int l
                          int *nslice_out, const double *mu = nullptr /*raw mode: Xr is uncentred; t = x.r - mu.r, st at [ldr+1]*/,
                          jch_part_view *pv = nullptr /*non-null: the launcher MAY leave the block partials unreduced and describe them here (pv->part stays null when it reduced into zt as usual)*/);
 int32_t jch_launch_reduce_rows(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *out);
+int32_t jch_launch_xty_rows(jch_ctx *ctx, const double *Xr, int ldr, const double *Yc, int64_t ldy, const double *d, int64_t n, int p, int q,
+                            const double *mom, double *Yr, int qpad, double *K, double *means_out, double *mshift_out,
+                            const double *spread2, double *qual, double *ones_out, bool *done);
 int32_t jch_launch_raw_scales(jch_ctx *ctx, const double *Xr, int64_t n, int p, int ldr, const double *d, const double *mshift,
                               const double *Yr, int qpad, int q, double *tmp, double *scl, double *K);
 int32_t jch_launch_reduce_part8(jch_ctx *ctx, const double *part, int nb, int ldpart, int m, double *zt, int ldz, int *nslice_out);

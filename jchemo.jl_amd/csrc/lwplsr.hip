@@ -744,6 +744,7 @@ static int32_t launch_locw_q(jch_ctx *ctx, locw_args &g)
     const char *e_bpc = getenv("JCH_LOCW_BPC");   // (measurement knob) blocks per CU of the local-fit kernel
     int nb = std::min(g.m, ctx->cus * ((e_bpc && atoi(e_bpc) > 0) ? atoi(e_bpc) : 2));
     g.slab = ((size_t)g.k * g.ldr + 2 * (size_t)g.nlv_hi * g.ldr + 31) & ~(size_t)31;
+    if (ctx->xcopy.host) ctx->xcopy_valid = false;   // (the staging buffer of a host-array fit is re-used for the slabs)
     JCH_TRY(jch_reserve(ctx, ctx->xstage, sizeof(double) * g.slab * nb));
     g.scratch = (double *)ctx->xstage.ptr;
     hipLaunchKernelGGL((k_locw_plskern<KC, Q>), dim3(nb), dim3(256), lds, ctx->stream, g);
@@ -1282,6 +1283,7 @@ extern "C" int32_t jch_weighted_cov(jch_ctx *ctx, int32_t loc, const double *A, 
         }
     }
     JCH_TRY(jch_reserve(ctx, ctx->dnorm, sizeof(double) * (size_t)n));
+    ctx->xcopy_valid = false;   // (the fit workspace's row-major copy is overwritten here)
     JCH_TRY(jch_reserve(ctx, ctx->xr, sizeof(double) * (size_t)n * ldr));
     if (d > JCH_MAXQ) {
         // wide A (round 4; the Mahalanobis branch of getknn on raw spectra, nlvdis = 0: src/getknn.jl:37-49, src/lwplsr.jl:21): the

@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "jch_internal.h"
+#include "rowsum_dev.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
@@ -602,6 +603,135 @@ int32_t jch_launch_pivot(jch_ctx *ctx, const double *Xc, int64_t ldx, int64_t n,
     JCH_HIP(ctx, hipGetLastError());
     JCH_TRY(jch_allreduce_f64(ctx, pivot, (size_t)p));
     return jch_allreduce_f64(ctx, spread2, (size_t)p);
+}
+
+// K2r (round 4, second half) — the raw-mode prologue WITHOUT the copy: when the caller promises that X has not changed since the
+// previous fit on this ctx (desc->reserved & JCH_REUSE_XCOPY: the folds of a cross-validation, the combinations of a parameter
+// grid — same X, other weights / Y), the row-major working copy x - pivot of that fit is still in the workspace, and all a new fit
+// needs from X before its first sweep is X'D[Yc | 1] (src/plskern.jl:131 + the weighted column sums, i.e. the means, :119).  One
+// streaming READ of the copy, rows as the sweep reads them (a row per wave-instruction quartet, lane l owns the column pairs
+// 2 l + 128 k), instead of a read of X plus a write of the copy: 4 GB at the sweep's rate instead of 8.2 GB at the transposing
+// kernel's.  Per row the q + 1 coefficients d_i yc_ik (and d_i for the ones column) are wave-uniform: four rows x 16 columns of
+// [Yc | 1] are ONE 64-lane load, a v_readlane pair turns an entry into a scalar operand, and the products are plain FMAs into
+// (q + 1) accumulators per owned column.  Partial matrices per block in k_center_xty_panel's layout: the same reduction follows.
+typedef double v2f64r __attribute__((ext_vector_type(2)));
+template <int KC, int NQ>   // KC 128-column chunks per row (ldr <= 128 KC), NQ >= q + 1 coefficient columns
+__global__ __launch_bounds__(256) void k_xty_rows(const double *__restrict__ Xr, int64_t n, int ldr, const double *__restrict__ Yc, int64_t ldy,
+                                                  const double *__restrict__ d, int q, const double *__restrict__ ymeans, int ones_col,
+                                                  double *__restrict__ Yr, double *__restrict__ Kpart, int kp_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) double xr_red[];   // [4][KC * 128]
+    constexpr int R = 4, NBUF = 3;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int coff[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { const int col = 2 * lane + 128 * k; coff[k] = col < ldr ? col : ldr - 2; }
+    v2f64r acc[KC][NQ];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) acc[k][c] = v2f64r{0.0, 0.0};
+    const int64_t ngroups = (n + R - 1) / R, gstride = (int64_t)gridDim.x * 4;
+    const int yk = lane & 15, yr = lane >> 4;                 // this lane's entry of the 4 x 16 block of [Yc | 1]
+    const double ym = yk < q ? ymeans[yk] : 0.0;
+    v2f64r X[NBUF][R][KC];
+    double Yv[NBUF], Dv[NBUF];
+    auto fetch = [&](int b, int64_t gg) {
+        const int64_t r0 = gg * R;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int64_t row = r0 + rr < n ? r0 + rr : n - 1;
+            const double *rp = Xr + (size_t)row * (size_t)ldr;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) X[b][rr][k] = __builtin_nontemporal_load(reinterpret_cast<const v2f64r *>(rp + coff[k]));
+        }
+        const int64_t myrow = r0 + yr < n ? r0 + yr : n - 1;
+        Yv[b] = Yc[(size_t)myrow + (size_t)min(yk, q - 1) * (size_t)ldy];
+        Dv[b] = d[myrow];
+    };
+    int64_t g = (int64_t)blockIdx.x * 4 + wv;
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (g + b * gstride < ngroups) fetch(b, g + b * gstride);
+    auto process = [&](int b, int64_t gg) {
+        const int64_t r0 = gg * R;
+        const bool live = r0 + yr < n;
+        const double yc = (live && yk < q) ? Yv[b] - ym : 0.0;
+        const double dv = live ? Dv[b] : 0.0;
+        if (live) Yr[(size_t)(r0 + yr) * 16 + yk] = yc;       // the centred responses, row-major (one 512-byte run per instruction)
+        const double bv = yk == ones_col ? dv : dv * yc;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                const double bc = jch_readlane(bv, 16 * rr + c);   // wave-uniform
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { acc[k][c].x += X[b][rr][k].x * bc; acc[k][c].y += X[b][rr][k].y * bc; }
+            }
+        }
+    };
+    while (g < ngroups) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            if (g < ngroups) {
+                const int64_t ahead = g + (NBUF - 1) * gstride;
+                if (ahead < ngroups) fetch((b + NBUF - 1) % NBUF, ahead);
+                process(b, g);
+                g += gstride;
+            }
+        }
+    }
+    // the block's four waves in wave order, one coefficient column at a time; columns past the row end are not stored (coff clamps
+    // them onto the last pair, which its own lane stores)
+    double *kp = Kpart + (size_t)blockIdx.x * kp_rows * 16;
+#pragma unroll 1
+    for (int c = 0; c < 16; ++c) {
+        if (c < NQ) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                v2f64r v = acc[k][0];
+#pragma unroll
+                for (int cc = 1; cc < NQ; ++cc) v = c == cc ? acc[k][cc] : v;
+                *reinterpret_cast<v2f64r *>(xr_red + wv * (KC * 128) + 2 * lane + 128 * k) = v;
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kp_rows; j += 256) {
+            double t = 0.0;
+            if (c < NQ && j < ldr) t = ((xr_red[j] + xr_red[KC * 128 + j]) + xr_red[2 * KC * 128 + j]) + xr_red[3 * KC * 128 + j];
+            kp[(size_t)j * 16 + c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// the raw-mode prologue from the workspace's row-major copy (see k_xty_rows); same outputs as jch_launch_center_xty in raw mode.
+// False in *done when the shape is outside this kernel (the caller then runs the full prologue).
+int32_t jch_launch_xty_rows(jch_ctx *ctx, const double *Xr, int ldr, const double *Yc, int64_t ldy, const double *d, int64_t n, int p, int q,
+                            const double *mom, double *Yr, int qpad, double *K, double *means_out, double *mshift_out,
+                            const double *spread2, double *qual, double *ones_out, bool *done)
+{
+    *done = false;
+    if (qpad != 16 || q + 1 > 12 || ldr > 512 || ldr < 2 || !means_out) return JCH_OK;
+    const int ones_col = q;
+    const int kc = (ldr + 127) / 128, kp_rows = 512;
+    const int64_t ngroups = (n + 3) / 4;
+    const int nbx = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, ctx->cus));
+    JCH_TRY(jch_reserve(ctx, ctx->kpart, sizeof(double) * (size_t)nbx * kp_rows * 16));
+    double *Kpart = (double *)ctx->kpart.ptr;
+    const int nq = q + 1 <= 4 ? 4 : (q + 1 <= 8 ? 8 : 12);
+#define JCH_XR(KC, NQ) hipLaunchKernelGGL((k_xty_rows<KC, NQ>), dim3(nbx), dim3(256), sizeof(double) * 4 * KC * 128, ctx->stream, Xr, n, ldr, Yc, ldy, d, q, \
+                                          mom + p, ones_col, Yr, Kpart, kp_rows)
+#define JCH_XR_NQ(KC) do { if (nq == 4) JCH_XR(KC, 4); else if (nq == 8) JCH_XR(KC, 8); else JCH_XR(KC, 12); } while (0)
+    if (kc == 1) JCH_XR_NQ(1); else if (kc == 2) JCH_XR_NQ(2); else if (kc == 3) JCH_XR_NQ(3); else JCH_XR_NQ(4);
+#undef JCH_XR_NQ
+#undef JCH_XR
+    hipLaunchKernelGGL(k_reduce_kpart_wide, dim3((p * 16 + 63) / 64), dim3(256), 0, ctx->stream, Kpart, nbx, kp_rows, p, 16, K);
+    JCH_TRY(jch_allreduce_f64(ctx, K, (size_t)p * qpad));
+    hipLaunchKernelGGL(k_extract_means, dim3((p + q + 255) / 256), dim3(256), 0, ctx->stream, K, qpad, p, ones_col, mom, means_out, mshift_out, spread2, qual, q, ones_out);
+    JCH_HIP(ctx, hipGetLastError());
+    *done = true;
+    return JCH_OK;
 }
 
 int32_t jch_launch_center_xty(jch_ctx *ctx, double *Xc, int64_t ldx, double *Yc, int64_t ldy, const double *d, int64_t n,

@@ -190,16 +190,22 @@ def _fit(entry: str, X, Y, weights, nlv: int, scal: bool, inplace: bool, ctx: Op
                 None if niter is None else niter[:k])
 
 
-def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, variant: int = 0) -> Plsr:
+REUSE_XCOPY = 8                # include/jchemo_hip.h JCH_REUSE_XCOPY
+
+
+def plskern(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, variant: int = 0, reuse_x: bool = False) -> Plsr:
     """`plskern(X, Y, weights = ones(n); nlv, scal = false)` — src/plskern.jl:106-110.  X, Y untouched
     (the reference copies them first; here the library simply never writes them).
-    `variant=1` (not in the reference) opts into kernel algorithm #2: X'DX once, no pass over X in the LV loop."""
+    `variant=1` (not in the reference) opts into kernel algorithm #2: X'DX once, no pass over X in the LV loop.
+    `reuse_x=True`: the caller's promise that X is the array (pointer AND contents) the previous fit on this ctx was given — a
+    cross-validation fold, a grid combination; the library then takes X'DY from the row-major copy that fit left behind instead
+    of staging and transposing X again (JCH_REUSE_XCOPY; ignored wherever it does not apply)."""
     X = ensure_mat(X); Y = ensure_mat(Y)
     try:
         _addr_ld(X, allow_bf16=True); _addr_ld(Y, allow_bf16=True)   # bf16 tensors: storage mode of BASELINE configs[2]
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)   # layout/dtype conversion only
-    return _fit("jch_plskern_fit", X, Y, weights, nlv, scal, False, ctx, variant)
+    return _fit("jch_plskern_fit", X, Y, weights, nlv, scal, False, ctx, variant | (REUSE_XCOPY if reuse_x else 0))
 
 
 def plskern_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
@@ -211,7 +217,7 @@ def plskern_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[
 NIPALS_ONE_PASS = 4            # include/jchemo_hip.h JCH_NIPALS_ONE_PASS
 
 
-def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, one_pass: bool = False) -> Plsr:
+def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, one_pass: bool = False, reuse_x: bool = False) -> Plsr:
     """`plsnipals` — src/plsnipals.jl:31-35.
     `one_pass=True` (not in the reference, never the default) opts into ONE pass over X per LV: the next X'DY follows from the exact
     identity K_{a+1} = K_a - zp_raw c_raw' / tt instead of being recomputed from the deflated matrices (src/plsnipals.jl:71); same
@@ -221,7 +227,7 @@ def plsnipals(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional
         _addr_ld(X, allow_bf16=True); _addr_ld(Y, allow_bf16=True)
     except (ValueError, TypeError):
         X, Y = _as_colmajor_copy(X), _as_colmajor_copy(Y)
-    return _fit("jch_plsnipals_fit", X, Y, weights, nlv, scal, False, ctx, NIPALS_ONE_PASS if one_pass else 0)
+    return _fit("jch_plsnipals_fit", X, Y, weights, nlv, scal, False, ctx, (NIPALS_ONE_PASS if one_pass else 0) | (REUSE_XCOPY if reuse_x else 0))
 
 
 def plsnipals_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
@@ -238,9 +244,9 @@ def _copy_fit(entry, X, Y, weights, nlv, scal, ctx, wold=None, variant=0):
     return _fit(entry, X, Y, weights, nlv, scal, False, ctx, wold=wold, variant=variant)
 
 
-def plssimp(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
-    """`plssimp` — src/plssimp.jl:22-26 (SIMPLS, scores not normed; `W` is returned equal to `R`, :85-87)."""
-    return _copy_fit("jch_plssimp_fit", X, Y, weights, nlv, scal, ctx)
+def plssimp(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, reuse_x: bool = False) -> Plsr:
+    """`plssimp` — src/plssimp.jl:22-26 (SIMPLS, scores not normed; `W` is returned equal to `R`, :85-87).  `reuse_x`: see plskern."""
+    return _copy_fit("jch_plssimp_fit", X, Y, weights, nlv, scal, ctx, variant=REUSE_XCOPY if reuse_x else 0)
 
 
 def plssimp_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
@@ -248,9 +254,9 @@ def plssimp_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[
     return _fit("jch_plssimp_fit", _as_colmajor_view(X), _as_colmajor_view(Y), weights, nlv, scal, True, ctx)
 
 
-def plsrosa(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
-    """`plsrosa` — src/plsrosa.jl:26-30."""
-    return _copy_fit("jch_plsrosa_fit", X, Y, weights, nlv, scal, ctx)
+def plsrosa(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None, reuse_x: bool = False) -> Plsr:
+    """`plsrosa` — src/plsrosa.jl:26-30.  `reuse_x`: see plskern."""
+    return _copy_fit("jch_plsrosa_fit", X, Y, weights, nlv, scal, ctx, variant=REUSE_XCOPY if reuse_x else 0)
 
 
 def plsrosa_(X, Y, weights=None, *, nlv: int, scal: bool = False, ctx: Optional[Context] = None) -> Plsr:
@@ -265,12 +271,12 @@ WOLD_REF_ZERO_WEIGHT_NAN = 2   # include/jchemo_hip.h JCH_WOLD_REF_ZERO_WEIGHT_N
 
 
 def plswold(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,
-            zero_weight_nan: bool = False, ctx: Optional[Context] = None, one_pass: bool = False) -> Plsr:
+            zero_weight_nan: bool = False, ctx: Optional[Context] = None, one_pass: bool = False, reuse_x: bool = False) -> Plsr:
     """`plswold` — src/plswold.jl:30-34; `niter` (inner passes per LV) as :93.  `zero_weight_nan = True` reproduces the
     reference's NaN scores for rows whose weight is 0 (:107); the default keeps them finite (t_i = x_i' r), which is what
     lets a cross-validation fold be ONE weighted fit (gridcvlv)."""
     return _copy_fit("jch_plswold_fit", X, Y, weights, nlv, scal, ctx, wold=(tol, maxit),
-                     variant=(WOLD_REF_ZERO_WEIGHT_NAN if zero_weight_nan else 0) | (NIPALS_ONE_PASS if one_pass else 0))   # one_pass: see plsnipals
+                     variant=(WOLD_REF_ZERO_WEIGHT_NAN if zero_weight_nan else 0) | (NIPALS_ONE_PASS if one_pass else 0) | (REUSE_XCOPY if reuse_x else 0))   # one_pass: see plsnipals
 
 
 def plswold_(X, Y, weights=None, *, nlv: int, tol: float = _SQRT_EPS, maxit: int = 200, scal: bool = False,
@@ -979,6 +985,10 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, verbose: bool = False, c
     rng = _nlv_range(nlv, p)
     combos = _pars_rows(pars)
     rep_out = []
+    # every fit of this call sees the SAME X (only the weights change): from the second one on the library is told so and takes X'DY
+    # from the row-major copy the previous fit left in its workspace (JCH_REUSE_XCOPY) instead of staging / transposing X again
+    ctx = ctx or default_context((X.device.index or 0) if dev else 0)
+    same_x = False
     for irep, listsegm in enumerate(segm):
         if verbose:                                     # src/gridcv.jl:197,202,226
             print(f"/ repl={irep + 1} ", end="")
@@ -997,7 +1007,8 @@ def gridcvlv(X, Y, *, segm, score, fun, nlv, pars=None, verbose: bool = False, c
             kfit = min(max(rng), n - len(s))                                   # the reference clamps with the TRAINING rows
             blocks = []
             for kw in combos:
-                fm = fun(X, Y, w, nlv=kfit, ctx=ctx, **kwargs, **kw)
+                fm = fun(X, Y, w, nlv=kfit, ctx=ctx, reuse_x=same_x, **kwargs, **kw)
+                same_x = True
                 # pred_a = ymeans + sum_{l < min(a, k)} T_l (C_l .* yscales)' on the held-out rows: running sums over the score
                 # columns inside jch_score_sums_lv — the n x (levels q) prediction matrix is never formed
                 blocks.append(_score_from_sums(name, _score_sums_lv(fm.T, fm, Y, held, rng, ctx)))

@@ -657,6 +657,94 @@ def test_score_sums_from_the_scores_equal_those_of_the_predictions(case, residen
         assert np.allclose(got, ref, rtol=1e-10, atol=1e-9 * np.abs(ref).max()), np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("shape", [dict(n=3000, p=500, q=10), dict(n=1501, p=37, q=1), dict(n=2200, p=130, q=3), dict(n=900, p=257, q=11),
+                                   dict(n=5000, p=384, q=4), dict(n=700, p=512, q=7)])
+@pytest.mark.parametrize("resident", [False, True])
+def test_fit_from_the_previous_fits_row_major_copy(shape, resident, J, monkeypatch):
+    """JCH_REUSE_XCOPY (`reuse_x=True`; round 4): a fit that is promised the SAME X as the previous fit on its ctx takes X'D[Yc | 1]
+    from the row-major copy that fit left in the workspace (prologue.hip k_xty_rows) — other weights, other Y, scaling on or off,
+    plskern / plsrosa / plssimp — and equals the fit that goes through the whole prologue (JCH_NO_REUSE_XCOPY=1) to rounding.
+    The bit is IGNORED (counter unchanged, results right) when the previous fit was on another X, when a fit in between
+    replaced the copy (plsnipals deflates it), after a call that re-used the staging buffers, and for q + 1 > 12."""
+    import torch
+    from jchemo_hip import _lib
+    n, p, q = (shape[k] for k in ("n", "p", "q"))
+    nlv = min(6, p)
+    ctx = J.Context(0)
+    X = CO.fill_uniform(431, n, p) + 2.0
+    Y = X @ (CO.fill_uniform(432, p, q) - 0.5) + 0.1 * CO.fill_uniform(433, n, q)
+    Y2 = Y[:, ::-1].copy() + 0.05 * CO.fill_uniform(434, n, q)
+    w1 = CO.fill_uniform(435, n, 1)[:, 0] + 0.1
+    w2 = (CO.fill_uniform(436, n, 1)[:, 0] > 0.2).astype(np.float64)           # a cross-validation fold: 0 / 1 weights
+    if resident:
+        dv = lambda a: (lambda t: (t.copy_(torch.from_numpy(np.asfortranarray(a))), t)[1])(J.colmajor_empty(a.shape[0], a.shape[1]))
+        Xi, Yi, Y2i = dv(X), dv(Y), dv(Y2)
+        w1i, w2i = torch.from_numpy(w1).cuda(), torch.from_numpy(w2).cuda()
+    else:
+        Xi, Yi, Y2i, w1i, w2i = np.asfortranarray(X), np.asfortranarray(Y), np.asfortranarray(Y2), w1, w2
+    host = lambda v: v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+    reused = lambda: ctx.counter(4)                                             # JCH_COUNTER_XCOPY_REUSED
+
+    def same(a, b, tol=1e-10):
+        s = O.sign_align(host(a.W), host(b.W))
+        for f in FIELDS:
+            assert O.rel_fro(host(getattr(a, f)), host(getattr(b, f)) * s) < tol, f
+        assert O.rel_fro(a.xmeans, b.xmeans) < 1e-13 and O.rel_fro(a.ymeans, b.ymeans) < 1e-13
+
+    J.plskern(Xi, Yi, w1i, nlv=nlv, ctx=ctx)                                    # leaves the copy
+    c0 = reused()
+    for fn, kw in ((J.plskern, dict(scal=False)), (J.plskern, dict(scal=True)), (J.plsrosa, dict(scal=False)), (J.plssimp, dict(scal=True))):
+        a = fn(Xi, Y2i, w2i, nlv=nlv, ctx=ctx, reuse_x=True, **kw)
+        assert reused() == c0 + 1, "the copy was not used"
+        c0 += 1
+        monkeypatch.setenv("JCH_NO_REUSE_XCOPY", "1")
+        b = fn(Xi, Y2i, w2i, nlv=nlv, ctx=ctx, reuse_x=True, **kw)
+        monkeypatch.delenv("JCH_NO_REUSE_XCOPY")
+        assert reused() == c0
+        same(a, b)
+        ref = getattr(O, fn.__name__)(X, Y2, w2, nlv=nlv, **kw)
+        s = O.sign_align(ref.W, host(a.W))
+        for f in FIELDS:
+            assert O.rel_fro(getattr(ref, f), host(getattr(a, f)) * s) < 1e-8, (fn.__name__, f)
+    # another X (same shape): the promise is false for the workspace, the bit must be ignored
+    X3 = X[::-1].copy()
+    X3i = dv(X3) if resident else np.asfortranarray(X3)
+    a = J.plskern(X3i, Yi, w1i, nlv=nlv, ctx=ctx, reuse_x=True)
+    assert reused() == c0
+    same(a, J.plskern(X3i, Yi, w1i, nlv=nlv, ctx=J.Context(0)))
+    # a fit that replaces the copy by its deflated rows in between
+    J.plskern(Xi, Yi, w1i, nlv=nlv, ctx=ctx)
+    J.plsnipals(Xi, Yi, w1i, nlv=nlv, ctx=ctx, reuse_x=True)
+    a = J.plskern(Xi, Y2i, w2i, nlv=nlv, ctx=ctx, reuse_x=True)
+    assert reused() == c0
+    same(a, J.plskern(Xi, Y2i, w2i, nlv=nlv, ctx=J.Context(0)))
+    # a call that re-uses the staging buffer of X in between (column statistics of other host rows: jch_col_stats)
+    from jchemo_hip import plsr as PL
+    J.plskern(Xi, Yi, w1i, nlv=nlv, ctx=ctx)
+    J.plskern(Xi, Yi, w1i, nlv=nlv, ctx=ctx, reuse_x=True)
+    c0 += 1
+    assert reused() == c0
+    PL._col_stats(np.asfortranarray(X3), None, True, ctx)
+    a = J.plskern(Xi, Y2i, w2i, nlv=nlv, ctx=ctx, reuse_x=True)
+    assert reused() == (c0 + 1 if resident else c0)       # (device-resident X has no staging copy to lose)
+    same(a, J.plskern(Xi, Y2i, w2i, nlv=nlv, ctx=J.Context(0)))
+    ctx.close()
+
+
+def test_fit_from_the_copy_is_refused_for_many_responses(J):
+    """q + 1 > 12: the copy-reading kernel has no instantiation, the whole prologue runs (and the result is right)."""
+    n, p, q = 1500, 200, 12
+    ctx = J.Context(0)
+    X = np.asfortranarray(CO.fill_uniform(441, n, p)); Y = np.asfortranarray(X @ (CO.fill_uniform(442, p, q) - 0.5))
+    J.plskern(X, Y, nlv=4, ctx=ctx)
+    a = J.plskern(X, Y, nlv=4, ctx=ctx, reuse_x=True)
+    assert ctx.counter(4) == 0
+    ref = O.plskern(X, Y, nlv=4)
+    s = O.sign_align(ref.W, a.W)
+    assert O.rel_fro(ref.T, a.T * s) < 1e-8
+    ctx.close()
+
+
 def test_scores_and_gridscorelv(J, ctx):
     """§8f rank 1: scores from device-side sums and gridscorelv == the oracle (src/scores.jl, src/gridscore.jl:167-221)."""
     n, p, q, m = 3000, 40, 3, 700
