@@ -223,13 +223,13 @@ _in(X) = _f64(ensure_mat(X))
 
 "`plskern(X, Y, weights = ones(n); nlv, scal = false)` — src/plskern.jl:106-110 (inputs untouched)."
 plskern(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
-    _fit(:plskern, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx)
+    _fit(:plskern, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; options = _same_x[])
 "`plskern!(X::Matrix, Y::Matrix, ...)` — src/plskern.jl:112-178: X, Y are overwritten (centred/scaled)."
 plskern!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plskern, X, Y, _w(weights, X), nlv, scal, true, ctx)
 "`plsnipals` — src/plsnipals.jl:31-35."
 plsnipals(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
-    _fit(:plsnipals, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; options = _nipals_options[])
+    _fit(:plsnipals, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; options = _nipals_options[] | _same_x[])
 "`plsnipals!` — src/plsnipals.jl:37-97: X, Y end up centred/scaled and deflated."
 plsnipals!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plsnipals, X, Y, _w(weights, X), nlv, scal, true, ctx)
@@ -237,19 +237,19 @@ plsnipals!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
 # Sibling algorithms (same row kernels, different small state; include/jchemo_hip.h)
 "`plssimp` — src/plssimp.jl:22-26 (`W` is returned equal to `R`, :85-87)."
 plssimp(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
-    _fit(:plssimp, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx)
+    _fit(:plssimp, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; options = _same_x[])
 "`plssimp!` — src/plssimp.jl:28-88."
 plssimp!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plssimp, X, Y, _w(weights, X), nlv, scal, true, ctx)
 "`plsrosa` — src/plsrosa.jl:26-30."
 plsrosa(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
-    _fit(:plsrosa, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx)
+    _fit(:plsrosa, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; options = _same_x[])
 "`plsrosa!` — src/plsrosa.jl:32-96: X centred/scaled, Y centred/scaled and deflated."
 plsrosa!(X, Y, weights = nothing; nlv, scal = false, ctx = default_ctx()) =
     _fit(:plsrosa, X, Y, _w(weights, X), nlv, scal, true, ctx)
 "`plswold` — src/plswold.jl:30-34; `niter` filled as :93."
 plswold(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
-    _fit(:plswold, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; tol = tol, maxit = maxit, options = _wold_options[] | _nipals_options[])
+    _fit(:plswold, _in(X), _in(Y), _w(weights, _in(X)), nlv, scal, false, ctx; tol = tol, maxit = maxit, options = _wold_options[] | _nipals_options[] | _same_x[])
 "`plswold!` — src/plswold.jl:36-111."
 plswold!(X, Y, weights = nothing; nlv, tol = sqrt(eps(1.)), maxit = 200, scal = false, ctx = default_ctx()) =
     _fit(:plswold, X, Y, _w(weights, X), nlv, scal, true, ctx; tol = tol, maxit = maxit, options = _wold_options[])
@@ -266,6 +266,11 @@ wold_zero_weight_nan!(on::Bool) = (_wold_options[] = on ? Int32(2) : Int32(0); o
 const _nipals_options = Ref{Int32}(0)
 "`nipals_one_pass!(true)`: `plsnipals` / `plswold` use the one-pass variant (q <= 16, p <= 2048); `false` (default): the reference's schedule."
 nipals_one_pass!(on::Bool) = (_nipals_options[] = on ? Int32(4) : Int32(0); on)
+
+# JCH_REUSE_XCOPY (include/jchemo_hip.h): the promise that X — pointer and contents — is what the previous fit on this ctx was given; a
+# Float64 plskern-shaped fit then takes X'DY from the row-major copy that fit left in the workspace instead of staging and transposing
+# X again.  Set by `gridcvlv` around its second and later fits (the same X, other weights); a module switch like the two above.
+const _same_x = Ref{Int32}(0)
 
 # out = ((X - 1*shift') ./ scale') * B .+ bias'   (shift, scale, B, bias on the host; X and out where X lives)
 function _affine(X, shift, scale, B::Matrix{Float64}, bias, ctx)
@@ -677,6 +682,7 @@ function gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false, 
     pars === nothing || !(:nlv in keys(pars)) || error("Argument `pars` must not contain `nlv`")
     X = _in(X); Y = _colocate_mat(_in(Y), X); n, p = size(X); q = size(Y, 2)
     rng = _nlv_range(nlv, p)
+    _same_x[] = Int32(0)                                   # the FIRST fit of the call makes no promise about the workspace
     res_rep = Vector{Vector{Matrix{Float64}}}()
     for (i, listsegm) in enumerate(segm)
         verbose && print("/ repl=", i, " ")
@@ -688,7 +694,8 @@ function gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false, 
             kfit = min(maximum(rng), n - length(s))                # the reference clamps with the TRAINING rows
             blocks = Matrix{Float64}[]
             for kw in _pars_rows(pars)
-                fm = fun(X, Y, w; nlv = kfit, kw...)
+                fm = try fun(X, Y, w; nlv = kfit, kw...) catch; _same_x[] = Int32(0); rethrow() end
+                _same_x[] = Int32(8)                       # every later fit of this call sees the same X (JCH_REUSE_XCOPY)
                 # pred_a = ymeans + sum_{l <= min(a, k)} T_l (C_l .* yscales)' on the held-out rows, level by level inside the library
                 push!(blocks, _score_from_sums(score.name, _score_sums_lv(fm.T, fm, Y, held, rng, ctx)))
             end
@@ -696,6 +703,7 @@ function gridcvlv(X, Y; segm, score, fun, nlv, pars = nothing, verbose = false, 
         end
         push!(res_rep, zres)
     end
+    _same_x[] = Int32(0)
     verbose && println("/ End.")
     # res_rep: per replication the segments' tables stacked, behind the columns repl, segm (src/gridcv.jl:211-222)
     per = length(rng) * length(_pars_rows(pars))                    # rows per fold
