@@ -177,7 +177,7 @@ def _roof(bytes_per_launch, kernel_ms_total, launches, kernel, note=None):
     return r
 
 
-def secondary_fit(J, _lib, lib, ctx, dev, *, label, algo, n, p, q, nlv, bf16, steps, warmup):
+def secondary_fit(J, _lib, lib, ctx, dev, *, label, algo, n, p, q, nlv, bf16, steps, warmup, reserved=0):
     """One of BASELINE.json's OTHER configs on this GPU (device-resident synthetic inputs, same generator and the same C-ABI
     entry points as the headline; run after — never inside — the headline's timed region).  value = LV/s over `steps` fits."""
     X = J.colmajor_empty(n, p, dev); Y = J.colmajor_empty(n, q, dev)
@@ -193,7 +193,7 @@ def secondary_fit(J, _lib, lib, ctx, dev, *, label, algo, n, p, q, nlv, bf16, st
     P = np.zeros((p, kmax), order="F"); R = np.zeros((p, kmax), order="F"); W = np.zeros((p, kmax), order="F")
     Cm = np.zeros((q, kmax), order="F"); TT = np.zeros(kmax)
     xm = np.empty(p); xs = np.empty(p); ym = np.empty(q); ys = np.empty(q)
-    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0, reserved=0)
+    desc = _lib.PlsDesc(n=n, p=p, q=q, nlv=nlv, scal=0, dtype=_lib.BF16 if bf16 else _lib.F64, loc=_lib.LOC_DEVICE, inplace=0, reserved=reserved)
     got = C.c_int32(0)
     entry = lib.jch_plsnipals_fit if algo == "plsnipals" else lib.jch_plskern_fit
 
@@ -212,10 +212,12 @@ def secondary_fit(J, _lib, lib, ctx, dev, *, label, algo, n, p, q, nlv, bf16, st
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     k = got.value
     assert np.all(np.isfinite(TT[:k])) and np.all(TT[:k] > 0), "secondary fit produced non-finite / non-positive t't"
-    kernel = ("k_sweep_lazy + k_kpass_lazy (per LV: two reads of X, rows rewritten every 6th LV; bytes_per_launch = bytes actually moved per LV)"
+    kernel = ("k_sweep_lazy + a sixth of k_kpass_lazy (OPT-IN one-pass variant: ONE read of X per LV, rows rewritten every 6th LV; bytes_per_launch = bytes actually moved per LV)"
+              if (algo == "plsnipals" and reserved == 4) else
+              "k_sweep_lazy + k_kpass_lazy (per LV: two reads of X, rows rewritten every 6th LV; bytes_per_launch = bytes actually moved per LV)"
               if algo == "plsnipals" else "k_sweep_bf16_v2 (fused sweep over the bf16 row-major copy)" if bf16 else "k_sweep")
     roof = _roof(sb, sw, nl, kernel)
-    roof["traffic"] = pmc_config_traffic("bf16_share", n=n, p=p) if bf16 else (pmc_config_traffic("cfg4_plsnipals", n=n, p=p) if algo == "plsnipals" else None)
+    roof["traffic"] = pmc_config_traffic("bf16_share", n=n, p=p) if bf16 else (pmc_config_traffic("cfg4_plsnipals", n=n, p=p) if (algo == "plsnipals" and not reserved) else None)
     roof["traffic_source"] = PMC_FILE + ": committed rocprofv3 --pmc passes of this configuration's kernels (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); NOT measured in this run"
     out = {"config": label, "metric": "latent-variables/sec", "value": k * steps / dt, "unit": "LV/s", "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "dtype": "bf16 storage / f32 rows / f64 state" if bf16 else "f64",
@@ -637,7 +639,11 @@ def main():
                                                   n=1_000_000, p=2000, q=1, nlv=50, bf16=False, steps=2, warmup=1)),
                              (secondary_fit, dict(label="plskern n=1000000 p=500 q=10 nlv=25 bf16-stored: the one-GPU share of BASELINE.json configs[2] (n=8e6 over 8 GPUs)",
                                                   algo="plskern", n=1_000_000, p=500, q=10, nlv=25, bf16=True, steps=5, warmup=2)),
-                             (secondary_lwplsr, dict(calls=20))):
+                             (secondary_lwplsr, dict(calls=20)),
+                             # last, so that the indices of the three BASELINE configs above stay what earlier rounds' records use
+                             (secondary_fit, dict(label="OPT-IN (JCH_NIPALS_ONE_PASS; never the default, not the reference's schedule: K updated by the exact identity "
+                                                        "K_{a+1} = K_a - zp_raw c_raw'/tt instead of a second pass over X) plsnipals n=1000000 p=2000 q=1 nlv=50 Float64",
+                                                  algo="plsnipals", n=1_000_000, p=2000, q=1, nlv=50, bf16=False, steps=2, warmup=1, reserved=4))):
                 try:
                     others.append(fn_(J, _lib, lib, ctx, dev, **kw_) if fn_ is secondary_fit else fn_(J, lib, ctx, dev, **kw_))
                 except Exception as e:  # noqa: BLE001   (never take the headline down)
