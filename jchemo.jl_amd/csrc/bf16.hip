@@ -1094,7 +1094,8 @@ static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n,
     const int64_t ngroups = (n + R - 1) / R;
     const char *eb = getenv("JCH_BF16_BPC");
     const int use_bpc = (eb && atoi(eb) > 0) ? atoi(eb) : bpc;
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * use_bpc));
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx->cus * use_bpc));
+    if (const char *e_nb = getenv("JCH_SWEEP_NB")) { const int v = atoi(e_nb); if (v > 0 && v < nb) nb = v; }   // (A/B runs: the grid)
     const int m = ldr_b + 2, ldpart = (m + 7) & ~7;
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->part.ptr;

@@ -49,6 +49,8 @@ extern "C" int32_t jch_ctx_create(jch_ctx **out, int32_t device_id, void *stream
     if (!ctx) return jch_fail(nullptr, JCH_ENOMEM, "jch_ctx_create: host allocation failed");
     ctx->device = device_id;
     ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // JCH_CUS=<count> (measurement knob, A/B runs): size every persistent grid as if the device had this many CUs
+    if (const char *e_cus = getenv("JCH_CUS")) { const int v = atoi(e_cus); if (v >= 8 && v <= ctx->cus) ctx->cus = v; }
     e = hipSetDevice(device_id);
     if (e == hipSuccess) {
         if (stream) {

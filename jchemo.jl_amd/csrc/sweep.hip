@@ -568,7 +568,17 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     }
     const int bpc = ctx->sweep_blocks_per_cu > 0 ? ctx->sweep_blocks_per_cu : bpc_cache;
     int64_t nb64 = (ngroups + 3) / 4;
-    if (nb64 > (int64_t)ctx->cus * bpc) nb64 = (int64_t)ctx->cus * bpc;
+    // FEWER blocks than CUs (round 4, last session; profiles/r04c_sweep_grid_scan.log): at one 4-wave block per CU the 500-column sweep
+    // is faster with 13/16 of the CUs streaming — 208 of 256: 581 us per launch against 593-598 at 1e6 rows (6.91 TB/s against 6.75),
+    // 293.5 / 298.9 at 500 k, 147.7 / 151.1 at 250 k — and with 7/8 of them on short shards (224: 77.6 / 79.0 us at 125 k rows; 208: 77.9);
+    // 232 / 240 / 248 lie in between, 192 is slower again at 125 k rows, counts that are not a multiple of the 8 XCDs (245, 250, 253)
+    // are slower than their neighbours.  The pass is bound by HBM, not by the CUs: fewer concurrent streams reach the stacks in a
+    // better order.  Not so for the other streaming kernels (JCH_CUS scan: the 2000-column NIPALS passes, the bf16 sweep, K2p and
+    // the local fits of lwplsr want every CU).  JCH_SWEEP_NB=<blocks> overrides (=256: the former grid).
+    int64_t cap = (int64_t)ctx->cus * bpc;
+    if (KC == 4 && bpc == 1) cap = std::max<int64_t>(8, (((int64_t)ctx->cus * (n < (int64_t)1280 * ctx->cus ? 14 : 13)) / 16) & ~(int64_t)7);
+    if (const char *e_nb = getenv("JCH_SWEEP_NB")) { const int v = atoi(e_nb); if (v > 0) cap = std::min<int64_t>(v, (int64_t)ctx->cus * bpc); }
+    if (nb64 > cap) nb64 = cap;
     if (nb64 < 1) nb64 = 1;
     const int nb = (int)nb64;
     const int ldpart = (m + 7) & ~7;
