@@ -574,9 +574,11 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     // 232 / 240 / 248 lie in between, 192 is slower again at 125 k rows, counts that are not a multiple of the 8 XCDs (245, 250, 253)
     // are slower than their neighbours.  The pass is bound by HBM, not by the CUs: fewer concurrent streams reach the stacks in a
     // better order.  Not so for the other streaming kernels (JCH_CUS scan: the 2000-column NIPALS passes, the bf16 sweep, K2p and
-    // the local fits of lwplsr want every CU).  JCH_SWEEP_NB=<blocks> overrides (=256: the former grid).
+    // the local fits of lwplsr want every CU; nor for the narrow sweeps: p = 250 / 120 lose 5-10 % per 32 blocks taken away).  1000-column
+    // rows (KC = 8) behave like 500-column ones: 569 us per launch at 192-208 blocks against 582.6 at 256 (n = 500 k).
+    // JCH_SWEEP_NB=<blocks> overrides (=256: the former grid).
     int64_t cap = (int64_t)ctx->cus * bpc;
-    if (KC == 4 && bpc == 1) cap = std::max<int64_t>(8, (((int64_t)ctx->cus * (n < (int64_t)1280 * ctx->cus ? 14 : 13)) / 16) & ~(int64_t)7);
+    if ((KC == 4 || KC == 8) && bpc == 1) cap = std::max<int64_t>(8, (((int64_t)ctx->cus * (n < (int64_t)1280 * ctx->cus ? 14 : 13)) / 16) & ~(int64_t)7);
     if (const char *e_nb = getenv("JCH_SWEEP_NB")) { const int v = atoi(e_nb); if (v > 0) cap = std::min<int64_t>(v, (int64_t)ctx->cus * bpc); }
     if (nb64 > cap) nb64 = cap;
     if (nb64 < 1) nb64 = 1;
