@@ -421,7 +421,9 @@ int32_t jch_lv_split_begin_fit(jch_ctx *ctx, jch_small &s, double *gbuf, int p, 
 {
     s.gpart = gbuf;
     s.lvctr = reinterpret_cast<unsigned *>(gbuf + jch_lv_split_doubles(p, nlv) - 8);
-    JCH_HIP(ctx, hipMemsetAsync(s.lvctr, 0, 64, ctx->stream));
+    // (only the opt-in merged kernel reads the counter: the default path saves the launch)
+    const char *e_mg = getenv("JCH_LV_MERGED");
+    if (e_mg && atoi(e_mg) == 1) JCH_HIP(ctx, hipMemsetAsync(s.lvctr, 0, 64, ctx->stream));
     return JCH_OK;
 }
 
