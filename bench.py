@@ -479,12 +479,18 @@ def main():
                     ctx.p2p_enable(False)
                 except Exception:  # noqa: BLE001
                     pass
-    ctx.set_profiling(True)        # HIP events on the ctx stream around every sweep launch
+    # HIP events on the ctx stream around the sweep launches — SAMPLED: an event record costs the stream about 3 us (50 per fit were
+    # 0.16 ms: 1 % of a cfg2 fit, 6 % of a 125 k-row share — tools/prof_overhead.py), so the timed fits bracket every PROF_STRIDE-th
+    # launch only (the counter runs across fits: 6 is coprime to nlv = 25, every LV's sweep is timed in turn).  JCH_BENCH_PROF_STRIDE=1
+    # brackets every launch as before.
+    PROF_STRIDE = max(1, min(int(os.environ.get("JCH_BENCH_PROF_STRIDE", "6")), nlv))   # (<= nlv: every fit has a bracketed launch)
+    ctx.set_profiling(PROF_STRIDE if PROF_STRIDE > 1 else True)
     for _ in range(args.warmup):
         step()
     sweep_ms = 0.0; sweep_launches = 0; fit_ms = 0.0; prologue_ms = 0.0; small_ms = 0.0
     coll_ms = 0.0; coll_wait_ms = 0.0; coll_pro_ms = 0.0; coll_calls = 0; coll_tr = 0
     barrier()
+    timed0 = ctx.counter(_lib.COUNTER_SWEEPS_TIMED)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -496,6 +502,7 @@ def main():
         sweep_bytes = pr.sweep_bytes
     barrier()
     dt = time.perf_counter() - t0
+    sweeps_timed = ctx.counter(_lib.COUNTER_SWEEPS_TIMED) - timed0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=fdev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -545,7 +552,7 @@ def main():
         # ---- this rank's shard fitted with NO communicator on the same GPU: what the fit would cost if collectives were free
         if not args.no_rank_share:
             solo = J.Context(local_rank, stream="torch")
-            solo.set_profiling(True)
+            solo.set_profiling(PROF_STRIDE if PROF_STRIDE > 1 else True)   # (the same event sampling as the timed fits)
             step(solo)
             torch.cuda.synchronize(); ts = time.perf_counter()
             reps = max(2, min(args.steps, 5)); sfit = 0.0; ssmall = 0.0
@@ -599,6 +606,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if (bf16 or args.algo not in ("plskern", "plsnipals")) else pmc_traffic(args.algo, n, p),
                          "traffic_source": PMC_FILE + ": committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of this kernel at this shape, scaled by rows; NOT measured in this run",
                          "bytes_per_launch": sweep_bytes, "avg_launch_ms": avg_sweep_s * 1e3, "launches": sweep_launches,
+                         "launches_timed": sweeps_timed if (sweeps_timed and PROF_STRIDE > 1) else sweep_launches,
+                         "timing": (f"HIP events on the launch stream around every {PROF_STRIDE}-th sweep launch of the timed fits (an event record costs the stream ~3 us; "
+                                    "JCH_BENCH_PROF_STRIDE=1 brackets all of them); avg_launch_ms = mean over launches_timed") if (sweeps_timed and PROF_STRIDE > 1)
+                                   else "HIP events on the launch stream around every launch of the dominant kernel in the timed fits",
                          **fit_roofline}),
             "device_ms_per_step": {"fit": fit_ms / args.steps, "prologue": prologue_ms / args.steps,
                                    "sweeps": sweep_ms / args.steps, "small_state_and_gaps": small_ms / args.steps,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JCH_VERSION 107 /* 0.1.7: JCH_REUSE_XCOPY, JCH_COUNTER_XCOPY_REUSED; 0.1.6: + jch_score_sums_lv, jch_predict over an nlv range as running sums over the scores; 0.1.5: screened kNN (JCH_COUNTER_KNN_SCREENED / _REDONE); 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
+#define JCH_VERSION 108 /* 0.1.8: jch_ctx_set_profiling(ctx, N > 1) samples the sweeps, JCH_COUNTER_SWEEPS_TIMED; 0.1.7: JCH_REUSE_XCOPY, JCH_COUNTER_XCOPY_REUSED; 0.1.6: + jch_score_sums_lv, jch_predict over an nlv range as running sums over the scores; 0.1.5: screened kNN (JCH_COUNTER_KNN_SCREENED / _REDONE); 0.1.4: no shape limits (generic lwplsr / small-state paths), JCH_NIPALS_ONE_PASS, JCH_COUNTER_LOCW_REFITS; 0.1.3: + jch_lwplsr_add_query_map (0.1.2: collective fields of jch_profile, jch_ctx_allreduce_probe, jch_lwplsr_prepare / _release) */
 
 #if defined(JCH_BUILD)
 #define JCH_API __attribute__((visibility("default")))
@@ -345,7 +345,10 @@ typedef struct jch_profile {
 #define JCH_TRANSPORT_INBOX_FUSED 3 /* inbox exchange inside the small-state kernel (no launch of its own)       */
 #define JCH_TRANSPORT_LOOPBACK 4    /* test harness                                                              */
 /* Enable (1) / disable (0) per-kernel HIP-event timing of subsequent fits (adds event records on the
- * ctx stream, no host syncs inside the fit). */
+ * ctx stream, no host syncs inside the fit).  enable = N > 1: the plskern-shaped sweeps (Float64 p <= 1024 and bf16) are SAMPLED —
+ * an event pair around every N-th launch only, counted across fits (an event record costs the stream about 3 us: 50 of them are
+ * 1 % of a cfg2 fit and 6 % of a 125 k-row share); jch_profile then reports sweep_ms = the sampled launches' mean x the launches
+ * made, sweep_launches = the launches made; JCH_COUNTER_SWEEPS_TIMED counts the launches actually bracketed. */
 JCH_API int32_t jch_ctx_set_profiling(jch_ctx *ctx, int32_t enable);
 JCH_API int32_t jch_ctx_get_profile(const jch_ctx *ctx, jch_profile *out);
 
@@ -380,6 +383,8 @@ JCH_API int32_t jch_ctx_allreduce_probe(jch_ctx *ctx, int32_t transport, double 
 #define JCH_COUNTER_KNN_SCREEN_REDONE 3
 /* which = JCH_COUNTER_XCOPY_REUSED: fits that honoured JCH_REUSE_XCOPY, i.e. took X'D[Yc | 1] from the previous fit's row-major copy */
 #define JCH_COUNTER_XCOPY_REUSED 4
+/* which = JCH_COUNTER_SWEEPS_TIMED: launches of the plskern-shaped sweep that were bracketed by HIP events (jch_ctx_set_profiling) */
+#define JCH_COUNTER_SWEEPS_TIMED 5
 JCH_API int32_t jch_ctx_get_counter(const jch_ctx *ctx, int32_t which, int64_t *out);
 
 #ifdef __cplusplus

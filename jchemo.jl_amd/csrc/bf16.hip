@@ -1099,9 +1099,10 @@ static int32_t launch_sweep_bf16_v2_t(jch_ctx *ctx, const bf16_t *Xr, int64_t n,
     const int m = ldr_b + 2, ldpart = (m + 7) & ~7;
     JCH_TRY(jch_reserve(ctx, ctx->part, sizeof(double) * (size_t)nb * ldpart));
     double *part = (double *)ctx->part.ptr;
-    (void)jch_ev(ctx);
+    const bool timed = jch_prof_sample(ctx);
+    if (timed) (void)jch_ev(ctx);
     hipLaunchKernelGGL((k_sweep_bf16_v2<KC, R, NBUF>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr_b, d, rvec, mom, scl, p, tcol, part, ldpart);
-    (void)jch_ev(ctx);
+    if (timed) (void)jch_ev(ctx);
     if (pv) { pv->part = part; pv->nb = nb; pv->ldpart = ldpart; *nslice = 1; JCH_HIP(ctx, hipGetLastError()); return JCH_OK; }
     JCH_TRY(jch_launch_reduce_part8(ctx, part, nb, ldpart, m, zt8, ldzb, nslice));
     JCH_HIP(ctx, hipGetLastError());

@@ -354,6 +354,7 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
             pr.prologue_ms = ctx->ev_mark > 0 ? ev_ms(evb, ctx->ev_pool[ctx->ev_mark - 1]) : 0.0;
             double sw = 0.0; int cnt = 0;
             for (size_t i = ctx->ev_mark; i + 1 < ev_last; i += 2) { sw += ev_ms(ctx->ev_pool[i], ctx->ev_pool[i + 1]); ++cnt; }
+            if (ctx->prof_stride > 1 && cnt > 0 && cnt < nlvb) { sw = sw * (double)nlvb / (double)cnt; cnt = nlvb; }   // sampled sweeps, see fit_impl's own block
             pr.sweep_ms = sw; pr.sweep_launches = cnt; pr.nlv = nlvb;
             pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
             pr.sweep_bytes = (double)n * ((p + 7) & ~7) * 2.0 + 16.0 * (double)n;
@@ -623,8 +624,11 @@ int32_t fit_impl(jch_ctx *ctx, const fit_io &io, int algo, bool allow_raw = true
         // events between sweep_ev0 and sweep_ev1 come in (begin,end) pairs recorded by the sweep/deflate launchers
         double sw = 0.0; int cnt = 0;
         for (size_t i = sweep_ev0; i + 1 < sweep_ev1; i += 2) { sw += ev_ms(ctx->ev_pool[i], ctx->ev_pool[i + 1]); ++cnt; }
+        // sampled sweeps (jch_ctx_set_profiling(ctx, N > 1)): cnt of the nlv launches were bracketed — their mean stands for the rest
+        const bool sampled = kern_like && !variant2 && ctx->prof_stride > 1;
+        if (sampled) sw = cnt > 0 ? sw * (double)nlv / (double)cnt : 0.0;
         pr.sweep_ms = sw;
-        pr.sweep_launches = variant2 ? 1 : (kern_like ? cnt : nlv);
+        pr.sweep_launches = variant2 ? 1 : (kern_like ? (sampled ? (cnt > 0 ? nlv : 0) : cnt) : nlv);
         pr.smallstate_ms = pr.fit_ms - pr.prologue_ms - sw;
         const double per_x = (double)n * ldr * 8.0;
         // plsnipals-shaped loops: average per LV of the passes actually made (eager: 2 reads + 1 write; postponed

@@ -72,6 +72,9 @@ struct jch_ctx {
     jch_buf gram, xr, yr, xstage, ystage, wstage, tbuf, dnorm, part, kpart, small, colpart, gemm_b, gemm_out, xq, tickets, qz, lw_work, lw_xrm, lvws, lw_flags, lw_screen;
     // profiling
     bool profiling = false;
+    int prof_stride = 1;        // jch_ctx_set_profiling(ctx, N > 1): event pairs around every N-th launch of the sampled dominant kernels only
+    unsigned prof_seq = 0;
+    int64_t sweeps_timed = 0;   // JCH_COUNTER_SWEEPS_TIMED
     jch_profile prof{};
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -134,6 +137,7 @@ struct jch_span {
     hipEvent_t a = nullptr, b = nullptr;
 };
 hipEvent_t jch_ev(jch_ctx *ctx);  // nullptr when profiling is off
+bool jch_prof_sample(jch_ctx *ctx);   // profiling on and this launch of a sampled dominant kernel is one to bracket with events
 void jch_coll_begin(jch_ctx *ctx);   // profiling: event in front of / behind an all-reduce call (ctx.hip)
 void jch_coll_end(jch_ctx *ctx);
 void jch_coll_reset(jch_ctx *ctx);   // start of a fit: forget the pairs, zero the inbox tick counters

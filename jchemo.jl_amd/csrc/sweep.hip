@@ -596,7 +596,8 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     const bool fused = e_fr && atoi(e_fr) == 1;
     int *tickets = nullptr;
     if (fused) JCH_TRY(jch_sweep_tickets(ctx, &tickets));
-    (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
+    const bool timed = jch_prof_sample(ctx);
+    if (timed) (void)jch_ev(ctx);  // profiling span of the dominant kernel (begin)
     // JCH_SWEEP_ALT=1: default-policy loads + the row groups walked in alternating directions, launch by launch (see k_sweep_v2)
     const char *e_alt = getenv("JCH_SWEEP_ALT");
     const int alt = e_alt ? atoi(e_alt) : 0;
@@ -607,7 +608,7 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
     } else
     hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF, true>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
                        tickets, zt, ldz, fused ? nslice : 0, 0);
-    (void)jch_ev(ctx);  // (end)
+    if (timed) (void)jch_ev(ctx);  // (end)
     if (pv && !fused) {   // split small-state path: k_lv_spread sums the block partials itself (no k_reduce_part launch)
         pv->part = part; pv->nb = nb; pv->ldpart = ldpart;
         *nslice_out = 1;

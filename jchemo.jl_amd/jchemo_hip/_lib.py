@@ -50,6 +50,7 @@ class Profile(C.Structure):
 
 
 TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_INBOX, TRANSPORT_INBOX_FUSED, TRANSPORT_LOOPBACK = 0, 1, 2, 3, 4
+COUNTER_PIVOT_REFITS, COUNTER_LOCW_REFITS, COUNTER_KNN_SCREENED, COUNTER_KNN_SCREEN_REDONE, COUNTER_XCOPY_REUSED, COUNTER_SWEEPS_TIMED = range(6)   # include/jchemo_hip.h JCH_COUNTER_*
 TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "inbox kernel", 3: "inbox fused into the small-state kernel", 4: "loopback (test harness)"}
 
 
@@ -176,7 +177,9 @@ class Context:
     def p2p_enable(self, on: bool):
         self.check(load().jch_ctx_p2p_enable(self._h, int(on)))
 
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """on = True / False; an integer N > 1 samples the plskern-shaped sweeps: events around every N-th launch only
+        (include/jchemo_hip.h jch_ctx_set_profiling)."""
         self.check(load().jch_ctx_set_profiling(self._h, int(on)))
 
     def counter(self, which: int = 0) -> int:

@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     assert sorted(J.SYMBOLS) == names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.jch_version() == 107
+    assert lib.jch_version() == 108
 
 
 def test_no_cpu_fallback_without_gpu():

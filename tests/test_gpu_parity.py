@@ -187,6 +187,35 @@ def test_generator_matches_oracle(J, ctx):
     assert np.array_equal(out.cpu().numpy(), O.rand_matrix(42, n, p, row0=11, n_total=5000))
 
 
+def test_sampled_profiling_of_the_sweeps(J):
+    """jch_ctx_set_profiling(ctx, N > 1) (include/jchemo_hip.h): event pairs around every N-th launch of the plskern-shaped sweep only
+    — an event record costs the stream ~3 us, and bench.py's timed fits should not pay 50 of them.  The profile then reports the
+    sampled launches' mean x the launches made: same fields, same results, a sum that agrees with the fully bracketed fit's."""
+    import torch
+    from jchemo_hip import _lib
+    n, p, q, nlv = 40000, 500, 3, 10
+    c = J.Context(0, stream="torch")
+    X = J.colmajor_empty(n, p); Y = J.colmajor_empty(n, q)
+    c.check(J.load().jch_fill_uniform(c._h, X.data_ptr(), n, p, n, 0, n, 5)); c.check(J.load().jch_fill_uniform(c._h, Y.data_ptr(), n, q, n, 0, n, 6))
+    c.set_profiling(True)
+    J.plskern(X, Y, nlv=nlv, ctx=c)
+    t0 = c.counter(_lib.COUNTER_SWEEPS_TIMED)
+    fm_all = J.plskern(X, Y, nlv=nlv, ctx=c); pr_all = c.profile()
+    assert c.counter(_lib.COUNTER_SWEEPS_TIMED) - t0 == nlv and pr_all.sweep_launches == nlv
+    c.set_profiling(3)
+    t0 = c.counter(_lib.COUNTER_SWEEPS_TIMED)
+    fm_s = J.plskern(X, Y, nlv=nlv, ctx=c); pr_s = c.profile()
+    timed = c.counter(_lib.COUNTER_SWEEPS_TIMED) - t0
+    assert 3 <= timed <= 4 and pr_s.sweep_launches == nlv                                  # every third of ten launches
+    assert 0.6 * pr_all.sweep_ms < pr_s.sweep_ms < 1.6 * pr_all.sweep_ms                    # (short launches on a shared box: a loose band)
+    assert abs(pr_s.fit_ms - pr_s.prologue_ms - pr_s.sweep_ms - pr_s.smallstate_ms) < 1e-9
+    assert np.array_equal(fm_all.TT, fm_s.TT) and np.array_equal(fm_all.P, fm_s.P)         # timing never touches results
+    c.set_profiling(False)
+    J.plskern(X, Y, nlv=nlv, ctx=c)
+    assert c.counter(_lib.COUNTER_SWEEPS_TIMED) - t0 == timed
+    c.close()
+
+
 def test_rccl_single_rank_plumbing(J):
     """World size 1: exercises dlopen(librccl), ncclCommInitRank and the all-reduce call sites."""
     c = J.Context(0)
