@@ -32,7 +32,7 @@ import ctypes as C
 import json
 import os
 import sys
-import time
+import math, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "jchemo.jl_amd")):
@@ -484,25 +484,38 @@ def main():
     # launch only (the counter runs across fits: 6 is coprime to nlv = 25, every LV's sweep is timed in turn).  JCH_BENCH_PROF_STRIDE=1
     # brackets every launch as before.
     PROF_STRIDE = max(1, min(int(os.environ.get("JCH_BENCH_PROF_STRIDE", "6")), nlv))   # (<= nlv: every fit has a bracketed launch)
+    if rehearsal and "JCH_BENCH_PROF_STRIDE" not in os.environ:
+        PROF_STRIDE = 1   # ranks time-slicing ONE GPU: a sweep launch takes anything between 1 x and world x its own time, a sampled mean says nothing about the sum
+    while PROF_STRIDE > 1 and math.gcd(PROF_STRIDE, nlv) != 1:   # coprime to nlv: over PROF_STRIDE consecutive fits every LV's sweep is bracketed exactly once
+        PROF_STRIDE -= 1                                          # (a stride dividing nlv would time the SAME LVs in every fit - the first sweep after the prologue is 10 % slower than the rest)
     ctx.set_profiling(PROF_STRIDE if PROF_STRIDE > 1 else True)
     for _ in range(args.warmup):
         step()
     sweep_ms = 0.0; sweep_launches = 0; fit_ms = 0.0; prologue_ms = 0.0; small_ms = 0.0
     coll_ms = 0.0; coll_wait_ms = 0.0; coll_pro_ms = 0.0; coll_calls = 0; coll_tr = 0
     barrier()
-    timed0 = ctx.counter(_lib.COUNTER_SWEEPS_TIMED)
+    timed0 = timed_prev = ctx.counter(_lib.COUNTER_SWEEPS_TIMED); raw_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         pr = ctx.profile()     # host-side read of already-recorded events (the fit call is blocking)
-        sweep_ms += pr.sweep_ms; sweep_launches += pr.sweep_launches; fit_ms += pr.fit_ms
-        prologue_ms += pr.prologue_ms; small_ms += pr.smallstate_ms
+        sweep_launches += pr.sweep_launches; fit_ms += pr.fit_ms; prologue_ms += pr.prologue_ms
+        if PROF_STRIDE > 1 and pr.sweep_launches > 0:
+            # sampled events: jch_profile.sweep_ms is THIS fit's estimate (mean of its bracketed launches x launches made); undo the scaling and keep the
+            # bracketed launches' own sum, so that the mean below is over all bracketed launches of the timed region with equal weights
+            timed1 = ctx.counter(_lib.COUNTER_SWEEPS_TIMED)
+            raw_ms += pr.sweep_ms * (timed1 - timed_prev) / pr.sweep_launches; timed_prev = timed1
+        else:
+            sweep_ms += pr.sweep_ms; small_ms += pr.smallstate_ms
         coll_ms += pr.collective_ms; coll_wait_ms += pr.collective_wait_ms; coll_pro_ms += pr.prologue_collective_ms
         coll_calls += pr.collective_calls; coll_tr = pr.collective_transport
         sweep_bytes = pr.sweep_bytes
     barrier()
     dt = time.perf_counter() - t0
     sweeps_timed = ctx.counter(_lib.COUNTER_SWEEPS_TIMED) - timed0
+    if PROF_STRIDE > 1 and sweeps_timed > 0:   # mean over the bracketed launches x the launches made; the rest of a fit is what the sweeps leave
+        sweep_ms = raw_ms / sweeps_timed * sweep_launches
+        small_ms = fit_ms - prologue_ms - sweep_ms
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=fdev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
