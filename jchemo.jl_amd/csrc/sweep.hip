@@ -605,9 +605,21 @@ static int32_t launch_sweep_v2_t(jch_ctx *ctx, const double *Xr, int64_t n, int 
         const int rev = alt == 2 ? 0 : (int)(ctx->sweep_seq++ & 1u);   // (=2: default-policy loads, one direction — A/B runs)
         hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF, false>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
                            tickets, zt, ldz, fused ? nslice : 0, rev);
-    } else
+    } else {
+    // The FIRST sweep of a fit runs right behind the prologue, whose last ~250 MB of the row-major copy still sit (dirty) in the memory-side
+    // cache: walked forwards it takes 0.65 ms at cfg2 against 0.573 for the other 24, walked BACKWARDS — it starts with what the prologue wrote
+    // last — 0.60 (profiles/r04d_first_sweep_reversed_ab.log: -50 us per cfg2 fit, -3..6 us at 125 k rows).  Same arithmetic, another order of
+    // the row groups within a block's partial sums for that one LV; every fit and every rank does the same, so repeated fits and the replicated
+    // state stay bit-identical.  JCH_SWEEP_FIRST_REV=0: forwards as before; =2: backwards with default-policy loads (measured SLOWER than either).
+    static const int first_rev_mode = [] { const char *e = getenv("JCH_SWEEP_FIRST_REV"); return e ? atoi(e) : 1; }();
+    const bool first = ctx->sweep_seq++ == 0u;
+    if (first && first_rev_mode == 2)
+        hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF, false>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
+                           tickets, zt, ldz, fused ? nslice : 0, 1);
+    else
     hipLaunchKernelGGL((k_sweep_v2<KC, R, NBUF, true>), dim3(nb), dim3(256), lds, ctx->stream, Xr, n, ldr, d, rvec, tcol, part, ldpart, mu,
-                       tickets, zt, ldz, fused ? nslice : 0, 0);
+                       tickets, zt, ldz, fused ? nslice : 0, first && first_rev_mode == 1 ? 1 : 0);
+    }
     if (timed) (void)jch_ev(ctx);  // (end)
     if (pv && !fused) {   // split small-state path: k_lv_spread sums the block partials itself (no k_reduce_part launch)
         pv->part = part; pv->nb = nb; pv->ldpart = ldpart;
