@@ -222,7 +222,7 @@ struct jch_small {  // device-resident replicated small state of one fit
     double *dbg;        // [nlv + 1] diagnostics (JCH_LV_DEBUG): Jacobi sweeps per LV; may be null
     double *niter;      // [nlv] plswold: inner iterations per LV (src/plswold.jl:93); null otherwise
     double *kr;         // [16] split small-state path (smallstate_split.hip): K' r of the current LV; null otherwise
-    double *gpart;      // [blocks][gld] split path: per-block partials of K_new'K_new, zp'K_new and P_i . zp; null otherwise
+    double *gpart;      // [blocks][gld] split path: per-block partials of K_new'K_new, zp'K_new and P_i'K_new; null otherwise
     unsigned *lvctr;    // split path, merged kernel: arrival counter of the fit's blocks (zeroed when a fit starts); null otherwise
 };
 

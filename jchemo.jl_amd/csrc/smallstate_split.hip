@@ -7,7 +7,8 @@
 //         K    <- K - zp c'                 (16 x 16 entries per block, one per thread)
 //         P_a   = zp / tt,  W_a = w,  R_a = r                     (src/plskern.jl:168-174)
 //       and the PARTIALS of the three quantities the second kernel needs summed over p:
-//         s_i   = P_i . zp  (i < a)        -> Z_i <- Z_i - s_i c'   (Z = P'K, the state of the r-recursion, smallstate_fast.hip)
+//         P_i' K_new (i < a, 16 columns)  -> Z_i = their sum over the blocks (Z = P'K, the state of the r-recursion, smallstate_fast.hip) — the DIRECT
+//                                          form since the end of round 4: the update Z_i - (P_i . zp) c' kept eps |K_0| of rounding error while K shrinks
 //         Z_a   = zp' K_new / tt
 //         G     = K_new' K_new             (16 x 16 Gram matrix: the input of the dominant-direction step, :150-155)
 //   k_lv_solve   (ONE 512-thread block) sums the 32 partial Gram matrices / Z rows, finds the dominant eigenvector v of G on
@@ -27,7 +28,7 @@
 
 #define SP_NT 256
 #define SP_RB 16          // partial rows per thread and load batch of k_lv_spread
-#define SP_GP 272          // doubles per block in gpart before the s_i: 256 Gram entries + 16 of zp' K_new
+#define SP_GP 272          // doubles per block in gpart before the 16-column partials of P_i' K_new: 256 Gram entries + 16 of zp' K_new
 
 struct lvs_args {
     jch_small s;
@@ -177,16 +178,26 @@ __device__ __forceinline__ bool spread_body(const lvs_args &g, const int tid)
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) s += zpl[jj] * Knl[jj][tid];
         gp[256 + tid] = s;
-    } else if (act && ipre < a) {   // partial of P_i . zp
-        double s = 0.0;
+    } else if (act && ipre < a) {   // partial of Z_i = P_i' K_new (the DIRECT form: see the header of this file), 16 columns
+        double zi[16];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) s += pre[jj] * zpl[jj];       // (zpl is zero beyond p)
-        gp[SP_GP + ipre] = s;
+        for (int k = 0; k < 16; ++k) zi[k] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) zi[k] += pre[jj] * Knl[jj][k];   // (rows beyond p of Knl are zero)
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gp[SP_GP + 16 * ipre + k] = zi[k];
     }
     for (int i = ipre + (SP_NT - 16); ipre >= 0 && i < a; i += SP_NT - 16) {   // (more than 240 finished LVs)
-        double s = 0.0;
-        for (int jj = 0; jj < 16; ++jj) s += g.s.P[(size_t)i * p + min(j0 + jj, p - 1)] * zpl[jj];
-        gp[SP_GP + i] = s;
+        double zi[16];
+        for (int k = 0; k < 16; ++k) zi[k] = 0.0;
+        for (int jj = 0; jj < 16; ++jj) {
+            const double pj = j0 + jj < p ? g.s.P[(size_t)i * p + j0 + jj] : 0.0;
+            for (int k = 0; k < 16; ++k) zi[k] += pj * Knl[jj][k];
+        }
+        for (int k = 0; k < 16; ++k) gp[SP_GP + 16 * i + k] = zi[k];
     }
     if (g.s.dbg && tid == 0 && blockIdx.x == 0) g.s.dbg[512 + 16 * (a + 1) + 7] = (double)__builtin_readcyclecounter();
     return true;
@@ -225,8 +236,7 @@ __device__ __forceinline__ void solve_body(const lvs_args &g, double *lds, const
     // outlasted it at the late LVs; small state 0.51 -> 0.555 ms per fit.)
     const double cpre = tid < q ? g.s.C[(size_t)a * q + tid] : 0.0;
     const double tt = g.s.TT[a];
-    const double zpre = tid < a * QP ? g.s.Z[tid] : 0.0;
-    const int nent = SP_GP + a;
+    const int nent = SP_GP;
     double gacc = 0.0;
     {
         const int e = min(tid, nent - 1);
@@ -253,14 +263,6 @@ __device__ __forceinline__ void solve_body(const lvs_args &g, double *lds, const
         if ((tid >> 4) < QP && (tid & 15) < QP) G0[(tid >> 4) * lda + (tid & 15)] = gacc;
         if ((tid & 15) == 0 && (tid >> 4) < QP) { G0[(tid >> 4) * lda + QP] = 0.0; G0[(tid >> 4) * lda + QP + 1] = 0.0; }
     } else if (tid < SP_GP) zal[tid - 256] = gacc;
-    else if (tid < nent) sl[tid - SP_GP] = gacc;
-    for (int e = tid + FT; e < nent; e += FT) {   // (more than 240 finished LVs)
-        double s = 0.0;
-        for (int b = 0; b < g.nblk; ++b) s += g.s.gpart[(size_t)b * g.gld + e];
-        sl[e - SP_GP] = s;
-    }
-    if (tid < a * QP) Zl[tid] = zpre;
-    for (int e = tid + FT; e < a * QP; e += FT) Zl[e] = g.s.Z[e];
     __syncthreads();
     // the loads the tail needs go out only NOW: a barrier waits for every outstanding load of the wave
     double rreg[32];   // R[i][tid], i < min(an, 32)   (tail)
@@ -292,8 +294,20 @@ __device__ __forceinline__ void solve_body(const lvs_args &g, double *lds, const
                 if (e < tot && (e & 15) < QP) Kl[(e >> 4) * ldk + (e & 15)] = kr[i];
             }
         }
-        for (int e = wt; e < a * QP; e += WT) {   // Z_i <- Z_i - s_i c'  (i < a)
-            const double z = Zl[e] - sl[e / QP] * cl[e & (QP - 1)];
+        // Z_i = P_i' K_new (i < a) as the sum of the blocks' partials, fixed order — NOT the update Z_i - (P_i . zp) c': that one keeps
+        // rounding errors of size eps |K_0| while K shrinks, and r = (K v - R (Z v)) / |K v| then loses eps |K_0| / |K_a| (six digits of
+        // T'DT = diag(TT) on a PLS1 fit whose K falls by 1e8: tools/z_recurrence_drift.py)
+        for (int e = wt; e < a * QP; e += WT) {
+            const size_t off = (size_t)SP_GP + 16 * (size_t)(e / QP) + (size_t)(e & (QP - 1));
+            double z = 0.0;
+            if ((e & (QP - 1)) < q) {   // (pad columns of K are exactly zero: no loads for them)
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = g.s.gpart[(size_t)min(u, g.nblk - 1) * g.gld + off];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) z += u < g.nblk ? v[u] : 0.0;
+            }
+            for (int b = 32; b < g.nblk && (e & (QP - 1)) < q; ++b) z += g.s.gpart[(size_t)b * g.gld + off];
             Zl[e] = z;
             g.s.Z[e] = z;
         }
@@ -412,7 +426,7 @@ __global__ __launch_bounds__(FT) void k_lv_merged(lvs_args g)
 static int qp_of(int q) { return q <= 1 ? 1 : (q <= 2 ? 2 : (q <= 4 ? 4 : (q <= 8 ? 8 : 16))); }
 
 int jch_lv_split_blocks(int p) { return (p + 15) / 16; }
-int jch_lv_split_gld(int nlv) { return (SP_GP + nlv + 7) & ~7; }
+int jch_lv_split_gld(int nlv) { return (SP_GP + 16 * nlv + 7) & ~7; }
 // doubles of jch_small::gpart: the block partials + 8 for the merged kernel's arrival counter (jch_small::lvctr)
 size_t jch_lv_split_doubles(int p, int nlv) { return (size_t)jch_lv_split_blocks(p) * jch_lv_split_gld(nlv) + 8; }
 // carve the split path's buffers out of `gbuf` (jch_lv_split_doubles(p, nlv) doubles); the arrival counter starts every fit at zero

@@ -1622,13 +1622,11 @@ def test_split_small_state_matches_one_kernel_path(shape, variant, J, ctx, monke
     # invariants on ALL LVs: T'DT = diag(TT), R'P = I
     d = fm.weights
     G = (fm.T * d[:, None]).T @ fm.T
-    # Seven of the eight shapes hold this to <= 2e-13 in every variant.  The PLS1 shape (n = 900, p = 37, q = 1, nlv = 12) sits at
-    # 2e-10 ... 1.1e-9 depending on the ORDER of the sweeps' partial sums (profiles/r04d_invariant_probe.txt: forwards-walked first
-    # sweep 2.9e-10 / 7.9e-10 / 7.9e-10, backwards-walked 4.0e-10 / 1.8e-10 / 1.13e-9 for raw / scal_w / centred) where the oracle holds
-    # 2e-15: K shrinks by orders of magnitude over the 12 LVs of that fit and Z = P'K is carried by the incremental update of DESIGN §5,
-    # whose rounding errors stay at eps |K_0| (DESIGN §9 has the direct form as the next step).  Inside the 1e-6 of the north star; the bound
-    # here says "no worse than that", not "as good as the reference".
-    assert np.abs(G - np.diag(fm.TT)).max() < 3e-9 * np.abs(fm.TT).max()
+    # Since the end of round 4 the split path carries Z = P'K in its DIRECT form (Z_i = P_i'K_new summed over the blocks): every shape
+    # and variant holds this to <= 7e-16 (profiles/r04f_invariant_probe.txt).  With the incremental update Z_i - (P_i.zp) c' the PLS1 shape
+    # (n = 900, p = 37, q = 1, nlv = 12: K falls by 1e8 over the fit) sat at 2e-10 ... 1.1e-9 where the oracle holds 2e-15
+    # (profiles/r04d_invariant_probe.txt, tools/z_recurrence_drift.py) — the bound below pins the direct form.
+    assert np.abs(G - np.diag(fm.TT)).max() < 1e-12 * np.abs(fm.TT).max()
     assert np.abs(fm.R.T @ fm.P - np.eye(k)).max() < 1e-8
 
 
