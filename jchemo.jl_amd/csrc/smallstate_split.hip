@@ -28,6 +28,7 @@
 
 #define SP_NT 256
 #define SP_RB 16          // partial rows per thread and load batch of k_lv_spread
+#define SP_PL 32           // finished LVs whose P slice is staged in LDS for the partials of P_i' K_new (later ones: one thread per LV)
 #define SP_GP 272          // doubles per block in gpart before the 16-column partials of P_i' K_new: 256 Gram entries + 16 of zp' K_new
 
 struct lvs_args {
@@ -57,6 +58,7 @@ __device__ __forceinline__ bool spread_body(const lvs_args &g, const int tid)
     __shared__ double tot[18];
     __shared__ double zpl[16], cl[16];
     __shared__ double Knl[16][17];
+    __shared__ double Pl[SP_PL][17];   // P_i[j0 .. j0 + 15] of the first SP_PL finished LVs: the Z partials below run one entry per thread
     const bool act = !WIDE || tid < SP_NT;
     const int col = tid & 15, gr = (tid >> 4) & 15;
     const int p = g.p, a = g.a, j0 = blockIdx.x * 16;
@@ -161,6 +163,10 @@ __device__ __forceinline__ bool spread_body(const lvs_args &g, const int tid)
         const double kn = kold - zpl[gr] * cl[col];
         if (live) g.s.K[(size_t)(j0 + gr) * 16 + col] = kn;
         Knl[gr][col] = live ? kn : 0.0;
+        if (ipre >= 0 && ipre < min(a, SP_PL)) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) Pl[ipre][jj] = pre[jj];
+        }
     }
     __syncthreads();
     double *gp = g.s.gpart + (size_t)blockIdx.x * g.gld;
@@ -178,7 +184,7 @@ __device__ __forceinline__ bool spread_body(const lvs_args &g, const int tid)
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) s += zpl[jj] * Knl[jj][tid];
         gp[256 + tid] = s;
-    } else if (act && ipre < a) {   // partial of Z_i = P_i' K_new (the DIRECT form: see the header of this file), 16 columns
+    } else if (act && ipre >= SP_PL && ipre < a) {   // partial of Z_i = P_i' K_new (the DIRECT form: see the header of this file), 16 columns
         double zi[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) zi[k] = 0.0;
@@ -189,6 +195,15 @@ __device__ __forceinline__ bool spread_body(const lvs_args &g, const int tid)
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) gp[SP_GP + 16 * ipre + k] = zi[k];
+    }
+    if (act) {   // the same partials for the first SP_PL finished LVs, one (i, column) entry per thread: same products in the same order
+        const int ne = min(a, SP_PL) * 16;
+        for (int e = tid; e < ne; e += SP_NT) {
+            double z = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) z += Pl[e >> 4][jj] * Knl[jj][e & 15];
+            gp[SP_GP + e] = z;
+        }
     }
     for (int i = ipre + (SP_NT - 16); ipre >= 0 && i < a; i += SP_NT - 16) {   // (more than 240 finished LVs)
         double zi[16];
